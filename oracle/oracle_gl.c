@@ -1,0 +1,451 @@
+/* TEST ORACLE - CPU restatement of the reference's Goldilocks hot path.
+ *
+ * Test infrastructure only (see gl.h).  Every function cites the reference file:line it follows
+ * (paths relative to /root/reference).  Pinned by: Poseidon-12 KATs, the serialized regression
+ * proof (all Merkle paths / PoW / FRI queries) and the circuit_digest KAT - see
+ * tests/test_oracle_*.py.  Parallelised with OpenMP the way the reference uses Rayon (over
+ * columns, over Merkle subtrees via recursive join) so that it can double as the "port" CPU
+ * baseline in bench.py.
+ */
+#include "gl.h"
+#include "poseidon_constants.h"
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define W 12
+#define RATE 8
+#define HOUT 4
+#define N_PARTIAL 22
+#define HALF_FULL 4
+
+static const uint64_t RC[GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN] = {GL_POSEIDON_ALL_ROUND_CONSTANTS_LIST};
+static const uint64_t MDS_CIRC[12] = {GL_POSEIDON_MDS_CIRC_LIST};
+static const uint64_t MDS_DIAG[12] = {GL_POSEIDON_MDS_DIAG_LIST};
+static const uint64_t FP_FIRST[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST};
+static const uint64_t FP_RC[22] = {GL_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS_LIST};
+static const uint64_t FP_VS[22][11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_VS_LIST};
+static const uint64_t FP_WHATS[22][11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_W_HATS_LIST};
+static const uint64_t FP_INIT[11][11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX_LIST};
+
+/* ------------------------------------------------------------------ Poseidon-12 */
+
+/* hash/poseidon_goldilocks.rs:840-846 */
+static inline gl_t sbox(gl_t x) {
+    gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
+    return gl_mul(x3, x4);
+}
+
+/* hash/poseidon_goldilocks.rs:547-557 (mds_row_shf_field) applied to all rows (:584-595).
+ * Entries are < 2^6 so the 12-term sum of 64x6-bit products fits 128 bits. */
+static void mds_layer(gl_t s[W]) {
+    gl_t out[W];
+    for (int r = 0; r < W; r++) {
+        unsigned __int128 acc = 0;
+        for (int i = 0; i < W; i++) acc += (unsigned __int128)s[(i + r) % W] * MDS_CIRC[i];
+        acc += (unsigned __int128)s[r] * MDS_DIAG[r];
+        out[r] = gl_reduce128(acc);
+    }
+    memcpy(s, out, sizeof out);
+}
+
+/* hash/poseidon_goldilocks.rs:802-809 */
+static inline void constant_layer(gl_t s[W], int round) {
+    for (int i = 0; i < W; i++) s[i] = gl_add(s[i], gl_canon(RC[i + W * round]));
+}
+
+/* hash/poseidon_goldilocks.rs:889-897 */
+static void full_rounds(gl_t s[W], int *round) {
+    for (int k = 0; k < HALF_FULL; k++) {
+        constant_layer(s, *round);
+        for (int i = 0; i < W; i++) s[i] = sbox(s[i]);
+        mds_layer(s);
+        (*round)++;
+    }
+}
+
+/* hash/poseidon_goldilocks.rs:927-948 (poseidon_naive: the defining form) */
+void gbo_gl_poseidon_naive(const gl_t in[W], gl_t out[W]) {
+    gl_t s[W];
+    memcpy(s, in, sizeof s);
+    int round = 0;
+    full_rounds(s, &round);
+    for (int k = 0; k < N_PARTIAL; k++) {
+        constant_layer(s, round);
+        s[0] = sbox(s[0]);
+        mds_layer(s);
+        round++;
+    }
+    full_rounds(s, &round);
+    memcpy(out, s, sizeof s);
+}
+
+/* hash/poseidon_goldilocks.rs:899-922 (the optimised form the reference actually runs;
+ * output-identical to the naive form, asserted by the reference at :1196-1198 and here in
+ * tests/test_oracle_kats.py).  partial_first_constant_layer :632-638, mds_partial_layer_init
+ * :657-683, mds_partial_layer_fast :718-744. */
+void gbo_gl_poseidon(const gl_t in[W], gl_t out[W]) {
+    gl_t s[W];
+    memcpy(s, in, sizeof s);
+    int round = 0;
+    full_rounds(s, &round);
+    for (int i = 0; i < W; i++) s[i] = gl_add(s[i], gl_canon(FP_FIRST[i]));
+    {
+        gl_t r[W];
+        r[0] = s[0];
+        for (int c = 1; c < W; c++) {
+            gl_t sum = 0;
+            for (int rr = 1; rr < W; rr++) sum = gl_add(sum, gl_mul(s[rr], gl_canon(FP_INIT[rr - 1][c - 1])));
+            r[c] = sum;
+        }
+        memcpy(s, r, sizeof r);
+    }
+    for (int k = 0; k < N_PARTIAL; k++) {
+        s[0] = sbox(s[0]);
+        s[0] = gl_add(s[0], gl_canon(FP_RC[k]));
+        gl_t d = gl_mul(s[0], MDS_CIRC[0] + MDS_DIAG[0]);
+        for (int i = 1; i < W; i++) d = gl_add(d, gl_mul(s[i], gl_canon(FP_WHATS[k][i - 1])));
+        gl_t r[W];
+        r[0] = d;
+        for (int i = 1; i < W; i++) r[i] = gl_add(s[i], gl_mul(s[0], gl_canon(FP_VS[k][i - 1])));
+        memcpy(s, r, sizeof r);
+    }
+    round += N_PARTIAL;
+    full_rounds(s, &round);
+    memcpy(out, s, sizeof s);
+}
+
+/* ------------------------------------------------------------------ sponge / compression */
+
+/* hash/hashing.rs:100-123 hash_n_to_m_no_pad with num_outputs = 4 (overwrite mode, rate 8) */
+void gbo_gl_hash_no_pad(const gl_t *in, size_t n, gl_t out[HOUT]) {
+    gl_t st[W] = {0};
+    for (size_t off = 0; off < n; off += RATE) {
+        size_t k = n - off < RATE ? n - off : RATE;
+        memcpy(st, in + off, k * sizeof(gl_t));
+        gbo_gl_poseidon(st, st);
+    }
+    memcpy(out, st, HOUT * sizeof(gl_t));
+}
+
+/* generic m-output squeeze (hash/hashing.rs:112-122) */
+void gbo_gl_hash_n_to_m_no_pad(const gl_t *in, size_t n, gl_t *out, size_t m) {
+    gl_t st[W] = {0};
+    for (size_t off = 0; off < n; off += RATE) {
+        size_t k = n - off < RATE ? n - off : RATE;
+        memcpy(st, in + off, k * sizeof(gl_t));
+        gbo_gl_poseidon(st, st);
+    }
+    size_t got = 0;
+    for (;;) {
+        for (int i = 0; i < RATE; i++) {
+            out[got++] = st[i];
+            if (got == m) return;
+        }
+        gbo_gl_poseidon(st, st);
+    }
+}
+
+/* plonk/config.rs:70-84 hash_or_noop: <= 4 elements are zero-padded, not hashed */
+void gbo_gl_hash_or_noop(const gl_t *in, size_t n, gl_t out[HOUT]) {
+    if (n <= HOUT) {
+        memset(out, 0, HOUT * sizeof(gl_t));
+        memcpy(out, in, n * sizeof(gl_t));
+    } else {
+        gbo_gl_hash_no_pad(in, n, out);
+    }
+}
+
+/* hash/hashing.rs:76-96 compress == Hasher::two_to_one (poseidon_goldilocks.rs:1108-1110) */
+void gbo_gl_two_to_one(const gl_t l[HOUT], const gl_t r[HOUT], gl_t out[HOUT]) {
+    gl_t st[W] = {0};
+    memcpy(st, l, HOUT * sizeof(gl_t));
+    memcpy(st + HOUT, r, HOUT * sizeof(gl_t));
+    gbo_gl_poseidon(st, st);
+    memcpy(out, st, HOUT * sizeof(gl_t));
+}
+
+/* ------------------------------------------------------------------ bit reversal */
+
+static inline size_t rev_bits(size_t x, unsigned bits) {
+    size_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+/* util/src/lib.rs:189-238 reverse_index_bits_in_place (semantics: swap i <-> bitrev(i)) */
+void gbo_reverse_index_bits_u64(uint64_t *a, unsigned lg_n) {
+    size_t n = (size_t)1 << lg_n;
+    for (size_t i = 0; i < n; i++) {
+        size_t j = rev_bits(i, lg_n);
+        if (i < j) { uint64_t t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+}
+
+/* ------------------------------------------------------------------ NTT */
+
+/* field/src/fft.rs:12-31 fft_root_table: row lg_m-1 holds powers of w_{2^lg_m}, max(half_m,2) entries */
+typedef struct { unsigned lg_n; gl_t **rows; } root_table_t;
+
+static root_table_t *root_table_new(unsigned lg_n) {
+    root_table_t *t = malloc(sizeof *t);
+    t->lg_n = lg_n;
+    t->rows = lg_n ? malloc(lg_n * sizeof(gl_t *)) : NULL;
+    for (unsigned lg_m = 1; lg_m <= lg_n; lg_m++) {
+        size_t half_m = (size_t)1 << (lg_m - 1);
+        size_t len = half_m < 2 ? 2 : half_m;
+        gl_t base = gl_two_adic_generator(lg_m);
+        gl_t *row = malloc(len * sizeof(gl_t));
+        gl_t x = 1;
+        for (size_t i = 0; i < len; i++) { row[i] = x; x = gl_mul(x, base); }
+        t->rows[lg_m - 1] = row;
+    }
+    return t;
+}
+static void root_table_free(root_table_t *t) {
+    for (unsigned i = 0; i < t->lg_n; i++) free(t->rows[i]);
+    free(t->rows);
+    free(t);
+}
+
+/* field/src/fft.rs:168-205 fft_classic + :98-160 fft_classic_simd (scalar instantiation):
+ * bit-reverse, zero-tail replication for the first r layers, then DIT layers r..lg_n. */
+static void fft_classic(gl_t *v, unsigned lg_n, unsigned r, const root_table_t *t) {
+    size_t n = (size_t)1 << lg_n;
+    gbo_reverse_index_bits_u64(v, lg_n);
+    if (r > 0) {
+        size_t mask = ~(((size_t)1 << r) - 1);
+        for (size_t i = 0; i < n; i++) v[i] = v[i & mask];
+    }
+    for (unsigned lg_half_m = r; lg_half_m < lg_n; lg_half_m++) {
+        size_t half_m = (size_t)1 << lg_half_m, m = half_m * 2;
+        const gl_t *om = t->rows[lg_half_m];
+        for (size_t k = 0; k < n; k += m)
+            for (size_t j = 0; j < half_m; j++) {
+                gl_t tt = gl_mul(om[j], v[k + half_m + j]);
+                gl_t u = v[k + j];
+                v[k + j] = gl_add(u, tt);
+                v[k + half_m + j] = gl_sub(u, tt);
+            }
+    }
+}
+
+/* fft_with_options (fft.rs:55-63); table==NULL -> built per call like fft_dispatch :39-46 */
+static void fft_opt(gl_t *v, unsigned lg_n, unsigned zero_factor, const root_table_t *table) {
+    if (lg_n == 0) return;
+    root_table_t *own = NULL;
+    if (!table) table = own = root_table_new(lg_n);
+    fft_classic(v, lg_n, zero_factor, table);
+    if (own) root_table_free(own);
+}
+
+void gbo_gl_fft(gl_t *v, unsigned lg_n, unsigned zero_factor) { fft_opt(v, lg_n, zero_factor, NULL); }
+
+/* field/src/fft.rs:70-94 ifft_with_options: forward transform, then reverse all but first and scale by 1/n */
+void gbo_gl_ifft(gl_t *v, unsigned lg_n) {
+    size_t n = (size_t)1 << lg_n;
+    gl_t n_inv = gl_pow(gl_inv(2), lg_n);
+    fft_opt(v, lg_n, 0, NULL);
+    v[0] = gl_mul(v[0], n_inv);
+    if (n > 1) v[n / 2] = gl_mul(v[n / 2], n_inv);
+    for (size_t i = 1; i < n / 2; i++) {
+        size_t j = n - i;
+        gl_t ci = gl_mul(v[j], n_inv), cj = gl_mul(v[i], n_inv);
+        v[i] = ci;
+        v[j] = cj;
+    }
+}
+
+/* field/src/polynomial/mod.rs:282-295 coset_fft_with_options: c_i *= shift^i, then fft */
+static void coset_fft_opt(gl_t *v, unsigned lg_n, gl_t shift, unsigned zero_factor, const root_table_t *t) {
+    size_t n = (size_t)1 << lg_n;
+    gl_t p = 1;
+    for (size_t i = 0; i < n; i++) { v[i] = gl_mul(v[i], p); p = gl_mul(p, shift); }
+    fft_opt(v, lg_n, zero_factor, t);
+}
+void gbo_gl_coset_fft(gl_t *v, unsigned lg_n, gl_t shift, unsigned zero_factor) {
+    coset_fft_opt(v, lg_n, shift, zero_factor, NULL);
+}
+
+/* field/src/polynomial/mod.rs:62-72 coset_ifft */
+void gbo_gl_coset_ifft(gl_t *v, unsigned lg_n, gl_t shift) {
+    size_t n = (size_t)1 << lg_n;
+    gbo_gl_ifft(v, lg_n);
+    gl_t si = gl_inv(shift), p = 1;
+    for (size_t i = 0; i < n; i++) { v[i] = gl_mul(v[i], p); p = gl_mul(p, si); }
+}
+
+/* ------------------------------------------------------------------ Merkle tree */
+
+/* hash/merkle_tree.rs:86-113 fill_subtree, same in-order interleaved digest layout (:50-58).
+ * digests_len counts hashes. rayon::join -> omp task above a size cut-off. */
+static void fill_subtree(gl_t *digests, size_t digests_len, const gl_t *leaves, size_t nleaves, size_t width,
+                         gl_t out[HOUT]) {
+    if (digests_len == 0) {
+        gbo_gl_hash_or_noop(leaves, width, out);
+        return;
+    }
+    size_t half = digests_len / 2;
+    gl_t *left_buf = digests, *left_mem = digests + (half - 1) * HOUT;
+    gl_t *right_mem = digests + half * HOUT, *right_buf = digests + (half + 1) * HOUT;
+    gl_t l[HOUT], r[HOUT];
+    if (nleaves >= 512) {
+#pragma omp task shared(l)
+        fill_subtree(left_buf, half - 1, leaves, nleaves / 2, width, l);
+#pragma omp task shared(r)
+        fill_subtree(right_buf, half - 1, leaves + (nleaves / 2) * width, nleaves / 2, width, r);
+#pragma omp taskwait
+    } else {
+        fill_subtree(left_buf, half - 1, leaves, nleaves / 2, width, l);
+        fill_subtree(right_buf, half - 1, leaves + (nleaves / 2) * width, nleaves / 2, width, r);
+    }
+    memcpy(left_mem, l, sizeof l);
+    memcpy(right_mem, r, sizeof r);
+    gbo_gl_two_to_one(l, r, out);
+}
+
+/* hash/merkle_tree.rs:152-181 MerkleTree::new (+ fill_digests_buf :115-149).
+ * leaves [L][width] row-major; digests [2(L-2^cap)][4]; cap [2^cap][4]. Returns 0, or -1 on the
+ * reference's assert (cap_height > log2 L). */
+int gbo_gl_merkle_tree(const gl_t *leaves, size_t log_l, size_t width, unsigned cap_height, gl_t *digests, gl_t *cap) {
+    if (cap_height > log_l) return -1;
+    size_t L = (size_t)1 << log_l, ncap = (size_t)1 << cap_height;
+    size_t num_digests = 2 * (L - ncap);
+    if (num_digests == 0) {
+        for (size_t i = 0; i < L; i++) gbo_gl_hash_or_noop(leaves + i * width, width, cap + i * HOUT);
+        return 0;
+    }
+    size_t sub_d = num_digests >> cap_height, sub_l = L >> cap_height;
+#pragma omp parallel
+#pragma omp single
+    for (size_t s = 0; s < ncap; s++) {
+#pragma omp task
+        fill_subtree(digests + s * sub_d * HOUT, sub_d, leaves + s * sub_l * width, sub_l, width, cap + s * HOUT);
+    }
+    return 0;
+}
+
+/* hash/merkle_tree.rs:188-222 MerkleTree::prove; returns number of siblings written */
+int gbo_gl_merkle_prove(const gl_t *digests, size_t log_l, unsigned cap_height, size_t leaf_index, gl_t *siblings) {
+    size_t L = (size_t)1 << log_l;
+    unsigned num_layers = (unsigned)log_l - cap_height;
+    size_t num_digests = 2 * (L - ((size_t)1 << cap_height));
+    size_t tree_index = leaf_index >> num_layers;
+    size_t tree_len = num_digests >> cap_height;
+    const gl_t *tree = digests + tree_len * tree_index * HOUT;
+    size_t pair_index = leaf_index & (((size_t)1 << num_layers) - 1);
+    for (unsigned i = 0; i < num_layers; i++) {
+        size_t parity = pair_index & 1;
+        pair_index >>= 1;
+        size_t siblings_index = (pair_index << (i + 1)) + ((size_t)1 << i) - 1;
+        size_t sibling_index = 2 * siblings_index + (1 - parity);
+        memcpy(siblings + i * HOUT, tree + sibling_index * HOUT, HOUT * sizeof(gl_t));
+    }
+    return (int)num_layers;
+}
+
+/* hash/merkle_proofs.rs:54-76 verify_merkle_proof_to_cap; returns 1 if ok */
+int gbo_gl_merkle_verify(const gl_t *leaf, size_t width, size_t leaf_index, const gl_t *cap, const gl_t *siblings, unsigned nsib) {
+    gl_t cur[HOUT];
+    gbo_gl_hash_or_noop(leaf, width, cur);
+    size_t idx = leaf_index;
+    for (unsigned i = 0; i < nsib; i++) {
+        const gl_t *sib = siblings + i * HOUT;
+        gl_t nxt[HOUT];
+        if (idx & 1) gbo_gl_two_to_one(sib, cur, nxt); else gbo_gl_two_to_one(cur, sib, nxt);
+        memcpy(cur, nxt, sizeof cur);
+        idx >>= 1;
+    }
+    return memcmp(cur, cap + idx * HOUT, sizeof cur) == 0;
+}
+
+/* ------------------------------------------------------------------ PolynomialBatch */
+
+/* fri/oracle.rs:68-123 from_values / from_coeffs.
+ *   cols      [ncols][n]   column-major input (values on H_n, or coefficients if is_coeffs)
+ *   salts     NULL or [4][N] (the F::rand_vec columns of :144-148, host-supplied)
+ *   coeffs    out [ncols][n]
+ *   leaves    out [N][ncols+nsalt]  leaf i = LDE point bitrev(i)   (:108-109)
+ *   digests   out [2(N-2^cap)][4], cap out [2^cap][4]
+ * "IFFT" :76-80 builds a root table per column (v.ifft() passes None); "FFT + blinding"
+ * :125-150 shares one table of size N (circuit_builder.rs:1227-1228). */
+int gbo_gl_commit(const gl_t *cols, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                  int is_coeffs, const gl_t *salts, gl_t *coeffs, gl_t *leaves, gl_t *digests, gl_t *cap) {
+    size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    unsigned log_N = log_n + rate_bits;
+    size_t nsalt = salts ? 4 : 0, width = ncols + nsalt;
+    if (cap_height > log_N) return -1;
+    memcpy(coeffs, cols, ncols * n * sizeof(gl_t));
+    if (!is_coeffs) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (size_t c = 0; c < ncols; c++) gbo_gl_ifft(coeffs + c * n, log_n);
+    }
+    root_table_t *table = root_table_new(log_N);
+    gl_t *lde = malloc(ncols ? ncols * N * sizeof(gl_t) : 1);
+    if (!lde) return -2;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t c = 0; c < ncols; c++) {
+        gl_t *v = lde + c * N;
+        memcpy(v, coeffs + c * n, n * sizeof(gl_t));
+        memset(v + n, 0, (N - n) * sizeof(gl_t)); /* p.lde(rate_bits): polynomial/mod.rs:201-203 */
+        coset_fft_opt(v, log_N, GL_GENERATOR, rate_bits, table);
+    }
+    root_table_free(table);
+    /* transpose (util/mod.rs:25-31) + reverse_index_bits_in_place on the leaf vector */
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < N; i++) {
+        size_t src = rev_bits(i, log_N);
+        gl_t *row = leaves + i * width;
+        for (size_t c = 0; c < ncols; c++) row[c] = lde[c * N + src];
+        for (size_t s = 0; s < nsalt; s++) row[ncols + s] = salts[s * N + src];
+    }
+    free(lde);
+    return gbo_gl_merkle_tree(leaves, log_N, width, cap_height, digests, cap);
+}
+
+/* ------------------------------------------------------------------ Challenger */
+
+/* iop/challenger.rs:18-150 */
+typedef struct {
+    gl_t state[W];
+    gl_t in[RATE];
+    int nin;
+    gl_t out[RATE];
+    int nout;
+} gbo_gl_challenger;
+
+void gbo_gl_challenger_init(gbo_gl_challenger *c) { memset(c, 0, sizeof *c); }
+static void duplexing(gbo_gl_challenger *c) {
+    for (int i = 0; i < c->nin; i++) c->state[i] = c->in[i];
+    c->nin = 0;
+    gbo_gl_poseidon(c->state, c->state);
+    memcpy(c->out, c->state, RATE * sizeof(gl_t));
+    c->nout = RATE;
+}
+void gbo_gl_challenger_observe(gbo_gl_challenger *c, const gl_t *e, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        c->nout = 0;
+        c->in[c->nin++] = e[i];
+        if (c->nin == RATE) duplexing(c);
+    }
+}
+gl_t gbo_gl_challenger_get(gbo_gl_challenger *c) {
+    if (c->nin != 0 || c->nout == 0) duplexing(c);
+    return c->out[--c->nout];
+}
+size_t gbo_gl_challenger_sizeof(void) { return sizeof(gbo_gl_challenger); }
+
+/* ------------------------------------------------------------------ small field helpers for the python checker */
+gl_t gbo_gl_mul(gl_t a, gl_t b) { return gl_mul(a, b); }
+gl_t gbo_gl_powu(gl_t a, uint64_t e) { return gl_pow(a, e); }
+gl_t gbo_gl_inv(gl_t a) { return gl_inv(a); }
+gl_t gbo_gl_two_adic_generator(unsigned bits) { return gl_two_adic_generator(bits); }
+int gbo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
