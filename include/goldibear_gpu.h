@@ -1,0 +1,114 @@
+/* goldibear_gpu.h - C ABI of libgoldibear_gpu.so, the MI355X (gfx950) implementation of the
+ * plonky2_goldibear commitment hot path.
+ *
+ * The reference has no FFI: the seam is the Rust struct `PolynomialBatch` with public fields
+ * (plonky2/src/fri/oracle.rs:29-40), built by `from_values` / `from_coeffs` (:68-123) and read by
+ * the prover.  Each entry point below names the reference item it replaces.  INTEGRATION.md shows
+ * the Rust `extern "C"` block and the `GpuPolynomialBatch` newtype that binds them.
+ *
+ * Conventions
+ *  - every function returns a gb_status (0 = ok) and never unwinds; gb_last_error() gives text;
+ *    GB_ERR_INVALID is returned where the reference would assert!/panic! on a shape violation
+ *    (oracle.rs:139, merkle_tree.rs:154-157, fft.rs:174-180);
+ *  - one gb_ctx per HIP device; calls on one ctx are serialised by the caller (the reference
+ *    prover is single-threaded above Rayon, plonk/prover.rs:228-447); contexts are independent,
+ *    which is how independent proofs shard one-per-GPU;
+ *  - field elements are canonical little-endian u64 (Goldilocks) / u32 (BabyBear);
+ *  - matrices are COLUMN-MAJOR [ncols][n]: the layout of Vec<PolynomialValues<F>>
+ *    (iop/witness.rs:277-284) with the per-column Vecs laid end to end;
+ *  - gb_batch is an opaque device-resident handle; nothing large is copied back unless asked.
+ */
+#ifndef GOLDIBEAR_GPU_H
+#define GOLDIBEAR_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gb_ctx gb_ctx;
+typedef struct gb_batch gb_batch;
+
+typedef int32_t gb_status;
+enum {
+    GB_OK = 0,
+    GB_ERR_INVALID = 1,     /* shape / argument violation (reference: assert!/panic!) */
+    GB_ERR_HIP = 2,         /* a HIP runtime call failed */
+    GB_ERR_OOM = 3,         /* device allocation failed */
+    GB_ERR_UNSUPPORTED = 4  /* valid in the reference, not implemented here (e.g. log_n > 20) */
+};
+
+enum { GB_GOLDILOCKS = 0, GB_BABYBEAR = 1 }; /* field tag: F = Goldilocks (Poseidon-12) | BabyBear (Poseidon2-16) */
+
+enum {
+    GB_INPUT_HOST = 0,   /* `cols` / `salts` are host pointers (the drop-in case) */
+    GB_INPUT_DEVICE = 1  /* they are device pointers on ctx's device (chained calls, benchmarks) */
+};
+
+#define GB_SALT_SIZE 4 /* fri/oracle.rs:25 */
+
+/* ---- context ------------------------------------------------------------------------------- */
+gb_status gb_ctx_create(int device, gb_ctx** out);
+gb_status gb_ctx_destroy(gb_ctx* ctx);
+const char* gb_last_error(const gb_ctx* ctx); /* valid until the next call on ctx; ctx may be NULL */
+gb_status gb_ctx_synchronize(gb_ctx* ctx);
+/* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
+gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out);
+
+/* ---- timing: the reference's timed!() scopes (util/proving_process_info.rs:196-212) ---------
+ * With profiling on, each commit records HIP events on ctx's stream around the scopes
+ * "IFFT", "FFT + blinding", "build Merkle tree" (fri/oracle.rs:76-114; "transpose LDEs" does not
+ * exist here).  gb_ctx_scope_ms returns the accumulated milliseconds of a scope since the last
+ * reset and synchronises the stream. */
+gb_status gb_ctx_set_profiling(gb_ctx* ctx, int32_t on);
+gb_status gb_ctx_scope_ms(gb_ctx* ctx, const char* scope, double* ms_out, uint64_t* count_out);
+gb_status gb_ctx_scope_reset(gb_ctx* ctx);
+
+/* ---- PolynomialBatch ------------------------------------------------------------------------ */
+/* PolynomialBatch::from_values (fri/oracle.rs:68-90): `cols` holds ncols columns of n = 2^log_n
+ * evaluations on the subgroup H_n.  Computes the coefficients, the rate-2^rate_bits LDE on the
+ * coset 7*H_N, and the Merkle tree with 2^cap_height cap entries.  `salts`: NULL (blinding =
+ * false) or GB_SALT_SIZE columns of N = n << rate_bits elements - the F::rand_vec columns of
+ * oracle.rs:144-148, supplied by the host so that results are reproducible.
+ * Errors: cap_height > log_n + rate_bits -> GB_ERR_INVALID (merkle_tree.rs:154-157). */
+gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n,
+                           uint32_t rate_bits, uint32_t cap_height, const void* salts, uint32_t flags,
+                           gb_batch** out);
+/* PolynomialBatch::from_coeffs (fri/oracle.rs:93-123): same, input already coefficients. */
+gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n,
+                           uint32_t rate_bits, uint32_t cap_height, const void* salts, uint32_t flags,
+                           gb_batch** out);
+gb_status gb_batch_free(gb_batch* b);
+
+/* shape queries: .polynomials.len(), .degree_log, .rate_bits, .blinding (oracle.rs:35-39) */
+gb_status gb_batch_info(const gb_batch* b, uint32_t* field, size_t* ncols, uint32_t* degree_log,
+                        uint32_t* rate_bits, uint32_t* cap_height, uint32_t* blinding);
+
+/* .merkle_tree.cap (hash/merkle_tree.rs:60-61): out[2^cap_height][H], H = 4 (GL) / 8 (BB) */
+gb_status gb_batch_cap(gb_batch* b, void* out);
+/* .polynomials[col].coeffs (oracle.rs:35): out[n] */
+gb_status gb_batch_coeffs(gb_batch* b, size_t col, void* out);
+/* get_lde_values(index, step) (oracle.rs:153-158): out[ncols] (salt columns dropped) */
+gb_status gb_batch_lde_values(gb_batch* b, uint64_t index, uint64_t step, void* out);
+/* MerkleTree::get(leaf_index) + MerkleTree::prove(leaf_index) (merkle_tree.rs:183-222):
+ * row[ncols + salt], siblings[(log_n + rate_bits - cap_height)][H], *nsib = that count */
+gb_status gb_batch_leaf(gb_batch* b, uint64_t leaf_index, void* row, void* siblings, uint32_t* nsib);
+/* .merkle_tree.digests in the reference's interleaved layout (merkle_tree.rs:50-58):
+ * out[2 * (N - 2^cap_height)][H].  Parity/debug aid; the device keeps level-major digests. */
+gb_status gb_batch_digests(gb_batch* b, void* out);
+/* .merkle_tree.leaves: out[N][ncols + salt] row-major (oracle.rs:108-109 order). Debug aid. */
+gb_status gb_batch_leaves(gb_batch* b, void* out);
+/* device pointers for zero-copy chaining: coeffs [ncols][n], lde [ncols+salt][N] in leaf order */
+gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** digest_levels);
+
+/* ---- bare kernels (parity tests and microbenchmarks) ---------------------------------------- */
+/* `count` Poseidon-12 (GL) / Poseidon2-16 (BB) permutations: in/out [count][width], host memory.
+ * PoseidonGoldilocks::poseidon (hash/poseidon_goldilocks.rs:912-922). */
+gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uint64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLDIBEAR_GPU_H */

@@ -1,0 +1,71 @@
+"""Build libgoldibear_gpu.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+plonky2_goldibear_amd/lib/libgoldibear_gpu.so travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libgoldibear_gpu.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the gfx950 library cannot be built")
+    return exe
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    hdr.append(os.path.join(os.path.dirname(HERE), "include", "goldibear_gpu.h"))
+    return hdr
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in sources() + _deps())
+
+
+def build_library(force=False, verbose=False):
+    """Compile every .hip translation unit for gfx950 and link the shared library."""
+    if not force and not is_stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    newest_hdr = max(os.path.getmtime(p) for p in _deps())
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr):
+            return obj
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

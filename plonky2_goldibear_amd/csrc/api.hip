@@ -1,0 +1,525 @@
+// C-ABI implementation (include/goldibear_gpu.h): contexts, device-resident PolynomialBatch
+// handles, twiddle/coset table caches and the reference's timing scopes.
+#include "../../include/goldibear_gpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gl_field.hpp"
+#include "kernels.hpp"
+
+using gbk::u32;
+using gbk::u64;
+
+namespace {
+
+thread_local std::string g_null_ctx_error;
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ScopeAcc {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+};
+
+struct GlTableSet {
+    gbk::GlNttTables t{};
+    std::vector<void*> owned;
+};
+struct GlCosetSet {
+    gbk::GlCosetTables t{};
+    std::vector<void*> owned;
+};
+
+}  // namespace
+
+struct gb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+    std::map<std::string, ScopeAcc> scopes;
+    u64* tw4096_fwd = nullptr;
+    u64* tw4096_inv = nullptr;
+    std::map<u32, GlTableSet> gl_tables;                    // by log_n
+    std::map<std::pair<u32, u32>, GlCosetSet> gl_cosets;    // by (log_n, rate_bits)
+    DeviceBuf scratch;                                      // grow-only workspace
+    DeviceBuf small;                                        // small gather staging (rows, siblings)
+};
+
+struct gb_batch {
+    gb_ctx* ctx = nullptr;
+    u32 field = 0, log_n = 0, rate_bits = 0, cap_height = 0, nsalt = 0;
+    size_t ncols = 0;
+    u64* coeffs = nullptr;  // [ncols][n]
+    u64* lde = nullptr;     // [ncols + nsalt][N], leaf order
+    u64* levels = nullptr;  // level-major digests, level k at hash offset 2N - (2N >> k); last level = cap
+};
+
+namespace {
+
+gb_status fail(gb_ctx* ctx, gb_status code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_null_ctx_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? GB_ERR_OOM : GB_ERR_HIP,                  \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+struct Scope {
+    gb_ctx* ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char* name;
+    Scope(gb_ctx* c, const char* n) : ctx(c), name(n) {
+        if (!ctx->profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        hipEventRecord(a, ctx->stream);
+    }
+    ~Scope() {
+        if (!a) return;
+        hipEventRecord(b, ctx->stream);
+        ctx->scopes[name].spans.emplace_back(a, b);
+    }
+};
+
+gb_status ensure(gb_ctx* ctx, DeviceBuf& buf, size_t bytes) {
+    if (buf.bytes >= bytes) return GB_OK;
+    if (buf.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(buf.p));
+        buf.p = nullptr;
+        buf.bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&buf.p, bytes));
+    buf.bytes = bytes;
+    return GB_OK;
+}
+
+gb_status upload(gb_ctx* ctx, const std::vector<u64>& host, u64** dev, std::vector<void*>* owned) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, host.size() * sizeof(u64)));
+    HIP_TRY(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
+    *dev = static_cast<u64*>(p);
+    if (owned) owned->push_back(p);
+    return GB_OK;
+}
+
+std::vector<u64> powers(u64 base, size_t count) {
+    std::vector<u64> v(count);
+    u64 x = 1;
+    for (size_t i = 0; i < count; i++) {
+        v[i] = x;
+        x = gl::mul(x, base);
+    }
+    return v;
+}
+
+u32 bitrev32(u32 x, u32 bits) {
+    u32 r = 0;
+    for (u32 i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
+    auto it = ctx->gl_tables.find(log_n);
+    if (it != ctx->gl_tables.end()) { *out = &it->second.t; return GB_OK; }
+    if (!ctx->tw4096_fwd) {
+        u64 w = gl::two_adic_generator(12);
+        gb_status s = upload(ctx, powers(w, 4096), &ctx->tw4096_fwd, nullptr);
+        if (s) return s;
+        s = upload(ctx, powers(gl::inv(w), 4096), &ctx->tw4096_inv, nullptr);
+        if (s) return s;
+    }
+    GlTableSet set;
+    set.t.log_n = log_n;
+    set.t.tw4096_fwd = ctx->tw4096_fwd;
+    set.t.tw4096_inv = ctx->tw4096_inv;
+    u64 w = gl::two_adic_generator(log_n), wi = gl::inv(w);
+    size_t n = (size_t)1 << log_n;
+    size_t nhi = n > 1024 ? n / 1024 : 1;
+    u64 *lo_f, *hi_f, *lo_i, *hi_i;
+    gb_status s;
+    if ((s = upload(ctx, powers(w, 1024), &lo_f, &set.owned))) return s;
+    if ((s = upload(ctx, powers(gl::pow(w, 1024), nhi), &hi_f, &set.owned))) return s;
+    if ((s = upload(ctx, powers(wi, 1024), &lo_i, &set.owned))) return s;
+    if ((s = upload(ctx, powers(gl::pow(wi, 1024), nhi), &hi_i, &set.owned))) return s;
+    set.t.tw_lo_fwd = lo_f; set.t.tw_hi_fwd = hi_f; set.t.tw_lo_inv = lo_i; set.t.tw_hi_inv = hi_i;
+    set.t.n_inv = gl::inv((u64)n % gl::P);
+    auto res = ctx->gl_tables.emplace(log_n, std::move(set));
+    *out = &res.first->second.t;
+    return GB_OK;
+}
+
+// coset c (block c of n leaves) has shift 7 * w_N^bitrev_r(c): leaf j = c*n + jl is the LDE
+// point 7 * w_N^bitrev_logN(j) (fri/oracle.rs:109 + polynomial/mod.rs:282-295)
+gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, const gbk::GlCosetTables** out) {
+    auto key = std::make_pair(log_n, rate_bits);
+    auto it = ctx->gl_cosets.find(key);
+    if (it != ctx->gl_cosets.end()) { *out = &it->second.t; return GB_OK; }
+    size_t n = (size_t)1 << log_n;
+    size_t nlo = n < 4096 ? n : 4096, nhi = n > 4096 ? n / 4096 : 1;
+    u32 nc = 1u << rate_bits;
+    u64 wN = gl::two_adic_generator(log_n + rate_bits);
+    std::vector<u64> lo(nc * nlo), hi(nc * nhi);
+    for (u32 c = 0; c < nc; c++) {
+        u64 s = gl::mul(gl::GENERATOR, gl::pow(wN, bitrev32(c, rate_bits)));
+        std::vector<u64> pl = powers(s, nlo), ph = powers(gl::pow(s, 4096), nhi);
+        std::memcpy(&lo[c * nlo], pl.data(), nlo * sizeof(u64));
+        std::memcpy(&hi[c * nhi], ph.data(), nhi * sizeof(u64));
+    }
+    GlCosetSet set;
+    set.t.rate_bits = rate_bits;
+    u64 *dlo, *dhi;
+    gb_status s;
+    if ((s = upload(ctx, lo, &dlo, &set.owned))) return s;
+    if ((s = upload(ctx, hi, &dhi, &set.owned))) return s;
+    set.t.pow_lo = dlo; set.t.pow_hi = dhi;
+    auto res = ctx->gl_cosets.emplace(key, std::move(set));
+    *out = &res.first->second.t;
+    return GB_OK;
+}
+
+inline size_t hout(u32 field) { return field == GB_GOLDILOCKS ? 4 : 8; }
+inline size_t level_offset(u64 N, u32 k) { return (size_t)(2 * N - ((2 * N) >> k)); }
+
+gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                 uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out) {
+    if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
+    if (!out) return fail(ctx, GB_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (field != GB_GOLDILOCKS) return fail(ctx, GB_ERR_UNSUPPORTED, "field not implemented yet");
+    if (ncols == 0) return fail(ctx, GB_ERR_INVALID, "from_values/from_coeffs needs at least one polynomial (oracle.rs:101)");
+    if (!cols) return fail(ctx, GB_ERR_INVALID, "null cols");
+    if (log_n + rate_bits > 32) return fail(ctx, GB_ERR_INVALID, "LDE size exceeds the field's two-adicity (32)");
+    if (cap_height > log_n + rate_bits)
+        return fail(ctx, GB_ERR_INVALID, "cap_height should be at most log2(leaves.len()) (merkle_tree.rs:154-157)");
+    if (log_n > 20) return fail(ctx, GB_ERR_UNSUPPORTED, "log_n > 20 not implemented");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    const u32 log_N = log_n + rate_bits;
+    const u32 nsalt = salts ? GB_SALT_SIZE : 0;
+    const size_t width = ncols + nsalt;
+    const bool dev_in = (flags & GB_INPUT_DEVICE) != 0;
+
+    gb_batch* b = new (std::nothrow) gb_batch();
+    if (!b) return fail(ctx, GB_ERR_OOM, "host allocation failed");
+    b->ctx = ctx; b->field = field; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->nsalt = nsalt; b->ncols = ncols;
+    auto cleanup = [&](gb_status s) { gb_batch_free(b); return s; };
+
+    void* p = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc(&p, ncols * n * sizeof(u64))) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc coeffs"));
+    b->coeffs = (u64*)p;
+    if ((e = hipMalloc(&p, width * N * sizeof(u64))) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc lde"));
+    b->lde = (u64*)p;
+    if ((e = hipMalloc(&p, 2 * N * 4 * sizeof(u64))) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc digests"));
+    b->levels = (u64*)p;
+
+    const gbk::GlNttTables* tabs;
+    const gbk::GlCosetTables* cos;
+    gb_status s;
+    if ((s = gl_tables_for(ctx, log_n, &tabs))) return cleanup(s);
+    if ((s = gl_cosets_for(ctx, log_n, rate_bits, &cos))) return cleanup(s);
+
+    hipStream_t st = ctx->stream;
+    const u64* src = static_cast<const u64*>(cols);
+    if (!dev_in || is_coeffs) {
+        // host input, or coefficients the batch must own a copy of
+        if (hipMemcpyAsync(b->coeffs, cols, ncols * n * sizeof(u64), dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           st) != hipSuccess)
+            return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+        src = b->coeffs;
+    }
+    if (!is_coeffs) {
+        if ((s = ensure(ctx, ctx->scratch, ncols * n * sizeof(u64)))) return cleanup(s);
+        Scope sc(ctx, "IFFT");
+        gbk::gl_intt_columns(src, b->coeffs, (u64*)ctx->scratch.p, ncols, *tabs, st);
+    }
+    {
+        Scope sc(ctx, "FFT + blinding");
+        gbk::gl_lde_columns(b->coeffs, b->lde, ncols, *tabs, *cos, st);
+        if (nsalt) {
+            // salt columns arrive in LDE-point order (like lde_values' extra columns, oracle.rs:144-148)
+            // and are stored, like everything else, in leaf order: leaf j <- point bitrev(j)
+            const u64* sdev = static_cast<const u64*>(salts);
+            if (!dev_in) {
+                if ((s = ensure(ctx, ctx->scratch, nsalt * N * sizeof(u64)))) return cleanup(s);
+                if (hipMemcpyAsync(ctx->scratch.p, salts, nsalt * N * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess)
+                    return cleanup(fail(ctx, GB_ERR_HIP, "copy of salts failed"));
+                sdev = (const u64*)ctx->scratch.p;
+            }
+            gbk::u64_bitrev_copy(sdev, b->lde + ncols * N, log_N, nsalt, st);
+        }
+    }
+    {
+        Scope sc(ctx, "build Merkle tree");
+        gbk::gl_merkle_leaves(b->lde, N, (u32)width, N, b->levels, st);
+        for (u32 k = 0; k < log_N - cap_height; k++)
+            gbk::gl_merkle_level(b->levels + 4 * level_offset(N, k), b->levels + 4 * level_offset(N, k + 1), N >> (k + 1), st);
+    }
+    if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, GB_ERR_HIP, "kernel launch failed"));
+    *out = b;
+    return GB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gb_status gb_ctx_create(int device, gb_ctx** out) {
+    if (!out) return fail(nullptr, GB_ERR_INVALID, "null out");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return fail(nullptr, GB_ERR_HIP, "no HIP device available");
+    if (device < 0 || device >= count) return fail(nullptr, GB_ERR_INVALID, "device index out of range");
+    gb_ctx* ctx = new (std::nothrow) gb_ctx();
+    if (!ctx) return fail(nullptr, GB_ERR_OOM, "host allocation failed");
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, GB_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
+    }
+    *out = ctx;
+    return GB_OK;
+}
+
+gb_status gb_ctx_destroy(gb_ctx* ctx) {
+    if (!ctx) return GB_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    gb_ctx_scope_reset(ctx);
+    for (auto& kv : ctx->gl_tables) for (void* p : kv.second.owned) hipFree(p);
+    for (auto& kv : ctx->gl_cosets) for (void* p : kv.second.owned) hipFree(p);
+    if (ctx->tw4096_fwd) hipFree(ctx->tw4096_fwd);
+    if (ctx->tw4096_inv) hipFree(ctx->tw4096_inv);
+    if (ctx->scratch.p) hipFree(ctx->scratch.p);
+    if (ctx->small.p) hipFree(ctx->small.p);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GB_OK;
+}
+
+const char* gb_last_error(const gb_ctx* ctx) { return ctx ? ctx->err.c_str() : g_null_ctx_error.c_str(); }
+
+gb_status gb_ctx_synchronize(gb_ctx* ctx) {
+    if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out) {
+    if (!ctx || !stream_out) return fail(ctx, GB_ERR_INVALID, "null argument");
+    *stream_out = (void*)ctx->stream;
+    return GB_OK;
+}
+
+gb_status gb_ctx_set_profiling(gb_ctx* ctx, int32_t on) {
+    if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
+    ctx->profiling = on != 0;
+    return GB_OK;
+}
+
+gb_status gb_ctx_scope_ms(gb_ctx* ctx, const char* scope, double* ms_out, uint64_t* count_out) {
+    if (!ctx || !scope || !ms_out) return fail(ctx, GB_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    uint64_t cnt = 0;
+    auto it = ctx->scopes.find(scope);
+    if (it != ctx->scopes.end()) {
+        for (auto& sp : it->second.spans) {
+            float ms = 0;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, sp.first, sp.second));
+            total += ms;
+            cnt++;
+        }
+    }
+    *ms_out = total;
+    if (count_out) *count_out = cnt;
+    return GB_OK;
+}
+
+gb_status gb_ctx_scope_reset(gb_ctx* ctx) {
+    if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->scopes)
+        for (auto& sp : kv.second.spans) {
+            hipEventDestroy(sp.first);
+            hipEventDestroy(sp.second);
+        }
+    ctx->scopes.clear();
+    return GB_OK;
+}
+
+gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, false, out);
+}
+
+gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, true, out);
+}
+
+gb_status gb_batch_free(gb_batch* b) {
+    if (!b) return GB_OK;
+    if (b->ctx) {
+        hipSetDevice(b->ctx->device);
+        hipStreamSynchronize(b->ctx->stream);
+    }
+    if (b->coeffs) hipFree(b->coeffs);
+    if (b->lde) hipFree(b->lde);
+    if (b->levels) hipFree(b->levels);
+    delete b;
+    return GB_OK;
+}
+
+gb_status gb_batch_info(const gb_batch* b, uint32_t* field, size_t* ncols, uint32_t* degree_log, uint32_t* rate_bits,
+                        uint32_t* cap_height, uint32_t* blinding) {
+    if (!b) return fail(nullptr, GB_ERR_INVALID, "null batch");
+    if (field) *field = b->field;
+    if (ncols) *ncols = b->ncols;
+    if (degree_log) *degree_log = b->log_n;
+    if (rate_bits) *rate_bits = b->rate_bits;
+    if (cap_height) *cap_height = b->cap_height;
+    if (blinding) *blinding = b->nsalt ? 1 : 0;
+    return GB_OK;
+}
+
+gb_status gb_batch_cap(gb_batch* b, void* out) {
+    if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
+    gb_ctx* ctx = b->ctx;
+    const u64 N = (u64)1 << (b->log_n + b->rate_bits);
+    const size_t H = hout(b->field);
+    const u64* cap = b->levels + H * level_offset(N, b->log_n + b->rate_bits - b->cap_height);
+    HIP_TRY(ctx, hipMemcpyAsync(out, cap, ((size_t)1 << b->cap_height) * H * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+gb_status gb_batch_coeffs(gb_batch* b, size_t col, void* out) {
+    if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
+    gb_ctx* ctx = b->ctx;
+    if (col >= b->ncols) return fail(ctx, GB_ERR_INVALID, "polynomial index out of range");
+    const size_t n = (size_t)1 << b->log_n;
+    HIP_TRY(ctx, hipMemcpyAsync(out, b->coeffs + col * n, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+static gb_status read_row(gb_batch* b, u64 leaf, u32 width, void* out) {
+    gb_ctx* ctx = b->ctx;
+    const u64 N = (u64)1 << (b->log_n + b->rate_bits);
+    gb_status s = ensure(ctx, ctx->small, 64 * 1024);
+    if (s) return s;
+    if (width * sizeof(u64) > ctx->small.bytes) return fail(ctx, GB_ERR_UNSUPPORTED, "row too wide");
+    gbk::gl_gather_row(b->lde, N, width, leaf, (u64*)ctx->small.p, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->small.p, width * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+gb_status gb_batch_lde_values(gb_batch* b, uint64_t index, uint64_t step, void* out) {
+    if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
+    const u32 bits = b->log_n + b->rate_bits;
+    const u64 N = (u64)1 << bits;
+    u64 i = index * step;
+    if (i >= N) return fail(b->ctx, GB_ERR_INVALID, "index * step out of range (oracle.rs:154-156 would index out of bounds)");
+    u64 leaf = 0;
+    for (u32 k = 0; k < bits; k++) leaf |= ((i >> k) & 1ull) << (bits - 1 - k);
+    return read_row(b, leaf, (u32)b->ncols, out);
+}
+
+gb_status gb_batch_leaf(gb_batch* b, uint64_t leaf_index, void* row, void* siblings, uint32_t* nsib) {
+    if (!b) return fail(nullptr, GB_ERR_INVALID, "null batch");
+    gb_ctx* ctx = b->ctx;
+    const u32 bits = b->log_n + b->rate_bits;
+    if (leaf_index >> bits) return fail(ctx, GB_ERR_INVALID, "leaf_index out of range (merkle_tree.rs:191)");
+    if (row) {
+        gb_status s = read_row(b, leaf_index, (u32)(b->ncols + b->nsalt), row);
+        if (s) return s;
+    }
+    const u32 layers = bits - b->cap_height;
+    if (nsib) *nsib = layers;
+    if (siblings && layers) {
+        gb_status s = ensure(ctx, ctx->small, 64 * 1024);
+        if (s) return s;
+        gbk::gl_gather_siblings(b->levels, bits, b->cap_height, leaf_index, (u64*)ctx->small.p, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(siblings, ctx->small.p, layers * hout(b->field) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return GB_OK;
+}
+
+gb_status gb_batch_digests(gb_batch* b, void* out) {
+    if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
+    gb_ctx* ctx = b->ctx;
+    const u32 bits = b->log_n + b->rate_bits;
+    const u64 N = (u64)1 << bits;
+    const size_t total = 2 * (N - ((u64)1 << b->cap_height));
+    if (!total) return GB_OK;
+    const size_t bytes = total * hout(b->field) * sizeof(u64);
+    gb_status s = ensure(ctx, ctx->scratch, bytes);
+    if (s) return s;
+    gbk::gl_digests_to_reference_layout(b->levels, (u64*)ctx->scratch.p, bits, b->cap_height, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+gb_status gb_batch_leaves(gb_batch* b, void* out) {
+    if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
+    gb_ctx* ctx = b->ctx;
+    const u64 N = (u64)1 << (b->log_n + b->rate_bits);
+    const u32 width = (u32)(b->ncols + b->nsalt);
+    const size_t bytes = (size_t)N * width * sizeof(u64);
+    gb_status s = ensure(ctx, ctx->scratch, bytes);
+    if (s) return s;
+    gbk::u64_transpose_to_rows(b->lde, N, width, N, (u64*)ctx->scratch.p, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** digest_levels) {
+    if (!b) return fail(nullptr, GB_ERR_INVALID, "null batch");
+    if (coeffs) *coeffs = b->coeffs;
+    if (lde) *lde = b->lde;
+    if (digest_levels) *digest_levels = b->levels;
+    return GB_OK;
+}
+
+gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uint64_t count) {
+    if (!ctx || !in || !out) return fail(ctx, GB_ERR_INVALID, "null argument");
+    if (field != GB_GOLDILOCKS) return fail(ctx, GB_ERR_UNSUPPORTED, "field not implemented yet");
+    if (!count) return GB_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = count * 12 * sizeof(u64);
+    gb_status s = ensure(ctx, ctx->scratch, 2 * bytes);
+    if (s) return s;
+    u64* din = (u64*)ctx->scratch.p;
+    u64* dout = din + count * 12;
+    HIP_TRY(ctx, hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    gbk::gl_poseidon_permute(din, dout, count, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+}  // extern "C"

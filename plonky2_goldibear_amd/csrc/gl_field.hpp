@@ -1,0 +1,74 @@
+// Goldilocks field p = 2^64 - 2^32 + 1 for gfx950 device code (and the host-side table builders).
+//
+// Replaces the arithmetic the reference takes from p3-goldilocks (Cargo.toml:17-24); call sites on
+// the hot path: field/src/fft.rs:141-159 (butterflies), hash/poseidon_goldilocks.rs:840-846 (x^7),
+// fri/oracle.rs:141 (F::generator() = 7).  All kernels keep elements canonical (< p) in memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gl {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+static constexpr u64 P = 0xFFFFFFFF00000001ULL;
+static constexpr u64 EPS = 0xFFFFFFFFULL;  // 2^64 mod p
+static constexpr u64 GENERATOR = 7;        // F::generator(), the LDE coset shift
+static constexpr u64 TWO_ADIC_GEN_32 = 1753635133440165772ULL;  // order 2^32
+
+__host__ __device__ __forceinline__ u64 canon(u64 x) { return x >= P ? x - P : x; }
+
+// a, b canonical -> canonical
+__host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
+    u64 s = a + b;
+    if (s < a) s += EPS;
+    return canon(s);
+}
+__host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
+    u64 d = a - b;
+    return a >= b ? d : d + P;
+}
+__host__ __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }
+
+__host__ __device__ __forceinline__ u64 mulhi(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// (lo + 2^64 hi) mod p, any 128-bit input, canonical output.
+// 2^64 = 2^32 - 1 and 2^96 = -1 (mod p):  x = lo - hi_hi + hi_lo * (2^32 - 1)
+__host__ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
+    u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
+    u64 t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= EPS;           // borrow: add p (mod 2^64)
+    u64 t1 = (hi_lo << 32) - hi_lo;      // hi_lo * EPS, < 2^64
+    u64 t2 = t0 + t1;
+    if (t2 < t0) t2 += EPS;              // carry: 2^64 = EPS
+    return canon(t2);
+}
+__host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) { return reduce128(a * b, mulhi(a, b)); }
+__host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
+
+__host__ __device__ inline u64 pow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+__host__ __device__ inline u64 inv(u64 a) { return pow(a, P - 2); }
+
+// F::two_adic_generator(bits) (call sites field/src/fft.rs:16, circuit_data.rs:666-668)
+__host__ __device__ inline u64 two_adic_generator(unsigned bits) {
+    u64 g = TWO_ADIC_GEN_32;
+    for (unsigned i = bits; i < 32; i++) g = sqr(g);
+    return g;
+}
+
+}  // namespace gl

@@ -1,0 +1,63 @@
+// Internal launch interface between the C-ABI layer (api.hip) and the gfx950 kernels.
+// Every launcher enqueues on `stream` and returns immediately; no allocation, no sync.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gbk {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---------------------------------------------------------------- Goldilocks NTT / LDE (kernels_ntt.hip)
+
+// Device-resident twiddle tables for one transform size n = 2^log_n (built once per ctx and size).
+struct GlNttTables {
+    u32 log_n;
+    const u64* tw4096_fwd;   // [4096] w_4096^j
+    const u64* tw4096_inv;   // [4096] w_4096^-j
+    const u64* tw_lo_fwd;    // [1024] w_n^e            (e < 1024)
+    const u64* tw_hi_fwd;    // [max(1, n/1024)] w_n^(1024 e)
+    const u64* tw_lo_inv;    // same for w_n^-1
+    const u64* tw_hi_inv;
+    u64 n_inv;               // n^-1 mod p
+};
+
+// Coset tables for the LDE of rate 2^rate_bits: coset c (leaf block c) has shift
+// s_c = 7 * w_N^bitrev_r(c);  pow_lo[c][l] = s_c^l (l < 4096 or n), pow_hi[c][h] = s_c^(4096 h).
+struct GlCosetTables {
+    u32 rate_bits;
+    const u64* pow_lo;  // [2^r][min(n,4096)]
+    const u64* pow_hi;  // [2^r][max(1, n/4096)]
+};
+
+// values on H_n (natural order) -> coefficients (natural order), in `coeffs` [ncols][n].
+// `scratch` must hold ncols*n elements. src may equal coeffs.
+void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
+
+// coefficients [ncols][n] -> LDE [ncols][N] in LEAF order: lde[c][j] = P_c(7 * w_N^bitrev_logN(j))
+// (fri/oracle.rs:108-109 order, no transpose / bit-reverse pass needed afterwards).
+void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
+                    hipStream_t stream);
+
+// ---------------------------------------------------------------- Poseidon-12 Merkle (kernels_merkle.hip)
+
+// leaf digests: out[j] = hash_or_noop(row j), row j = { cols[c*col_stride + j] : c < width }
+void gl_merkle_leaves(const u64* cols, size_t col_stride, u32 width, u64 num_leaves, u64* out, hipStream_t stream);
+// one level: out[i] = two_to_one(in[2i], in[2i+1]), i < num_out
+void gl_merkle_level(const u64* in, u64* out, u64 num_out, hipStream_t stream);
+// level-major digests -> the reference's interleaved layout (hash/merkle_tree.rs:50-58)
+void gl_digests_to_reference_layout(const u64* levels, u64* out, u32 log_leaves, u32 cap_height, hipStream_t stream);
+// gather one row (width elements at stride col_stride) into dst[0..width)
+void gl_gather_row(const u64* cols, size_t col_stride, u32 width, u64 index, u64* dst, hipStream_t stream);
+// siblings of MerkleTree::prove(leaf) from level-major digests: dst[i] = level_i[(leaf >> i) ^ 1], i < layers
+void gl_gather_siblings(const u64* levels, u32 log_leaves, u32 cap_height, u64 leaf, u64* dst, hipStream_t stream);
+// dst[j] = src[bitrev_bits(j)] for `ncols` columns of 2^bits elements (salt columns -> leaf order)
+void u64_bitrev_copy(const u64* src, u64* dst, u32 bits, size_t ncols, hipStream_t stream);
+// leaf-order column-major [width][N] -> row-major leaves [N][width] (debug / parity export)
+void u64_transpose_to_rows(const u64* cols, size_t col_stride, u32 width, u64 rows, u64* dst, hipStream_t stream);
+// raw permutation of `count` states (tests / microbenchmarks)
+void gl_poseidon_permute(const u64* in, u64* out, u64 count, hipStream_t stream);
+
+}  // namespace gbk

@@ -1,0 +1,162 @@
+// Poseidon-12 Merkle-tree kernels for gfx950: replaces MerkleTree::new's per-leaf sponge and
+// recursive fill_subtree (hash/merkle_tree.rs:86-181) with a lane-per-leaf / lane-per-node grid.
+//
+// Input is the column-major LDE matrix (column stride = number of leaves), so a wave's 64 lanes
+// read 64 consecutive leaves of one column: fully coalesced, no transpose.
+// Digests are kept LEVEL-MAJOR on the device: level 0 = leaf digests, level k = N >> k nodes,
+// 4 x u64 per digest.  The reference's interleaved layout is produced on request only.
+#include "kernels.hpp"
+#include "poseidon_gl.hpp"
+
+namespace gbk {
+
+using poseidon_gl::permute;
+
+// hash/hashing.rs:100-123 (overwrite-mode sponge, rate 8) + plonk/config.rs:70-84 (hash_or_noop)
+__global__ __launch_bounds__(256) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
+                                                          u64 num_leaves, u64* __restrict__ out) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    if (width <= 4) {
+        for (u32 c = 0; c < width; c++) s[c] = cols[(size_t)c * col_stride + j];
+    } else {
+        u32 c0 = 0;
+        for (; c0 + 8 <= width; c0 += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            permute(s);
+        }
+        if (c0 < width) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            permute(s);
+        }
+    }
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * j);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// hash/hashing.rs:76-96 compress / Hasher::two_to_one
+__global__ __launch_bounds__(256) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_out) return;
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
+    ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
+    u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
+    permute(s);
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// Level k node t (t < N>>k) sits, in the reference layout, inside subtree s = t >> (layers-k) at
+// pair p = (t & mask) >> 1 of layer k:  2*((p << (k+1)) + (1<<k) - 1) + (t&1)   (merkle_tree.rs:200-217)
+__global__ void k_gl_digests_to_reference(const u64* __restrict__ levels, u64* __restrict__ out, u32 log_leaves,
+                                          u32 cap_height) {
+    u32 layers = log_leaves - cap_height;
+    u64 total = 2 * (((u64)1 << log_leaves) - ((u64)1 << cap_height));
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    // find level: level k occupies [off_k, off_k + N>>k), off_k = 2N - (2N >> k)
+    u64 N = (u64)1 << log_leaves;
+    u32 k = 0;
+    u64 off = 0;
+    while (g >= off + (N >> k)) {
+        off += N >> k;
+        k++;
+    }
+    u64 t = g - off;
+    u64 per_tree = (u64)1 << (layers - k);
+    u64 tree = t / per_tree, w = t % per_tree;
+    u64 p = w >> 1;
+    u64 tree_len = total >> cap_height;
+    u64 dst = tree * tree_len + 2 * ((p << (k + 1)) + ((u64)1 << k) - 1) + (w & 1);
+#pragma unroll
+    for (int e = 0; e < 4; e++) out[4 * dst + e] = levels[4 * g + e];
+}
+
+__global__ void k_gl_gather_row(const u64* __restrict__ cols, size_t col_stride, u32 width, u64 index, u64* dst) {
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < width) dst[c] = cols[(size_t)c * col_stride + index];
+}
+
+__global__ void k_gl_gather_siblings(const u64* __restrict__ levels, u32 log_leaves, u32 cap_height, u64 leaf, u64* dst) {
+    u32 i = threadIdx.x >> 2, e = threadIdx.x & 3;
+    if (i >= log_leaves - cap_height) return;
+    u64 N = (u64)1 << log_leaves;
+    u64 off = 2 * N - ((2 * N) >> i);
+    dst[4 * i + e] = levels[4 * (off + ((leaf >> i) ^ 1)) + e];
+}
+
+__global__ void k_u64_bitrev_copy(const u64* __restrict__ src, u64* __restrict__ dst, u32 bits, size_t total) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    size_t col = g >> bits;
+    u64 j = g & (((u64)1 << bits) - 1);
+    u64 r = bits ? (__brevll(j) >> (64 - bits)) : 0;
+    dst[g] = src[(col << bits) + r];
+}
+
+__global__ void k_u64_transpose_to_rows(const u64* __restrict__ cols, size_t col_stride, u32 width, u64 rows,
+                                        u64* __restrict__ dst) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rows * width) return;
+    u64 r = g / width;
+    u32 c = (u32)(g % width);
+    dst[g] = cols[(size_t)c * col_stride + r];
+}
+
+__global__ __launch_bounds__(256) void k_gl_poseidon_permute(const u64* __restrict__ in, u64* __restrict__ out, u64 count) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 s[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) s[e] = in[12 * i + e];
+    permute(s);
+#pragma unroll
+    for (int e = 0; e < 12; e++) out[12 * i + e] = s[e];
+}
+
+static inline u32 blocks_for(u64 n, u32 bs) { return (u32)((n + bs - 1) / bs); }
+
+void gl_merkle_leaves(const u64* cols, size_t col_stride, u32 width, u64 num_leaves, u64* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gl_merkle_leaves, dim3(blocks_for(num_leaves, 256)), dim3(256), 0, stream, cols, col_stride,
+                       width, num_leaves, out);
+}
+void gl_merkle_level(const u64* in, u64* out, u64 num_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gl_merkle_level, dim3(blocks_for(num_out, 256)), dim3(256), 0, stream, in, out, num_out);
+}
+void gl_digests_to_reference_layout(const u64* levels, u64* out, u32 log_leaves, u32 cap_height, hipStream_t stream) {
+    u64 total = 2 * (((u64)1 << log_leaves) - ((u64)1 << cap_height));
+    if (!total) return;
+    hipLaunchKernelGGL(k_gl_digests_to_reference, dim3(blocks_for(total, 256)), dim3(256), 0, stream, levels, out,
+                       log_leaves, cap_height);
+}
+void gl_gather_row(const u64* cols, size_t col_stride, u32 width, u64 index, u64* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gl_gather_row, dim3(blocks_for(width, 64)), dim3(64), 0, stream, cols, col_stride, width, index,
+                       dst);
+}
+void gl_gather_siblings(const u64* levels, u32 log_leaves, u32 cap_height, u64 leaf, u64* dst, hipStream_t stream) {
+    if (log_leaves == cap_height) return;
+    hipLaunchKernelGGL(k_gl_gather_siblings, dim3(1), dim3(256), 0, stream, levels, log_leaves, cap_height, leaf, dst);
+}
+void u64_bitrev_copy(const u64* src, u64* dst, u32 bits, size_t ncols, hipStream_t stream) {
+    size_t total = ncols << bits;
+    if (!total) return;
+    hipLaunchKernelGGL(k_u64_bitrev_copy, dim3(blocks_for(total, 256)), dim3(256), 0, stream, src, dst, bits, total);
+}
+void u64_transpose_to_rows(const u64* cols, size_t col_stride, u32 width, u64 rows, u64* dst, hipStream_t stream) {
+    if (!rows || !width) return;
+    hipLaunchKernelGGL(k_u64_transpose_to_rows, dim3(blocks_for(rows * width, 256)), dim3(256), 0, stream, cols,
+                       col_stride, width, rows, dst);
+}
+void gl_poseidon_permute(const u64* in, u64* out, u64 count, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gl_poseidon_permute, dim3(blocks_for(count, 256)), dim3(256), 0, stream, in, out, count);
+}
+
+}  // namespace gbk

@@ -1,0 +1,82 @@
+"""ctypes binding of libgoldibear_gpu.so - exactly the symbols include/goldibear_gpu.h declares.
+
+There is no fallback: if the HIP library is missing or fails to load this raises, so a GPU test
+can never pass on a silent CPU path.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+GB_OK, GB_ERR_INVALID, GB_ERR_HIP, GB_ERR_OOM, GB_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+GB_GOLDILOCKS, GB_BABYBEAR = 0, 1
+GB_INPUT_HOST, GB_INPUT_DEVICE = 0, 1
+GB_SALT_SIZE = 4
+
+_vp, _u32, _u64, _sz, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_int32
+_pvp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); kept in step with include/goldibear_gpu.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "gb_ctx_create": (_i32, [C.c_int, _pvp]),
+    "gb_ctx_destroy": (_i32, [_vp]),
+    "gb_last_error": (C.c_char_p, [_vp]),
+    "gb_ctx_synchronize": (_i32, [_vp]),
+    "gb_ctx_stream": (_i32, [_vp, _pvp]),
+    "gb_ctx_set_profiling": (_i32, [_vp, _i32]),
+    "gb_ctx_scope_ms": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    "gb_ctx_scope_reset": (_i32, [_vp]),
+    "gb_commit_values": (_i32, [_vp, _u32, _vp, _sz, _u32, _u32, _u32, _vp, _u32, _pvp]),
+    "gb_commit_coeffs": (_i32, [_vp, _u32, _vp, _sz, _u32, _u32, _u32, _vp, _u32, _pvp]),
+    "gb_batch_free": (_i32, [_vp]),
+    "gb_batch_info": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "gb_batch_cap": (_i32, [_vp, _vp]),
+    "gb_batch_coeffs": (_i32, [_vp, _sz, _vp]),
+    "gb_batch_lde_values": (_i32, [_vp, _u64, _u64, _vp]),
+    "gb_batch_leaf": (_i32, [_vp, _u64, _vp, _vp, C.POINTER(_u32)]),
+    "gb_batch_digests": (_i32, [_vp, _vp]),
+    "gb_batch_leaves": (_i32, [_vp, _vp]),
+    "gb_batch_device_ptrs": (_i32, [_vp, _pvp, _pvp, _pvp]),
+    "gb_permute": (_i32, [_vp, _u32, _vp, _vp, _u64]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load the in-tree HIP library (raises if it has not been built - no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the gfx950 HIP library is the only implementation; there is no CPU fallback)" % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class GoldibearError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("gb_status=%d: %s" % (status, message))
+        self.status = status
+
+
+class ShapeError(GoldibearError, ValueError):
+    """GB_ERR_INVALID: where the reference would assert!/panic! on a shape violation."""
+
+
+def check(status, ctx_handle=None):
+    if status == GB_OK:
+        return
+    msg = load().gb_last_error(ctx_handle)
+    msg = msg.decode() if msg else ""
+    raise (ShapeError if status == GB_ERR_INVALID else GoldibearError)(status, msg)

@@ -1,0 +1,186 @@
+"""Host-side mirror of the reference's commitment interface, over the C ABI.
+
+Same names and argument meaning as plonky2/src/fri/oracle.rs (PolynomialBatch::from_values /
+from_coeffs / get_lde_values, fields polynomials / merkle_tree / degree_log / rate_bits /
+blinding) and plonky2/src/hash/merkle_tree.rs (MerkleTree::get / prove, fields cap / digests /
+leaves).  Shape violations raise ShapeError (a ValueError) where the reference panics.
+Everything large stays on the GPU; accessors copy back only what is asked for.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native as N
+
+GL_P = 0xFFFFFFFF00000001
+
+
+class GpuContext:
+    """One per HIP device (gb_ctx).  Independent contexts are how proofs shard one-per-GPU."""
+
+    def __init__(self, device=0):
+        self._lib = N.load()
+        h = C.c_void_p()
+        N.check(self._lib.gb_ctx_create(device, C.byref(h)))
+        self.handle, self.device = h, device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.gb_ctx_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def synchronize(self):
+        N.check(self._lib.gb_ctx_synchronize(self.handle), self.handle)
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        N.check(self._lib.gb_ctx_stream(self.handle, C.byref(s)), self.handle)
+        return s.value
+
+    # timed!() scopes of the reference (util/proving_process_info.rs:196-212)
+    def set_profiling(self, on=True):
+        N.check(self._lib.gb_ctx_set_profiling(self.handle, int(on)), self.handle)
+
+    def scope_ms(self, scope):
+        ms, cnt = C.c_double(), C.c_uint64()
+        N.check(self._lib.gb_ctx_scope_ms(self.handle, scope.encode(), C.byref(ms), C.byref(cnt)), self.handle)
+        return ms.value, cnt.value
+
+    def scope_reset(self):
+        N.check(self._lib.gb_ctx_scope_reset(self.handle), self.handle)
+
+    def permute(self, states, field=N.GB_GOLDILOCKS):
+        """PoseidonGoldilocks::poseidon on each row of `states` [count][12]."""
+        x = np.ascontiguousarray(states, dtype=np.uint64)
+        out = np.empty_like(x)
+        N.check(self._lib.gb_permute(self.handle, field, x.ctypes.data, out.ctypes.data, x.shape[0]), self.handle)
+        return out
+
+
+def _as_input(x):
+    """numpy array (host) or torch CUDA tensor (device, int64/uint64 bit pattern) -> (ptr, shape, flags, keepalive)"""
+    if isinstance(x, np.ndarray) or not hasattr(x, "data_ptr"):
+        a = np.ascontiguousarray(x, dtype=np.uint64)
+        return a.ctypes.data, a.shape, N.GB_INPUT_HOST, a
+    assert x.is_cuda and x.is_contiguous() and x.element_size() == 8, "device input must be a contiguous 8-byte CUDA tensor"
+    return x.data_ptr(), tuple(x.shape), N.GB_INPUT_DEVICE, x
+
+
+class MerkleTree:
+    """View of a batch's tree: hash/merkle_tree.rs:46-62,183-222."""
+
+    def __init__(self, batch):
+        self._b = batch
+
+    @property
+    def cap(self):
+        b = self._b
+        out = np.empty((1 << b.cap_height, b._hout), dtype=np.uint64)
+        N.check(b._lib.gb_batch_cap(b.handle, out.ctypes.data), b.ctx.handle)
+        return out
+
+    @property
+    def digests(self):
+        """The reference's interleaved digest vector (merkle_tree.rs:50-58), copied to the host."""
+        b = self._b
+        n = 2 * ((1 << (b.degree_log + b.rate_bits)) - (1 << b.cap_height))
+        out = np.empty((n, b._hout), dtype=np.uint64)
+        N.check(b._lib.gb_batch_digests(b.handle, out.ctypes.data), b.ctx.handle)
+        return out
+
+    @property
+    def leaves(self):
+        b = self._b
+        out = np.empty((1 << (b.degree_log + b.rate_bits), b.width), dtype=np.uint64)
+        N.check(b._lib.gb_batch_leaves(b.handle, out.ctypes.data), b.ctx.handle)
+        return out
+
+    def get(self, i):
+        return self._b._leaf(i)[0]
+
+    def prove(self, leaf_index):
+        """MerkleTree::prove -> siblings [layers][H]"""
+        return self._b._leaf(leaf_index)[1]
+
+
+class PolynomialBatch:
+    """fri/oracle.rs:29-158 with the data resident on the GPU."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle, self._lib = ctx, handle, ctx._lib
+        f, nc, dl, rb, ch, bl = C.c_uint32(), C.c_size_t(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        N.check(self._lib.gb_batch_info(handle, C.byref(f), C.byref(nc), C.byref(dl), C.byref(rb), C.byref(ch), C.byref(bl)))
+        self.field, self.num_polys, self.degree_log = f.value, nc.value, dl.value
+        self.rate_bits, self.cap_height, self.blinding = rb.value, ch.value, bool(bl.value)
+        self._hout = 4 if self.field == N.GB_GOLDILOCKS else 8
+        self.width = self.num_polys + (N.GB_SALT_SIZE if self.blinding else 0)
+        self.merkle_tree = MerkleTree(self)
+
+    @classmethod
+    def _commit(cls, fn_name, ctx, cols, rate_bits, cap_height, salts, field):
+        ptr, shape, flags, keep = _as_input(cols)
+        if len(shape) != 2:
+            raise N.ShapeError(N.GB_ERR_INVALID, "expected a [num_polys][n] matrix")
+        ncols, n = shape
+        log_n = int(n).bit_length() - 1
+        if n == 0 or (1 << log_n) != n:
+            raise N.ShapeError(N.GB_ERR_INVALID, "polynomial length must be a power of two (util log2_strict)")
+        sptr, skeep = None, None
+        if salts is not None:
+            sptr, sshape, sflags, skeep = _as_input(salts)
+            if tuple(sshape) != (N.GB_SALT_SIZE, n << rate_bits) or sflags != flags:
+                raise N.ShapeError(N.GB_ERR_INVALID, "salts must be [4][n << rate_bits] in the same memory space as the columns")
+        h = C.c_void_p()
+        st = getattr(ctx._lib, fn_name)(ctx.handle, field, ptr, ncols, log_n, rate_bits, cap_height, sptr, flags, C.byref(h))
+        N.check(st, ctx.handle)
+        del keep, skeep
+        return cls(ctx, h)
+
+    @classmethod
+    def from_values(cls, ctx, values, rate_bits, cap_height, salts=None, field=N.GB_GOLDILOCKS):
+        """PolynomialBatch::from_values (oracle.rs:68-90). blinding == (salts is not None)."""
+        return cls._commit("gb_commit_values", ctx, values, rate_bits, cap_height, salts, field)
+
+    @classmethod
+    def from_coeffs(cls, ctx, coeffs, rate_bits, cap_height, salts=None, field=N.GB_GOLDILOCKS):
+        """PolynomialBatch::from_coeffs (oracle.rs:93-123)."""
+        return cls._commit("gb_commit_coeffs", ctx, coeffs, rate_bits, cap_height, salts, field)
+
+    def free(self):
+        if getattr(self, "handle", None):
+            self._lib.gb_batch_free(self.handle)
+            self.handle = None
+
+    __del__ = free
+
+    def polynomial(self, col):
+        """.polynomials[col].coeffs"""
+        out = np.empty(1 << self.degree_log, dtype=np.uint64)
+        N.check(self._lib.gb_batch_coeffs(self.handle, col, out.ctypes.data), self.ctx.handle)
+        return out
+
+    @property
+    def polynomials(self):
+        return np.stack([self.polynomial(c) for c in range(self.num_polys)])
+
+    def get_lde_values(self, index, step):
+        """oracle.rs:153-158"""
+        out = np.empty(self.num_polys, dtype=np.uint64)
+        N.check(self._lib.gb_batch_lde_values(self.handle, index, step, out.ctypes.data), self.ctx.handle)
+        return out
+
+    def _leaf(self, i):
+        row = np.empty(self.width, dtype=np.uint64)
+        layers = self.degree_log + self.rate_bits - self.cap_height
+        sib = np.empty((max(layers, 1), self._hout), dtype=np.uint64)
+        n = C.c_uint32()
+        N.check(self._lib.gb_batch_leaf(self.handle, i, row.ctypes.data, sib.ctypes.data, C.byref(n)), self.ctx.handle)
+        return row, sib[: n.value]
+
+    def device_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(self._lib.gb_batch_device_ptrs(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value

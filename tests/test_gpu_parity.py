@@ -1,0 +1,139 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.  -m gpu only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from plonky2_goldibear_amd import GpuContext, PolynomialBatch, ShapeError
+
+pytestmark = pytest.mark.gpu
+P = O.GL_P
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _cols(ncols, log_n, seed=None):
+    seed = (0xC0FFEE ^ (ncols << 32) ^ log_n) if seed is None else seed
+    return O.splitmix64_fill(seed, ncols << log_n).reshape(ncols, 1 << log_n)
+
+
+def test_poseidon12_kats_and_random(ctx, kats):
+    # hash/poseidon_goldilocks.rs:1158-1193
+    ins = np.array([v["input"] for v in kats["poseidon12"]], dtype=np.uint64)
+    outs = np.array([v["output"] for v in kats["poseidon12"]], dtype=np.uint64)
+    assert (ctx.permute(ins) == outs).all()
+    rnd = O.splitmix64_fill(5, 12 * 1000).reshape(1000, 12)
+    rnd[0, :] = P - 1
+    got = ctx.permute(rnd)
+    for i in range(0, 1000, 37):
+        assert (got[i] == O.poseidon(rnd[i])).all()
+
+
+def _check_batch(gpu, cpu, full=True):
+    assert (gpu.merkle_tree.cap == cpu.cap).all()
+    assert (gpu.polynomials == cpu.polynomials).all()
+    if full:
+        assert (gpu.merkle_tree.leaves == cpu.leaves).all()
+        if cpu.digests.size:
+            assert (gpu.merkle_tree.digests == cpu.digests).all()
+    N = cpu.leaves.shape[0]
+    for i in {0, 1, N // 2, N - 1, (N * 5) // 7}:
+        row, sib = gpu._leaf(i)
+        assert (row == cpu.leaves[i]).all()
+        assert (sib == cpu.prove(i)).all()
+        assert O.merkle_verify(row, i, cpu.cap, sib)
+
+
+@pytest.mark.parametrize("log_n,ncols,rate_bits,cap_height", [
+    (0, 1, 0, 0), (0, 3, 3, 2), (1, 2, 1, 0), (2, 5, 3, 4), (4, 1, 3, 4), (5, 4, 3, 0), (6, 9, 3, 4),
+    (8, 17, 3, 4), (10, 8, 3, 4), (10, 135, 3, 4), (11, 3, 2, 13), (12, 5, 3, 4), (12, 2, 0, 1),
+    (13, 3, 3, 4), (14, 2, 1, 4), (15, 2, 3, 4), (16, 3, 3, 4), (17, 2, 3, 4), (18, 1, 2, 4),
+])
+def test_from_values_matches_oracle(ctx, log_n, ncols, rate_bits, cap_height):
+    vals = _cols(ncols, log_n)
+    gpu = PolynomialBatch.from_values(ctx, vals, rate_bits, cap_height)
+    cpu = O.PolynomialBatch.from_values(vals, rate_bits, cap_height)
+    _check_batch(gpu, cpu)
+    assert (gpu.get_lde_values(0, 1) == cpu.get_lde_values(0, 1)).all()
+    if log_n >= 2:
+        step = 1 << rate_bits  # the prover's next_step (plonk/prover.rs:819-831)
+        assert (gpu.get_lde_values(3, step) == cpu.get_lde_values(3, step)).all()
+    gpu.free()
+
+
+@pytest.mark.parametrize("log_n,ncols", [(3, 2), (10, 30), (13, 4), (16, 2)])
+def test_from_coeffs_and_salts(ctx, log_n, ncols):
+    coeffs = _cols(ncols, log_n, seed=77 + log_n)
+    salts = O.splitmix64_fill(1234, 4 << (log_n + 3)).reshape(4, -1)
+    gpu = PolynomialBatch.from_coeffs(ctx, coeffs, 3, 4 if log_n > 3 else 2, salts=salts)
+    cpu = O.PolynomialBatch.from_coeffs(coeffs, 3, 4 if log_n > 3 else 2, salts=salts)
+    assert gpu.blinding and gpu.width == ncols + 4
+    _check_batch(gpu, cpu)
+    assert gpu.get_lde_values(1, 1).size == ncols  # salt columns dropped (oracle.rs:157)
+    gpu.free()
+
+
+def test_device_resident_input(ctx):
+    import torch
+    vals = _cols(6, 14)
+    t = torch.from_numpy(vals.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    gpu = PolynomialBatch.from_values(ctx, t, 3, 4)
+    cpu = O.PolynomialBatch.from_values(vals, 3, 4)
+    _check_batch(gpu, cpu, full=False)
+    assert (t.cpu().numpy().view(np.uint64) == vals).all()  # input not clobbered
+    gpu.free()
+
+
+def test_error_behaviour(ctx):
+    with pytest.raises(ShapeError):  # merkle_tree.rs:154-157 / :257-272 should_panic
+        PolynomialBatch.from_values(ctx, _cols(2, 5), 3, 9)
+    with pytest.raises(ShapeError):
+        PolynomialBatch.from_values(ctx, np.zeros((2, 12), np.uint64), 3, 1)  # not a power of two
+    b = PolynomialBatch.from_values(ctx, _cols(2, 5), 3, 8)  # cap_height == log2(leaves): allowed (:274-288)
+    assert b.merkle_tree.digests.shape[0] == 0
+    cpu = O.PolynomialBatch.from_values(_cols(2, 5), 3, 8)
+    assert (b.merkle_tree.cap == cpu.cap).all()
+    with pytest.raises(ShapeError):
+        b._leaf(1 << 8)
+    with pytest.raises(ShapeError):
+        b.polynomial(2)
+
+
+def test_edge_values(ctx):
+    # all-zero, all p-1 and a single spike: exercises carries / canonical reduction paths
+    n = 1 << 13
+    vals = np.zeros((4, n), dtype=np.uint64)
+    vals[1, :] = P - 1
+    vals[2, 7] = P - 1
+    vals[3, :] = np.arange(n, dtype=np.uint64) * np.uint64(0xFFFFFFFF) % np.uint64(P)
+    gpu = PolynomialBatch.from_values(ctx, vals, 3, 4)
+    cpu = O.PolynomialBatch.from_values(vals, 3, 4)
+    _check_batch(gpu, cpu)
+
+
+def test_full_size_2pow20_properties(ctx):
+    """BASELINE size (n = 2^20, N = 2^23): two columns checked against the oracle's own
+    ifft / coset fft, plus size-independent properties (Merkle paths verify against the cap,
+    from_coeffs(from_values(v).polynomials) reproduces the cap)."""
+    log_n, ncols = 20, 3
+    vals = _cols(ncols, log_n)
+    gpu = PolynomialBatch.from_values(ctx, vals, 3, 4)
+    c0 = gpu.polynomial(0)
+    assert (c0 == O.ifft(vals[0])).all()
+    assert (O.fft(gpu.polynomial(2)) == vals[2]).all()
+    lde0 = O.coset_fft(np.concatenate([c0, np.zeros((1 << 23) - (1 << 20), np.uint64)]), 7, 3)
+    cap = gpu.merkle_tree.cap
+    rng = np.random.default_rng(7)
+    for i in [0, 1, (1 << 23) - 1] + rng.integers(0, 1 << 23, 12).tolist():
+        row, sib = gpu._leaf(int(i))
+        src = int(format(int(i), "023b")[::-1], 2)
+        assert row[0] == lde0[src]
+        assert sib.shape == (19, 4)
+        assert O.merkle_verify(row, int(i), cap, sib)
+    again = PolynomialBatch.from_coeffs(ctx, gpu.polynomials, 3, 4)
+    assert (again.merkle_tree.cap == cap).all()
