@@ -56,6 +56,10 @@ def load():
             raise RuntimeError(
                 "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(the gfx950 HIP library is the only implementation; there is no CPU fallback)" % path)
+        # PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
+        # process cannot both open the GPU.  Importing torch first makes the dynamic loader bind
+        # this library's NEEDED libamdhip64.so.7 to the copy torch already loaded.
+        import torch  # noqa: F401
         lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

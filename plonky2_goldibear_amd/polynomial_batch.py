@@ -6,13 +6,29 @@ blinding) and plonky2/src/hash/merkle_tree.rs (MerkleTree::get / prove, fields c
 leaves).  Shape violations raise ShapeError (a ValueError) where the reference panics.
 Everything large stays on the GPU; accessors copy back only what is asked for.
 """
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 import numpy as np
 
 from . import native as N
 
 GL_P = 0xFFFFFFFF00000001
+
+# Handles must be released while the HIP runtime is still alive: at interpreter exit free every
+# live batch, then every context, before C++ static destructors run.
+_live_batches = weakref.WeakSet()
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _shutdown():
+    for b in list(_live_batches):
+        b.free()
+    for c in list(_live_contexts):
+        c.close()
 
 
 class GpuContext:
@@ -23,13 +39,16 @@ class GpuContext:
         h = C.c_void_p()
         N.check(self._lib.gb_ctx_create(device, C.byref(h)))
         self.handle, self.device = h, device
+        _live_contexts.add(self)
 
     def close(self):
         if getattr(self, "handle", None):
             self._lib.gb_ctx_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        if not sys.is_finalizing():
+            self.close()
 
     def synchronize(self):
         N.check(self._lib.gb_ctx_synchronize(self.handle), self.handle)
@@ -73,7 +92,7 @@ class MerkleTree:
     """View of a batch's tree: hash/merkle_tree.rs:46-62,183-222."""
 
     def __init__(self, batch):
-        self._b = batch
+        self._b = weakref.proxy(batch)  # no cycle: the batch frees its device memory when dropped
 
     @property
     def cap(self):
@@ -118,6 +137,7 @@ class PolynomialBatch:
         self._hout = 4 if self.field == N.GB_GOLDILOCKS else 8
         self.width = self.num_polys + (N.GB_SALT_SIZE if self.blinding else 0)
         self.merkle_tree = MerkleTree(self)
+        _live_batches.add(self)
 
     @classmethod
     def _commit(cls, fn_name, ctx, cols, rate_bits, cap_height, salts, field):
@@ -150,11 +170,13 @@ class PolynomialBatch:
         return cls._commit("gb_commit_coeffs", ctx, coeffs, rate_bits, cap_height, salts, field)
 
     def free(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self._lib.gb_batch_free(self.handle)
-            self.handle = None
+        self.handle = None
 
-    __del__ = free
+    def __del__(self):
+        if not sys.is_finalizing():
+            self.free()
 
     def polynomial(self, col):
         """.polynomials[col].coeffs"""
