@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py - one JSON line for the driver (see DESIGN.md "Measurement").
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: workload `commit` = PolynomialBatch::from_values on the 2^20-row Goldilocks wires matrix
+(135 columns, rate 3, cap 4 - fri/oracle.rs:68-123 as called at plonk/prover.rs:261-272);
+Independent circuits shard one per GPU: every rank runs the same workload on its own device,
+no data-path collective ("scaling": "weak").  The roofline object prices the NTT pass (the IFFT
++ LDE kernels) against the 8 TB/s HBM peak with SURVEY.md 8(d)'s algorithmic bytes; the
+cpu_baseline object times the CPU oracle (a restatement of the reference algorithm, "port") on
+a bounded sample on rank 0's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+GL_P = 0xFFFFFFFF00000001
+
+
+def splitmix64_matrix(seed, rows, cols):
+    """SURVEY.md 8(d) synthetic input: SplitMix64 stream reduced mod p, [rows][cols] uint64."""
+    count = rows * cols
+    idx = np.arange(1, count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z % np.uint64(GL_P)).reshape(rows, cols)
+
+
+def cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample_log_n):
+    """The CPU oracle (same algorithm as the reference: per-column radix-2 NTTs, transpose,
+    recursive Merkle) on all host cores, on a row-reduced sample of the same matrix."""
+    from oracle import oracle as O
+    cores = int(O.lib().gbo_num_threads())
+    vals = splitmix64_matrix(0xC0FFEE ^ (ncols << 32) ^ sample_log_n, ncols, 1 << sample_log_n)
+    O.PolynomialBatch.from_values(vals[:, : 1 << 10].copy(), rate_bits, cap_height)  # warm the library
+    t0 = time.perf_counter()
+    O.PolynomialBatch.from_values(vals, rate_bits, cap_height)
+    dt = time.perf_counter() - t0
+    scale = float(1 << (log_n - sample_log_n))  # rows ratio; ignores the log factor in the NTT (favours the CPU)
+    return {
+        "value": 1.0 / (dt * scale), "unit": "commits/s", "cores": cores, "kind": "port",
+        "sample": "oracle from_values on %d cols x 2^%d rows (1/%d of the workload's rows) took %.2f s; "
+                  "scaled linearly in rows" % (ncols, sample_log_n, int(scale), dt),
+        "sample_seconds": dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="commit", choices=["commit"])
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--cols", type=int, default=135)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from plonky2_goldibear_amd import GpuContext, PolynomialBatch
+
+    ncols, log_n, rate_bits, cap_height = args.cols, args.log_n, 3, 4
+    n = 1 << log_n
+    ctx = GpuContext(local_rank)
+    host = splitmix64_matrix((0xC0FFEE ^ (ncols << 32) ^ log_n) + rank, ncols, n)
+    dev = torch.from_numpy(host.view(np.int64)).to("cuda:%d" % local_rank)
+    del host
+    torch.cuda.synchronize()
+
+    def step():
+        b = PolynomialBatch.from_values(ctx, dev, rate_bits, cap_height)
+        b.free()
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)
+    ctx.scope_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    scopes = {s: ctx.scope_ms(s) for s in ("IFFT", "FFT + blinding", "build Merkle tree")}
+    ctx.set_profiling(False)
+
+    if rank == 0:
+        steps = args.steps
+        ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps
+        merkle_ms = scopes["build Merkle tree"][0] / steps
+        alg_bytes = (2 + (1 << rate_bits)) * n * 8 * ncols  # (2 + 2^r) n s per column
+        achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
+        N = n << rate_bits
+        perms = N * (-(-ncols // 8)) + (N - (1 << cap_height))  # leaf sponge + internal nodes
+        out = {
+            "metric": "commits/s (PolynomialBatch::from_values, wires oracle of the 2^%d-row circuit)" % log_n,
+            "value": world * steps / dt, "unit": "commits/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "from_values: %d cols x 2^%d rows Goldilocks, rate_bits 3, cap_height 4, Poseidon-12" % (ncols, log_n),
+                       "field": "goldilocks", "log_n": log_n, "cols": ncols, "rate_bits": rate_bits, "cap_height": cap_height,
+                       "sharding": "one independent circuit per GPU, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "NTT pass = k_gl_intt_p1+p2+p3 (IFFT) + k_gl_lde_pa+pb (FFT + blinding)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": alg_bytes, "ms": ntt_ms},
+            "scopes_ms_per_step": {"IFFT": scopes["IFFT"][0] / steps, "FFT + blinding": scopes["FFT + blinding"][0] / steps,
+                                   "build Merkle tree": merkle_ms},
+            "merkle": {"permutations": perms, "Gperm_per_s": perms / (merkle_ms * 1e-3) / 1e9},
+        }
+        if not args.no_cpu_baseline:
+            sample = args.cpu_sample_log_n
+            if sample is None:
+                cores = os.cpu_count() or 1
+                sample = max(10, min(log_n, 19, 13 + (cores.bit_length() - 1)))  # sized for ~10-30 s of CPU work
+            out["cpu_baseline"] = cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,9 @@ gb_status gb_ctx_create(int device, gb_ctx** out);
 gb_status gb_ctx_destroy(gb_ctx* ctx);
 const char* gb_last_error(const gb_ctx* ctx); /* valid until the next call on ctx; ctx may be NULL */
 gb_status gb_ctx_synchronize(gb_ctx* ctx);
+/* Freed batches keep their device blocks in a per-context pool for reuse by later commits of the
+ * same shape (the reference allocates fresh Vecs per PolynomialBatch); this returns them to HIP. */
+gb_status gb_ctx_trim(gb_ctx* ctx);
 /* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
 gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out);
 

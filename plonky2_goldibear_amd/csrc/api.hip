@@ -52,12 +52,14 @@ struct gb_ctx {
     u64* tw4096_inv = nullptr;
     std::map<u32, GlTableSet> gl_tables;                    // by log_n
     std::map<std::pair<u32, u32>, GlCosetSet> gl_cosets;    // by (log_n, rate_bits)
+    std::multimap<size_t, void*> pool;                      // freed batch blocks by size (stream-ordered reuse)
     DeviceBuf scratch;                                      // grow-only workspace
     DeviceBuf small;                                        // small gather staging (rows, siblings)
 };
 
 struct gb_batch {
     gb_ctx* ctx = nullptr;
+    size_t coeffs_bytes = 0, lde_bytes = 0, levels_bytes = 0;
     u32 field = 0, log_n = 0, rate_bits = 0, cap_height = 0, nsalt = 0;
     size_t ncols = 0;
     u64* coeffs = nullptr;  // [ncols][n]
@@ -107,6 +109,30 @@ gb_status ensure(gb_ctx* ctx, DeviceBuf& buf, size_t bytes) {
     HIP_TRY(ctx, hipMalloc(&buf.p, bytes));
     buf.bytes = bytes;
     return GB_OK;
+}
+
+// Batch storage comes from a per-context pool: a prover commits batches of the same few shapes
+// over and over, and hipMalloc/hipFree of multi-GiB blocks would otherwise dominate.  All work of
+// a context is on one stream, so handing a freed block to a later commit is stream-ordered.
+hipError_t pool_alloc(gb_ctx* ctx, size_t bytes, void** out) {
+    auto it = ctx->pool.find(bytes);
+    if (it != ctx->pool.end()) {
+        *out = it->second;
+        ctx->pool.erase(it);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+        ctx->pool.clear();
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+void pool_free(gb_ctx* ctx, void* p, size_t bytes) {
+    if (p) ctx->pool.emplace(bytes, p);
 }
 
 gb_status upload(gb_ctx* ctx, const std::vector<u64>& host, u64** dev, std::vector<void*>* owned) {
@@ -223,12 +249,14 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     auto cleanup = [&](gb_status s) { gb_batch_free(b); return s; };
 
     void* p = nullptr;
-    hipError_t e;
-    if ((e = hipMalloc(&p, ncols * n * sizeof(u64))) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc coeffs"));
+    b->coeffs_bytes = ncols * n * sizeof(u64);
+    b->lde_bytes = width * N * sizeof(u64);
+    b->levels_bytes = 2 * N * 4 * sizeof(u64);
+    if (pool_alloc(ctx, b->coeffs_bytes, &p) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc coeffs"));
     b->coeffs = (u64*)p;
-    if ((e = hipMalloc(&p, width * N * sizeof(u64))) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc lde"));
+    if (pool_alloc(ctx, b->lde_bytes, &p) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc lde"));
     b->lde = (u64*)p;
-    if ((e = hipMalloc(&p, 2 * N * 4 * sizeof(u64))) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc digests"));
+    if (pool_alloc(ctx, b->levels_bytes, &p) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc digests"));
     b->levels = (u64*)p;
 
     const gbk::GlNttTables* tabs;
@@ -311,6 +339,7 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     if (ctx->tw4096_inv) hipFree(ctx->tw4096_inv);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->small.p) hipFree(ctx->small.p);
+    for (auto& kv : ctx->pool) hipFree(kv.second);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return GB_OK;
@@ -321,6 +350,15 @@ const char* gb_last_error(const gb_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 gb_status gb_ctx_synchronize(gb_ctx* ctx) {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GB_OK;
+}
+
+gb_status gb_ctx_trim(gb_ctx* ctx) {
+    if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+    ctx->pool.clear();
     return GB_OK;
 }
 
@@ -380,12 +418,10 @@ gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t
 gb_status gb_batch_free(gb_batch* b) {
     if (!b) return GB_OK;
     if (b->ctx) {
-        hipSetDevice(b->ctx->device);
-        hipStreamSynchronize(b->ctx->stream);
+        pool_free(b->ctx, b->coeffs, b->coeffs_bytes);
+        pool_free(b->ctx, b->lde, b->lde_bytes);
+        pool_free(b->ctx, b->levels, b->levels_bytes);
     }
-    if (b->coeffs) hipFree(b->coeffs);
-    if (b->lde) hipFree(b->lde);
-    if (b->levels) hipFree(b->levels);
     delete b;
     return GB_OK;
 }

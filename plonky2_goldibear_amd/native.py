@@ -22,6 +22,7 @@ SIGNATURES = {
     "gb_ctx_destroy": (_i32, [_vp]),
     "gb_last_error": (C.c_char_p, [_vp]),
     "gb_ctx_synchronize": (_i32, [_vp]),
+    "gb_ctx_trim": (_i32, [_vp]),
     "gb_ctx_stream": (_i32, [_vp, _pvp]),
     "gb_ctx_set_profiling": (_i32, [_vp, _i32]),
     "gb_ctx_scope_ms": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),

@@ -53,6 +53,10 @@ class GpuContext:
     def synchronize(self):
         N.check(self._lib.gb_ctx_synchronize(self.handle), self.handle)
 
+    def trim(self):
+        """Return pooled (freed-batch) device memory to HIP."""
+        N.check(self._lib.gb_ctx_trim(self.handle), self.handle)
+
     @property
     def stream(self):
         s = C.c_void_p()
