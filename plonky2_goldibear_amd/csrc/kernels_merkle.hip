@@ -11,6 +11,8 @@
 namespace gbk {
 
 using poseidon_gl::permute;
+using poseidon_gl::permute_lazy;
+using poseidon_gl::to_canonical;
 
 // hash/hashing.rs:100-123 (overwrite-mode sponge, rate 8) + plonk/config.rs:70-84 (hash_or_noop)
 __global__ __launch_bounds__(256) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
@@ -27,18 +29,18 @@ __global__ __launch_bounds__(256) void k_gl_merkle_leaves(const u64* __restrict_
         for (; c0 + 8 <= width; c0 += 8) {
 #pragma unroll
             for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
-            permute(s);
+            permute_lazy(s);  // capacity lanes stay lazy residues between absorptions
         }
         if (c0 < width) {
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
-            permute(s);
+            permute_lazy(s);
         }
     }
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * j);
-    o[0] = make_ulonglong2(s[0], s[1]);
-    o[1] = make_ulonglong2(s[2], s[3]);
+    o[0] = make_ulonglong2(to_canonical(s[0]), to_canonical(s[1]));
+    o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
 }
 
 // hash/hashing.rs:76-96 compress / Hasher::two_to_one
@@ -48,10 +50,10 @@ __global__ __launch_bounds__(256) void k_gl_merkle_level(const u64* __restrict__
     const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
     ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
     u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
-    permute(s);
+    permute_lazy(s);
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
-    o[0] = make_ulonglong2(s[0], s[1]);
-    o[1] = make_ulonglong2(s[2], s[3]);
+    o[0] = make_ulonglong2(to_canonical(s[0]), to_canonical(s[1]));
+    o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
 }
 
 // Level k node t (t < N>>k) sits, in the reference layout, inside subtree s = t >> (layers-k) at

@@ -3,8 +3,16 @@
 // Same function as the reference's PoseidonGoldilocks::poseidon (hash/poseidon_goldilocks.rs:912-922):
 // 4 full rounds, 22 partial rounds in the "fast" (v, w_hat, M_init) form (:899-909, :718-744),
 // 4 full rounds; x^7 s-box (:840-846); MDS = circulant(MDS_CIRC) + diag(MDS_DIAG) (:301-302,:547-557).
-// Round index loops stay rolled (uniform index -> scalar loads of the constants); the 12-lane
-// state loops are unrolled so the state lives in VGPRs.
+//
+// gfx950 cost model (tools/microbench_valu.hip): every 64-bit-result VALU op - v_mad_u64_u32,
+// v_lshl_add_u64, v_mul_* - issues at ~4.2 cycles per wave, plain 32-bit VOP2 ops at ~2.6, so the
+// work is counted in instructions, and a v_mad_u64_u32 (32x32+64) is the densest one.  Hence:
+//  * LAZY residues: a state word is any u64 congruent to the value; canonical form only at the end
+//    (tools/microbench_mulmod.hip: 70 vs 108 cycles per wave-mul);
+//  * dot products (w_hat row, M_init columns) are accumulated UNREDUCED as six carry-free 64-bit
+//    sums of 32-bit x 22-bit partial products (12 terms < 2^58) and reduced once;
+//  * the MDS layer is 24 mads per output on 32-bit halves, one fold per output.
+// Round loops stay rolled (uniform index -> scalar loads of the constants).
 #pragma once
 #include "gl_field.hpp"
 #include "poseidon_constants.h"
@@ -13,15 +21,40 @@ namespace poseidon_gl {
 
 using gl::u32;
 using gl::u64;
+typedef unsigned __int128 u128;
 
 static constexpr int WIDTH = 12, RATE = 8, HOUT = 4, N_PARTIAL = 22, HALF_FULL = 4;
+static constexpr u64 EPS = gl::EPS;
+
+// ------------------------------------------------------------------ constants
+struct Limb3 {
+    u32 l[3];  // b = l0 + l1 * 2^22 + l2 * 2^44
+};
+template <int N>
+struct LimbTable {
+    Limb3 v[N];
+};
+template <int N>
+constexpr LimbTable<N> split22(const u64 (&src)[N]) {
+    LimbTable<N> t{};
+    for (int i = 0; i < N; i++) {
+        t.v[i].l[0] = (u32)(src[i] & 0x3FFFFF);
+        t.v[i].l[1] = (u32)((src[i] >> 22) & 0x3FFFFF);
+        t.v[i].l[2] = (u32)(src[i] >> 44);
+    }
+    return t;
+}
+namespace raw {
+constexpr u64 WHATS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_W_HATS_LIST};
+constexpr u64 INIT[11 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX_LIST};
+}  // namespace raw
 
 __device__ static const u64 RC[GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN] = {GL_POSEIDON_ALL_ROUND_CONSTANTS_LIST};
 __device__ static const u64 FP_FIRST[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST};
 __device__ static const u64 FP_RC[22] = {GL_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS_LIST};
 __device__ static const u64 FP_VS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_VS_LIST};
-__device__ static const u64 FP_WHATS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_W_HATS_LIST};
-__device__ static const u64 FP_INIT[11 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX_LIST};
+__device__ static const LimbTable<22 * 11> WHATS_L = split22(raw::WHATS);
+__device__ static const LimbTable<11 * 11> INIT_L = split22(raw::INIT);
 
 // MDS_MATRIX_CIRC / MDS_MATRIX_DIAG (hash/poseidon_goldilocks.rs:301-302) as immediates
 __device__ __forceinline__ constexpr u32 mds_circ(int i) {
@@ -30,14 +63,86 @@ __device__ __forceinline__ constexpr u32 mds_circ(int i) {
 }
 static constexpr u32 MDS_DIAG0 = 8;
 
+// ------------------------------------------------------------------ lazy arithmetic (any u64 in, any u64 out)
+
+// (lo + 2^64 hi) mod p, not canonical.  2^64 = 2^32 - 1, 2^96 = -1.
+__device__ __forceinline__ u64 reduce128_lazy(u64 lo, u64 hi) {
+    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 t0, t2;
+    bool br = __builtin_usubll_overflow(lo, (u64)hh, &t0);
+    t0 -= br ? EPS : 0;
+    bool cy = __builtin_uaddll_overflow(t0, (u64)hl * EPS, &t2);
+    t2 += cy ? EPS : 0;
+    return t2;
+}
+__device__ __forceinline__ u64 reduce128_lazy(u128 x) { return reduce128_lazy((u64)x, (u64)(x >> 64)); }
+
+__device__ __forceinline__ void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    u64 p11 = (u64)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
+    lo = (p10 << 32) | (u32)p00;
+    hi = p11;
+}
+__device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
+    u64 lo, hi;
+    mul_wide(a, b, lo, hi);
+    return reduce128_lazy(lo, hi);
+}
+// a * b + c
+__device__ __forceinline__ u64 mul_add_lazy(u64 a, u64 b, u64 c) {
+    u64 lo, hi;
+    mul_wide(a, b, lo, hi);
+    u64 l2 = lo + c;
+    hi += l2 < lo;  // hi <= 2^64 - 2: cannot overflow
+    return reduce128_lazy(l2, hi);
+}
+// x lazy, rc canonical (< p): one carry fix is enough
+__device__ __forceinline__ u64 add_rc(u64 x, u64 rc) {
+    u64 s;
+    bool cy = __builtin_uaddll_overflow(x, rc, &s);
+    s += cy ? EPS : 0;
+    return s;
+}
+__device__ __forceinline__ u64 to_canonical(u64 x) { return gl::canon(x); }
+
 __device__ __forceinline__ u64 sbox(u64 x) {
-    u64 x2 = gl::sqr(x), x4 = gl::sqr(x2), x3 = gl::mul(x, x2);
-    return gl::mul(x3, x4);
+    u64 x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);
+    return mul_lazy(x3, x4);
 }
 
-// res[r] = sum_i s[(i+r)%12] * CIRC[i] + s[r]*DIAG[r].  Entries < 2^6: split each element into
-// 32-bit halves, accumulate the two 12-term sums in 64 bits (< 2^42), recombine and reduce once
-// (same decomposition as the reference's mds_layer :497-528, without its FFT form).
+// Unreduced dot product sum_i a_i * b_i for up to 16 terms: six carry-free 64-bit sums.
+struct Dot {
+    u64 t0[3], t1[3];
+    __device__ __forceinline__ Dot() : t0{0, 0, 0}, t1{0, 0, 0} {}
+    __device__ __forceinline__ void acc(u64 a, const Limb3& b) {
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            t0[k] += (u64)a0 * b.l[k];
+            t1[k] += (u64)a1 * b.l[k];
+        }
+    }
+    __device__ __forceinline__ void acc_small(u64 a, u32 c) {  // c < 2^22
+        t0[0] += (u64)(u32)a * c;
+        t1[0] += (u64)(u32)(a >> 32) * c;
+    }
+    __device__ __forceinline__ u64 finish() const {
+        u128 g0 = (u128)t0[0] + ((u128)t0[1] << 22) + ((u128)t0[2] << 44);
+        u128 g1 = (u128)t1[0] + ((u128)t1[1] << 22) + ((u128)t1[2] << 44);
+        u64 r1 = reduce128_lazy(g1);
+        u128 v = g0 + ((u128)r1 << 32);  // < 2^103 + 2^96
+        return reduce128_lazy(v);
+    }
+};
+
+// ------------------------------------------------------------------ layers
+
+// res[r] = sum_i s[(i+r)%12] * CIRC[i] + s[r]*DIAG[r]; entries < 2^6, so the two 32-bit halves
+// accumulate in 64 bits (< 2^41) and fold once: value = sl + 2^32 sh  (the decomposition of the
+// reference's mds_layer :497-528, without its FFT form).
 __device__ __forceinline__ void mds_layer(u64 (&s)[12]) {
     u32 lo[12], hi[12];
 #pragma unroll
@@ -57,11 +162,12 @@ __device__ __forceinline__ void mds_layer(u64 (&s)[12]) {
             sl += (u64)lo[0] * MDS_DIAG0;
             sh += (u64)hi[0] * MDS_DIAG0;
         }
-        // value = sl + 2^32 * sh  (< 2^75)
-        u64 t_lo = sh << 32, t_hi = sh >> 32;
-        u64 l = sl + t_lo;
-        u64 h = t_hi + (l < sl ? 1 : 0);
-        s[r] = gl::reduce128(l, h);
+        // sl + 2^32 (sh_lo + 2^32 sh_hi) = sl + sh_hi * EPS + (sh_lo << 32), sh_hi < 2^10
+        u64 t = sl + (sh >> 32) * EPS;  // < 2^43
+        u64 r2;
+        bool cy = __builtin_uaddll_overflow(t, sh << 32, &r2);
+        r2 += cy ? EPS : 0;
+        s[r] = r2;
     }
 }
 
@@ -69,7 +175,7 @@ __device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0) {
     for (int k = 0; k < HALF_FULL; k++) {
         const u64* rc = RC + 12 * (round0 + k);
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(gl::add(s[i], rc[i]));
+        for (int i = 0; i < 12; i++) s[i] = sbox(add_rc(s[i], rc[i]));
         mds_layer(s);
     }
 }
@@ -78,33 +184,41 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
     // partial_first_constant_layer (:632-638) + mds_partial_layer_init (:657-683)
     u64 t[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = gl::add(s[i], FP_FIRST[i]);
+    for (int i = 0; i < 12; i++) t[i] = add_rc(s[i], FP_FIRST[i]);
     s[0] = t[0];
 #pragma unroll
     for (int c = 1; c < 12; c++) {
-        u64 acc = 0;
+        Dot d;
 #pragma unroll
-        for (int r = 1; r < 12; r++) acc = gl::add(acc, gl::mul(t[r], FP_INIT[(r - 1) * 11 + (c - 1)]));
-        s[c] = acc;
+        for (int r = 1; r < 12; r++) d.acc(t[r], INIT_L.v[(r - 1) * 11 + (c - 1)]);
+        s[c] = d.finish();
     }
     for (int k = 0; k < N_PARTIAL; k++) {
-        const u64* wh = FP_WHATS + 11 * k;
+        const Limb3* wh = WHATS_L.v + 11 * k;
         const u64* vs = FP_VS + 11 * k;
-        u64 s0 = gl::add(sbox(s[0]), FP_RC[k]);
+        u64 s0 = add_rc(sbox(s[0]), FP_RC[k]);
         // mds_partial_layer_fast (:718-744): d = s0*(CIRC[0]+DIAG[0]) + sum_i s[i]*w_hat[i-1]
-        u64 d = gl::mul(s0, (u64)(mds_circ(0) + MDS_DIAG0));
+        Dot d;
+        d.acc_small(s0, mds_circ(0) + MDS_DIAG0);
 #pragma unroll
-        for (int i = 1; i < 12; i++) d = gl::add(d, gl::mul(s[i], wh[i - 1]));
+        for (int i = 1; i < 12; i++) d.acc(s[i], wh[i - 1]);
 #pragma unroll
-        for (int i = 1; i < 12; i++) s[i] = gl::add(s[i], gl::mul(s0, vs[i - 1]));
-        s[0] = d;
+        for (int i = 1; i < 12; i++) s[i] = mul_add_lazy(s0, vs[i - 1], s[i]);
+        s[0] = d.finish();
     }
 }
 
-__device__ __forceinline__ void permute(u64 (&s)[12]) {
+// state in: any u64 residues; state out: any u64 residues (call to_canonical before storing)
+__device__ __forceinline__ void permute_lazy(u64 (&s)[12]) {
     full_rounds(s, 0);
     partial_rounds(s);
     full_rounds(s, HALF_FULL + N_PARTIAL);
+}
+
+__device__ __forceinline__ void permute(u64 (&s)[12]) {
+    permute_lazy(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = to_canonical(s[i]);
 }
 
 }  // namespace poseidon_gl
