@@ -66,6 +66,8 @@ def lib():
         L.gbo_gl_inv.restype = C.c_uint64
         L.gbo_gl_two_adic_generator.argtypes = [C.c_uint]
         L.gbo_gl_two_adic_generator.restype = C.c_uint64
+        L.gbo_gl_powers.argtypes = [C.c_uint64, C.c_size_t, _u64p]
+        L.gbo_gl_scale_vec.argtypes = [_u64p, C.c_uint64, C.c_size_t, _u64p]
         L.gbo_num_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -257,6 +259,19 @@ class Challenger:
 
     def state(self):
         return np.frombuffer(self._buf.raw, dtype=np.uint64).copy()
+
+
+def powers(base, n):
+    out = np.empty(n, dtype=np.uint64)
+    lib().gbo_gl_powers(int(base), n, out)
+    return out
+
+
+def scale_vec(a, k):
+    a = _a(a)
+    out = np.empty_like(a)
+    lib().gbo_gl_scale_vec(a, int(k), a.size, out)
+    return out
 
 
 def splitmix64_fill(seed, count, modulus=GL_P):

@@ -449,3 +449,12 @@ int gbo_num_threads(void) {
     return 1;
 #endif
 }
+
+/* out[i] = base^i ; out[i] = a[i] * k  (vector helpers for the python circuit restatement) */
+void gbo_gl_powers(gl_t base, size_t n, gl_t *out) {
+    gl_t x = 1;
+    for (size_t i = 0; i < n; i++) { out[i] = x; x = gl_mul(x, base); }
+}
+void gbo_gl_scale_vec(const gl_t *a, gl_t k, size_t n, gl_t *out) {
+    for (size_t i = 0; i < n; i++) out[i] = gl_mul(a[i], k);
+}

@@ -1,0 +1,225 @@
+"""TEST ORACLE - restatement of the dummy circuit (bench form) and of the PLONK verifier identity.
+
+Test infrastructure only.  Follows (paths relative to /root/reference/plonky2):
+  examples/bench_recursion.rs:87-122   dummy_proof: 2^(k-1)+1 NoopGates -> 2^k rows
+  src/plonk/circuit_builder.rs:1110-1312  build(): PublicInputGate row, ConstantGate row for the
+       `zero` target (src/plonk/config.rs:135-166 with no public inputs), padding, selectors
+       (src/gates/selectors.rs:125-159 single-group case), constant_polys (:982-1003),
+       k_is (field/src/cosets.rs:8-21), sigma (src/plonk/permutation_argument.rs:108-157),
+       circuit_digest (:1300-1312, hash_pad src/plonk/config.rs:58-66)
+  src/iop/witness.rs:359-371           full_witness: unset wires are zero
+  src/plonk/verifier.rs:17-128, src/plonk/vanishing_poly.rs:40-170   verify()
+The gate set is exactly {NoopGate, ConstantGate{2}, PublicInputGate<4>} sorted by (degree, id).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import oracle as O
+from . import verifier as V
+
+P = O.GL_P
+
+
+class CircuitConfig:
+    """standard_recursion_config_gl (src/plonk/circuit_data.rs:102-159) with num_challenges overridable
+    (2^16 / 2^20 rows need num_challenges = 3)."""
+
+    def __init__(self, num_challenges=2, num_wires=135, num_routed_wires=80, num_constants=2, rate_bits=3, cap_height=4,
+                 proof_of_work_bits=16, num_query_rounds=28, arity_bits=4, final_poly_bits=5, max_quotient_degree_factor=8,
+                 security_bits=100):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+def reduction_arity_bits(cfg, degree_bits):
+    """fri/reduction_strategies.rs:44-56 ConstantArityBits"""
+    out, db = [], degree_bits
+    while db > cfg.final_poly_bits and db + cfg.rate_bits - cfg.arity_bits >= cfg.cap_height:
+        out.append(cfg.arity_bits)
+        db -= cfg.arity_bits
+    return out
+
+
+class DummyCircuit:
+    """CircuitData of the bench-form dummy circuit with 2^degree_bits rows (degree_bits >= 3)."""
+
+    GATE_NOOP, GATE_CONSTANT, GATE_PI = 0, 1, 2  # sorted by (degree, id): Noop(0), "ConstantGate {..}"(1), "PublicInputGate<4>"(1)
+
+    def __init__(self, degree_bits, cfg=None, check_security=True):
+        cfg = cfg or CircuitConfig()
+        assert degree_bits >= 3
+        if check_security:  # circuit_builder.rs:1187-1192
+            assert (64 - degree_bits) * cfg.num_challenges >= cfg.security_bits, "num_challenges too small for this degree"
+        self.cfg, self.degree_bits = cfg, degree_bits
+        n = 1 << degree_bits
+        self.n = n
+        num_noops = (1 << (degree_bits - 1)) + 1
+        self.pi_row, self.const_row = num_noops, num_noops + 1
+        assert self.const_row < n
+        # selector column: gate index per row; constants: all zero (the only constant is 0)
+        sel = np.zeros(n, dtype=np.uint64)
+        sel[self.pi_row] = self.GATE_PI
+        sel[self.const_row] = self.GATE_CONSTANT
+        consts = np.zeros((cfg.num_constants, n), dtype=np.uint64)
+        self.num_constants = 1 + cfg.num_constants
+        self.k_is = np.array([pow(7, i, P) for i in range(cfg.num_routed_wires)], dtype=np.uint64)
+        w = pow(1753635133440165772, 1 << (32 - degree_bits), P)
+        self.subgroup = sub = O.powers(w, n)
+        # sigma: identity except the single copy class {(pi,0..3), (const,0)} in (row, column) order
+        sig = np.empty((cfg.num_routed_wires, n), dtype=np.uint64)
+        for j in range(cfg.num_routed_wires):
+            sig[j] = O.scale_vec(sub, int(self.k_is[j]))
+        cls = [(self.pi_row, 0), (self.pi_row, 1), (self.pi_row, 2), (self.pi_row, 3), (self.const_row, 0)]
+        for t, (row, col) in enumerate(cls):
+            nrow, ncol = cls[(t + 1) % len(cls)]
+            sig[col, row] = int(self.k_is[ncol]) * int(sub[nrow]) % P
+        self.constants_sigmas = np.concatenate([sel[None, :], consts, sig]).astype(np.uint64)
+        self.sigma = sig
+        self.num_partial_products = -(-cfg.num_routed_wires // cfg.max_quotient_degree_factor) - 1
+        self.reduction_arity_bits = reduction_arity_bits(cfg, degree_bits)
+        self._digest = None
+        self.constants_sigmas_cap = None
+
+    def set_cap(self, cap):
+        """circuit_digest = hash_no_pad(cap.flatten() ++ hash_pad(domain_sep = []) ++ [degree_bits])"""
+        cap = np.asarray(cap, dtype=np.uint64)
+        self.constants_sigmas_cap = cap
+        dom = O.hash_no_pad(np.array([1, 0, 0, 0, 0, 0, 0, 1], dtype=np.uint64))  # hash_pad([]) (config.rs:58-66)
+        parts = np.concatenate([cap.ravel(), dom, np.array([self.degree_bits], dtype=np.uint64)])
+        self._digest = O.hash_no_pad(parts)
+        return self._digest
+
+    @property
+    def circuit_digest(self):
+        if self._digest is None:
+            b = O.PolynomialBatch.from_values(self.constants_sigmas, self.cfg.rate_bits, self.cfg.cap_height)
+            self.set_cap(b.cap)
+        return self._digest
+
+    def witness(self, seed=0):
+        """MatrixWitness wire_values[column][row]: zeros except the PublicInputGate row's wires 4..,
+        filled from SplitMix64 (stands in for RandomValueGenerator's F::rand())."""
+        cfg = self.cfg
+        w = np.zeros((cfg.num_wires, self.n), dtype=np.uint64)
+        w[4:, self.pi_row] = O.splitmix64_fill(0x9E3779B97F4A7C15 + seed, cfg.num_wires - 4)
+        return w
+
+    def common_data(self):
+        """The dict shape oracle/verifier.py uses."""
+        cfg = self.cfg
+        fri_cfg = dict(rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, num_query_rounds=cfg.num_query_rounds,
+                       proof_of_work_bits=cfg.proof_of_work_bits)
+        return dict(
+            config=dict(num_wires=cfg.num_wires, num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
+                        num_challenges=cfg.num_challenges, fri_config=fri_cfg, zero_knowledge=False),
+            fri_params=dict(config=fri_cfg, reduction_arity_bits=self.reduction_arity_bits, degree_bits=self.degree_bits,
+                            hiding=False),
+            quotient_degree_factor=cfg.max_quotient_degree_factor, num_constants=self.num_constants,
+            num_partial_products=self.num_partial_products, num_lookup_polys=0, k_is=[int(k) for k in self.k_is],
+            num_public_inputs=0)
+
+    def c_cfg(self):
+        cfg = self.cfg
+        vals = [cfg.num_wires, cfg.num_routed_wires, self.num_constants, cfg.num_challenges, cfg.rate_bits, cfg.cap_height,
+                cfg.proof_of_work_bits, cfg.num_query_rounds, cfg.arity_bits, cfg.final_poly_bits,
+                cfg.max_quotient_degree_factor, self.degree_bits, 1, self.GATE_NOOP, self.GATE_CONSTANT, self.GATE_PI,
+                cfg.num_constants]
+        return (C.c_uint * len(vals))(*vals)
+
+
+def prove_cpu(circ, witness, public_inputs=()):
+    """Run the CPU oracle prover; returns (proof_bytes, debug challenges)."""
+    L = O.lib()
+    fn = L.gbo_gl_prove_dummy
+    fn.restype = C.c_int
+    c = circ.cfg.num_challenges
+    cs = np.ascontiguousarray(circ.constants_sigmas)
+    wit = np.ascontiguousarray(witness, dtype=np.uint64)
+    pis = np.ascontiguousarray(list(public_inputs) or [0], dtype=np.uint64)
+    dig = np.ascontiguousarray(circ.circuit_digest)
+    cap = 64 << 20
+    out = np.zeros(cap, dtype=np.uint8)
+    out_len = C.c_size_t()
+    dbg = np.zeros(3 * c + 5, dtype=np.uint64)
+    rc = fn(circ.c_cfg(), cs.ctypes.data_as(C.c_void_p), dig.ctypes.data_as(C.c_void_p), circ.k_is.ctypes.data_as(C.c_void_p),
+            wit.ctypes.data_as(C.c_void_p), pis.ctypes.data_as(C.c_void_p), C.c_size_t(len(public_inputs)),
+            out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("oracle prover failed: rc=%d" % rc)
+    return out[: out_len.value].tobytes(), dbg
+
+
+# ----------------------------------------------------------------------------- verify()
+def eval_vanishing_poly(circ, zeta, openings, pi_hash, betas, gammas, alphas):
+    """plonk/vanishing_poly.rs:40-170 for the dummy gate set, at an extension point."""
+    cfg = circ.cfg
+    e = V
+    n = circ.n
+    consts, wires, sig = openings["constants"], openings["wires"], openings["plonk_sigmas"]
+    zs, zs_next, pps = openings["plonk_zs"], openings["plonk_zs_next"], openings["partial_products"]
+    qdf, num_prods = cfg.max_quotient_degree_factor, circ.num_partial_products
+    # gate constraints (filter * unfiltered; compute_filter gates/gate.rs:391-404)
+    s = consts[0]
+    gc = consts[1:]
+    cons = [(0, 0)] * 4
+    for g in range(3):
+        f = (1, 0)
+        for i in range(3):
+            if i != g:
+                f = e.emul(f, e.esub(e.efrom(i), s))
+        if g == circ.GATE_CONSTANT:
+            for j in range(cfg.num_constants):
+                cons[j] = e.eadd(cons[j], e.emul(f, e.esub(gc[j], wires[j])))
+        elif g == circ.GATE_PI:
+            for j in range(4):
+                cons[j] = e.eadd(cons[j], e.emul(f, e.esub(wires[j], e.efrom(int(pi_hash[j])))))
+    # eval_l_0 (plonk_common.rs:56-66)
+    zn = e.epow(zeta, n)
+    if zeta == (1, 0):
+        l0 = (1, 0)
+    else:
+        l0 = e.ediv(e.esub(zn, (1, 0)), e.emul(e.efrom(n), e.esub(zeta, (1, 0))))
+    z1_terms, pp_terms = [], []
+    for i in range(cfg.num_challenges):
+        z1_terms.append(e.emul(l0, e.esub(zs[i], (1, 0))))
+        nums = [e.eadd(e.eadd(wires[j], e.emul(e.efrom(betas[i]), e.emul(e.efrom(int(circ.k_is[j])), zeta))), e.efrom(gammas[i]))
+                for j in range(cfg.num_routed_wires)]
+        dens = [e.eadd(e.eadd(wires[j], e.emul(e.efrom(betas[i]), sig[j])), e.efrom(gammas[i])) for j in range(cfg.num_routed_wires)]
+        accs = [zs[i]] + pps[i * num_prods:(i + 1) * num_prods] + [zs_next[i]]
+        for m in range(num_prods + 1):
+            npd, dpd = (1, 0), (1, 0)
+            for j in range(m * qdf, min((m + 1) * qdf, cfg.num_routed_wires)):
+                npd, dpd = e.emul(npd, nums[j]), e.emul(dpd, dens[j])
+            pp_terms.append(e.esub(e.emul(accs[m], npd), e.emul(accs[m + 1], dpd)))
+    terms = z1_terms + pp_terms + cons
+    out = []
+    for a in alphas:
+        cum = (0, 0)
+        for t in reversed(terms):
+            cum = e.eadd(t, e.emul(cum, e.efrom(a)))
+        out.append(cum)
+    return out
+
+
+def verify(circ, proof_bytes, stats=None):
+    """plonk/verifier.rs:17-128: transcript, vanishing identity at zeta, FRI.  Raises AssertionError."""
+    cd = circ.common_data()
+    proof, pis = V.read_proof_with_pis(proof_bytes, cd)
+    assert len(pis) == 0
+    ch = V.get_challenges(proof, pis, circ.circuit_digest, cd)
+    pi_hash = O.hash_no_pad(np.zeros(0, np.uint64))
+    van = eval_vanishing_poly(circ, ch["plonk_zeta"], proof["openings"], pi_hash, ch["plonk_betas"], ch["plonk_gammas"],
+                              ch["plonk_alphas"])
+    zeta_pow = V.epow(ch["plonk_zeta"], circ.n)
+    z_h = V.esub(zeta_pow, (1, 0))
+    q = proof["openings"]["quotient_polys"]
+    qdf = circ.cfg.max_quotient_degree_factor
+    for i in range(circ.cfg.num_challenges):
+        acc = (0, 0)
+        for t in reversed(q[i * qdf:(i + 1) * qdf]):
+            acc = V.eadd(V.emul(acc, zeta_pow), t)
+        assert van[i] == V.emul(z_h, acc), "vanishing(zeta) != Z_H(zeta) * quotient(zeta) for challenge %d" % i
+    caps = [[[int(x) for x in h] for h in circ.constants_sigmas_cap], proof["wires_cap"], proof["zs_cap"], proof["quotient_cap"]]
+    V.verify_fri(proof, ch, caps, cd, stats)
+    return True
