@@ -106,6 +106,44 @@ gb_status gb_batch_leaves(gb_batch* b, void* out);
 /* device pointers for zero-copy chaining: coeffs [ncols][n], lde [ncols+salt][N] in leaf order */
 gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** digest_levels);
 
+/* ---- circuit + prove() ------------------------------------------------------------------------
+ * gb_circuit holds what CircuitBuilder::build() leaves in ProverOnlyCircuitData / CommonCircuitData
+ * for the prover (plonk/circuit_builder.rs:1214-1312): the constants||sigmas commitment (committed
+ * here, :1230-1239), the sigma values, k_is, and circuit_digest (:1300-1312, empty domain separator).
+ * Only the gate set of the reference's dummy circuit is evaluated on the GPU:
+ * gates sorted by (degree, id) = [NoopGate, ConstantGate{num_constants}, PublicInputGate], one selector
+ * column (gates/selectors.rs:142-159); anything else is GB_ERR_UNSUPPORTED and stays on the CPU path. */
+typedef struct gb_circuit gb_circuit;
+typedef struct gb_circuit_config {
+    uint32_t field;                 /* GB_GOLDILOCKS */
+    uint32_t degree_bits;
+    uint32_t num_wires, num_routed_wires, num_constants; /* CircuitConfig (plonk/circuit_data.rs:63-93) */
+    uint32_t num_challenges, max_quotient_degree_factor;
+    uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds; /* FriConfig (fri/mod.rs:25-45) */
+    uint32_t arity_bits, final_poly_bits;  /* FriReductionStrategy::ConstantArityBits */
+    uint32_t num_selectors;         /* 1 */
+    uint32_t gate_constant, gate_pi;/* selector values of ConstantGate / PublicInputGate (NoopGate is the third) */
+} gb_circuit_config;
+
+/* constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits] VALUES on H_n
+ * (selector, constants, sigma columns - circuit_builder.rs:1198-1229); k_is: [num_routed_wires]. */
+gb_status gb_circuit_create(gb_ctx* ctx, const gb_circuit_config* cfg, const void* constants_sigmas, const void* k_is,
+                            uint32_t flags, gb_circuit** out);
+gb_status gb_circuit_free(gb_circuit* c);
+/* VerifierOnlyCircuitData: constants_sigmas_cap [2^cap_height][4] and circuit_digest [4] */
+gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_out);
+/* prove_with_partition_witness -> internal_prove_with_partition_witness (plonk/prover.rs:160-447):
+ * witness = MatrixWitness.wire_values [num_wires][n] (iop/witness.rs:277-284), already generated.
+ * Writes ProofWithPublicInputs bytes (util/serialization/mod.rs:2134-2151) to proof_out; *proof_len
+ * is the size needed.  The PoW witness is the MINIMUM valid nonce (the reference's find_any with one
+ * thread).  GB_ERR_PERM_ARG_ZERO mirrors ProverError::InvZeroPermArg (prover.rs:512-514): the caller
+ * re-randomises the random wire and retries, as prover.rs:186-226 does. */
+#define GB_ERR_PERM_ARG_ZERO 16
+#define GB_ERR_OPENING_IN_SUBGROUP 17
+#define GB_ERR_BUFFER_TOO_SMALL 18
+gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uint64_t* public_inputs,
+                   size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);
+
 /* ---- bare kernels (parity tests and microbenchmarks) ---------------------------------------- */
 /* `count` Poseidon-12 (GL) / Poseidon2-16 (BB) permutations: in/out [count][width], host memory.
  * PoseidonGoldilocks::poseidon (hash/poseidon_goldilocks.rs:912-922). */

@@ -9,6 +9,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -51,7 +52,7 @@ struct gb_ctx {
     u64* tw4096_fwd = nullptr;
     u64* tw4096_inv = nullptr;
     std::map<u32, GlTableSet> gl_tables;                    // by log_n
-    std::map<std::pair<u32, u32>, GlCosetSet> gl_cosets;    // by (log_n, rate_bits)
+    std::map<std::tuple<u32, u32, u64, int>, GlCosetSet> gl_cosets;  // by (log_n, rate_bits, shift, inverse)
     std::multimap<size_t, void*> pool;                      // freed batch blocks by size (stream-ordered reuse)
     DeviceBuf scratch;                                      // grow-only workspace
     DeviceBuf small;                                        // small gather staging (rows, siblings)
@@ -190,10 +191,11 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
     return GB_OK;
 }
 
-// coset c (block c of n leaves) has shift 7 * w_N^bitrev_r(c): leaf j = c*n + jl is the LDE
-// point 7 * w_N^bitrev_logN(j) (fri/oracle.rs:109 + polynomial/mod.rs:282-295)
-gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, const gbk::GlCosetTables** out) {
-    auto key = std::make_pair(log_n, rate_bits);
+// coset c (block c of n leaves) has shift s_c = shift * w_N^bitrev_r(c): leaf j = c*n + jl is the LDE
+// point shift * w_N^bitrev_logN(j) (fri/oracle.rs:109 + polynomial/mod.rs:282-295; shift = 7, or
+// 7^(arity^l) for FRI layer l, fri/prover.rs:122-123).  inverse: tables of s_c^-1 instead.
+gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u64 shift, bool inverse, const gbk::GlCosetTables** out) {
+    auto key = std::make_tuple(log_n, rate_bits, shift, inverse ? 1 : 0);
     auto it = ctx->gl_cosets.find(key);
     if (it != ctx->gl_cosets.end()) { *out = &it->second.t; return GB_OK; }
     size_t n = (size_t)1 << log_n;
@@ -202,7 +204,8 @@ gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, const gbk::GlCose
     u64 wN = gl::two_adic_generator(log_n + rate_bits);
     std::vector<u64> lo(nc * nlo), hi(nc * nhi);
     for (u32 c = 0; c < nc; c++) {
-        u64 s = gl::mul(gl::GENERATOR, gl::pow(wN, bitrev32(c, rate_bits)));
+        u64 s = gl::mul(shift, gl::pow(wN, bitrev32(c, rate_bits)));
+        if (inverse) s = gl::inv(s);
         std::vector<u64> pl = powers(s, nlo), ph = powers(gl::pow(s, 4096), nhi);
         std::memcpy(&lo[c * nlo], pl.data(), nlo * sizeof(u64));
         std::memcpy(&hi[c * nhi], ph.data(), nhi * sizeof(u64));
@@ -263,7 +266,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     const gbk::GlCosetTables* cos;
     gb_status s;
     if ((s = gl_tables_for(ctx, log_n, &tabs))) return cleanup(s);
-    if ((s = gl_cosets_for(ctx, log_n, rate_bits, &cos))) return cleanup(s);
+    if ((s = gl_cosets_for(ctx, log_n, rate_bits, gl::GENERATOR, false, &cos))) return cleanup(s);
 
     hipStream_t st = ctx->stream;
     const u64* src = static_cast<const u64*>(cols);
@@ -559,3 +562,5 @@ gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uin
 }
 
 }  // extern "C"
+
+#include "prover_host.inc"

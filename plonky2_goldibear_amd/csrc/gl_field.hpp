@@ -71,4 +71,31 @@ __host__ __device__ inline u64 two_adic_generator(unsigned bits) {
     return g;
 }
 
+// ---- quadratic extension F[x]/(x^2 - 7): BinomialExtensionField<Goldilocks, 2> (field/src/types.rs:25-29)
+static constexpr u64 EXT_W = 7;
+struct ext2 {
+    u64 c0, c1;
+};
+__host__ __device__ __forceinline__ ext2 e2(u64 a, u64 b = 0) { return ext2{a, b}; }
+__host__ __device__ __forceinline__ ext2 add(ext2 a, ext2 b) { return ext2{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+__host__ __device__ __forceinline__ ext2 sub(ext2 a, ext2 b) { return ext2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+__host__ __device__ __forceinline__ ext2 mul(ext2 a, ext2 b) {
+    return ext2{add(mul(a.c0, b.c0), mul(EXT_W, mul(a.c1, b.c1))), add(mul(a.c0, b.c1), mul(a.c1, b.c0))};
+}
+__host__ __device__ __forceinline__ ext2 scale(ext2 a, u64 s) { return ext2{mul(a.c0, s), mul(a.c1, s)}; }
+__host__ __device__ inline ext2 inv(ext2 a) {
+    u64 nrm = sub(sqr(a.c0), mul(EXT_W, sqr(a.c1)));
+    u64 ni = inv(nrm);
+    return ext2{mul(a.c0, ni), mul(neg(a.c1), ni)};
+}
+__host__ __device__ inline ext2 pow(ext2 b, u64 e) {
+    ext2 r = e2(1);
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
 }  // namespace gl

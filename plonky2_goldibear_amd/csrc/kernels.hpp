@@ -60,4 +60,63 @@ void u64_transpose_to_rows(const u64* cols, size_t col_stride, u32 width, u64 ro
 // raw permutation of `count` states (tests / microbenchmarks)
 void gl_poseidon_permute(const u64* in, u64* out, u64 count, hipStream_t stream);
 
+// ---------------------------------------------------------------- prover (kernels_prover.hip)
+
+static constexpr u32 MAX_CHUNKS = 32, MAX_CHALLENGES = 16, MAX_RATE = 16;
+
+struct PowTab {      // base^e = lo[e & (2^lo_bits - 1)] * hi[e >> lo_bits]
+    const u64* lo;
+    const u64* hi;
+    u32 lo_bits;
+};
+struct ExtPowTab {   // same for an extension-field base; entries are (c0, c1) pairs
+    const u64* lo;
+    const u64* hi;
+    u32 lo_bits;
+};
+struct CosetPow {    // per coset c: shift_c^t = lo[c][t % nlo] * hi[c][t / nlo]
+    const u64* lo;
+    const u64* hi;
+    u32 nlo, nhi;
+};
+struct ZsParams {
+    u32 log_n, num_routed, num_challenges, chunk /* quotient_degree_factor */, nchunks;
+    PowTab w_n;      // subgroup generator powers
+};
+struct QuotientParams {
+    u32 log_n, rate_bits, num_challenges, num_routed, num_constants /* selectors + constants */, num_selectors;
+    u32 chunk, nchunks, nterms;
+    u32 gate_constant, gate_pi, num_gate_consts;
+    PowTab w_N;      // LDE domain generator powers
+};
+struct PolyGroups {
+    const u64* ptr[4];
+    u32 ncols[4];
+    u32 ngroups;
+};
+struct PowState {
+    u64 s[12];
+    u32 pos;
+};
+
+void gl_zs_partial_products(const ZsParams& p, const u64* witness, const u64* sigma, const u64* k_is, const u64* betas,
+                            const u64* gammas, u64* q_tmp, u64* zloc_tmp, u64* totals_tmp, u32* err, u64* out, hipStream_t st);
+void gl_quotient_values(const QuotientParams& p, const u64* cs, const u64* wires, const u64* zs, const u64* uniforms, u64* qv,
+                        hipStream_t st);
+void gl_quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const u64* a, const u64* mat, const CosetPow& inv_shift,
+                         u64* out, hipStream_t st);
+void gl_ext_pow_table(const ExtPowTab& z, size_t n, u64* table, hipStream_t st);
+void gl_eval_columns(const u64* coeffs, size_t ncols, size_t n, const u64* ztab, u64* partial_tmp, u64* out, hipStream_t st);
+void gl_reduce_polys(const PolyGroups& g, size_t n, const u64* apow, u64* comp, hipStream_t st);
+void gl_divide_by_linear_accumulate(const u64* comp, size_t n, const ExtPowTab& z, const ExtPowTab& zinv, const u64 shift[2],
+                                    int first, u64* sloc_tmp, u64* totals_tmp, u64* final_poly, hipStream_t st);
+void gl_ext_split(const u64* src, size_t n, u64* dst, hipStream_t st);
+void gl_fri_leaves(const u64* v0, const u64* v1, u32 arity_bits, u64 num_leaves, u64* out, hipStream_t st);
+void gl_fri_fold(const u64* in, size_t in_len, u32 arity_bits, const u64 beta[2], u64* out, hipStream_t st);
+void gl_pow_grind(const PowState& s, u64 start, u64 count, u32 min_lz, u64* result, hipStream_t st);
+void gl_gather_rows_multi(const u64* cols, size_t stride, u32 width, const u64* idx, u32 nidx, u64* rows, hipStream_t st);
+void gl_gather_fri_leaves(const u64* v0, const u64* v1, u32 arity_bits, const u64* idx, u32 nidx, u64* out, hipStream_t st);
+void gl_gather_siblings_multi(const u64* levels, u32 log_leaves, u32 cap_height, const u64* idx, u32 nidx, u64* out,
+                              hipStream_t st);
+
 }  // namespace gbk

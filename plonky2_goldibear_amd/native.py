@@ -9,6 +9,7 @@ import os
 from . import build as _build
 
 GB_OK, GB_ERR_INVALID, GB_ERR_HIP, GB_ERR_OOM, GB_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+GB_ERR_PERM_ARG_ZERO, GB_ERR_OPENING_IN_SUBGROUP, GB_ERR_BUFFER_TOO_SMALL = 16, 17, 18
 GB_GOLDILOCKS, GB_BABYBEAR = 0, 1
 GB_INPUT_HOST, GB_INPUT_DEVICE = 0, 1
 GB_SALT_SIZE = 4
@@ -39,6 +40,10 @@ SIGNATURES = {
     "gb_batch_leaves": (_i32, [_vp, _vp]),
     "gb_batch_device_ptrs": (_i32, [_vp, _pvp, _pvp, _pvp]),
     "gb_permute": (_i32, [_vp, _u32, _vp, _vp, _u64]),
+    "gb_circuit_create": (_i32, [_vp, _vp, _vp, _vp, _u32, _pvp]),
+    "gb_circuit_free": (_i32, [_vp]),
+    "gb_circuit_verifier_data": (_i32, [_vp, _vp, _vp]),
+    "gb_prove": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
 }
 
 _lib = None
@@ -75,6 +80,10 @@ class GoldibearError(RuntimeError):
         self.status = status
 
 
+class PermArgZeroError(GoldibearError):
+    """GB_ERR_PERM_ARG_ZERO: ProverError::InvZeroPermArg (plonk/prover.rs:512-514) - re-randomise and retry."""
+
+
 class ShapeError(GoldibearError, ValueError):
     """GB_ERR_INVALID: where the reference would assert!/panic! on a shape violation."""
 
@@ -84,4 +93,5 @@ def check(status, ctx_handle=None):
         return
     msg = load().gb_last_error(ctx_handle)
     msg = msg.decode() if msg else ""
-    raise (ShapeError if status == GB_ERR_INVALID else GoldibearError)(status, msg)
+    cls = {GB_ERR_INVALID: ShapeError, GB_ERR_PERM_ARG_ZERO: PermArgZeroError}.get(status, GoldibearError)
+    raise cls(status, msg)

@@ -25,6 +25,9 @@ _live_contexts = weakref.WeakSet()
 
 @atexit.register
 def _shutdown():
+    from . import prover as _prover
+    for c in list(_prover._live_circuits):
+        c.free()
     for b in list(_live_batches):
         b.free()
     for c in list(_live_contexts):

@@ -1,0 +1,83 @@
+"""Host-side mirror of the reference's circuit/prover entry points, over the C ABI.
+
+`CircuitData` stands for what `CircuitBuilder::build()` returns (plonk/circuit_builder.rs:1373-1378):
+`prover_only` (constants_sigmas_commitment resident on the GPU, sigmas, circuit_digest) and
+`verifier_only` (constants_sigmas_cap, circuit_digest).  `prove(witness, public_inputs)` is
+`prove_with_partition_witness` (plonk/prover.rs:160-447) from an already generated
+`MatrixWitness.wire_values` matrix to `ProofWithPublicInputs` bytes.
+"""
+import ctypes as C
+import sys
+import weakref
+
+import numpy as np
+
+from . import native as N
+from .polynomial_batch import _as_input, _live_contexts  # noqa: F401
+
+_live_circuits = weakref.WeakSet()
+
+
+class gb_circuit_config(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in (
+        "field", "degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges",
+        "max_quotient_degree_factor", "rate_bits", "cap_height", "proof_of_work_bits", "num_query_rounds",
+        "arity_bits", "final_poly_bits", "num_selectors", "gate_constant", "gate_pi")]
+
+
+class CircuitData:
+    def __init__(self, ctx, degree_bits, constants_sigmas, k_is, *, num_wires=135, num_routed_wires=80, num_constants=2,
+                 num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16,
+                 num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1, gate_constant=1, gate_pi=2,
+                 field=N.GB_GOLDILOCKS):
+        self.ctx, self._lib = ctx, ctx._lib
+        self.cfg = gb_circuit_config(field, degree_bits, num_wires, num_routed_wires, num_constants, num_challenges,
+                                     max_quotient_degree_factor, rate_bits, cap_height, proof_of_work_bits,
+                                     num_query_rounds, arity_bits, final_poly_bits, num_selectors, gate_constant, gate_pi)
+        ptr, shape, flags, keep = _as_input(constants_sigmas)
+        want = (num_selectors + num_constants + num_routed_wires, 1 << degree_bits)
+        if tuple(shape) != want:
+            raise N.ShapeError(N.GB_ERR_INVALID, "constants_sigmas must be %r, got %r" % (want, tuple(shape)))
+        k = np.ascontiguousarray(k_is, dtype=np.uint64)
+        if k.shape != (num_routed_wires,):
+            raise N.ShapeError(N.GB_ERR_INVALID, "k_is must have num_routed_wires entries")
+        if flags == N.GB_INPUT_DEVICE:
+            import torch
+            kd = torch.from_numpy(k.view(np.int64)).to("cuda:%d" % ctx.device)
+            kptr, keep2 = kd.data_ptr(), kd
+        else:
+            kptr, keep2 = k.ctypes.data, k
+        h = C.c_void_p()
+        N.check(self._lib.gb_circuit_create(ctx.handle, C.byref(self.cfg), ptr, kptr, flags, C.byref(h)), ctx.handle)
+        del keep, keep2
+        self.handle = h
+        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        dig = np.empty(4, dtype=np.uint64)
+        N.check(self._lib.gb_circuit_verifier_data(h, cap.ctypes.data, dig.ctypes.data), ctx.handle)
+        self.constants_sigmas_cap, self.circuit_digest = cap, dig
+        self._proof_buf = None
+        _live_circuits.add(self)
+
+    def prove(self, witness, public_inputs=()):
+        ptr, shape, flags, keep = _as_input(witness)
+        want = (self.cfg.num_wires, 1 << self.cfg.degree_bits)
+        if tuple(shape) != want:
+            raise N.ShapeError(N.GB_ERR_INVALID, "witness must be %r, got %r" % (want, tuple(shape)))
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        if self._proof_buf is None:
+            self._proof_buf = np.empty(8 << 20, dtype=np.uint8)
+        n = C.c_size_t()
+        st = self._lib.gb_prove(self.handle, ptr, flags, pis.ctypes.data if pis.size else None, pis.size,
+                                self._proof_buf.ctypes.data, self._proof_buf.size, C.byref(n))
+        N.check(st, self.ctx.handle)
+        del keep
+        return self._proof_buf[: n.value].tobytes()
+
+    def free(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self._lib.gb_circuit_free(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        if not sys.is_finalizing():
+            self.free()
