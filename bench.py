@@ -4,8 +4,11 @@
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident
-in HBM: workload `commit` = PolynomialBatch::from_values on the 2^20-row Goldilocks wires matrix
-(135 columns, rate 3, cap 4 - fri/oracle.rs:68-123 as called at plonk/prover.rs:261-272);
+in HBM.  Workload `prove` (default, BASELINE.json configs[2]): one full prove() of the 2^20-row
+Goldilocks dummy circuit (num_challenges = 3) from a device-resident
+MatrixWitness to ProofWithPublicInputs bytes, constants/sigmas commitment pre-resident
+(plonk/prover.rs:228-447).  Workload `commit` = PolynomialBatch::from_values on the wires matrix
+only (135 columns, rate 3, cap 4 - fri/oracle.rs:68-123 as called at plonk/prover.rs:261-272).
 Independent circuits shard one per GPU: every rank runs the same workload on its own device,
 no data-path collective ("scaling": "weak").  The roofline object prices the NTT pass (the IFFT
 + LDE kernels) against the 8 TB/s HBM peak with SURVEY.md 8(d)'s algorithmic bytes; the
@@ -59,12 +62,35 @@ def cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample_log_n):
     }
 
 
+def cpu_baseline_prove(log_n, num_challenges, sample_log_n):
+    """The CPU oracle prover (restatement of the reference's prove(), OpenMP where the reference uses
+    Rayon) on a smaller dummy circuit of the same shape, scaled linearly in rows."""
+    from oracle import oracle as O
+    from oracle import plonk_dummy as D
+    cores = int(O.lib().gbo_num_threads())
+    circ = D.DummyCircuit(sample_log_n, D.CircuitConfig(num_challenges=num_challenges), check_security=False)
+    _ = circ.circuit_digest  # build(): not part of prove()
+    w = circ.witness(seed=1)
+    t0 = time.perf_counter()
+    proof, _dbg = D.prove_cpu(circ, w)
+    dt = time.perf_counter() - t0
+    assert D.verify(circ, proof)
+    scale = float(1 << (log_n - sample_log_n))
+    return {
+        "value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "kind": "port",
+        "sample": "oracle prove() of the 2^%d-row dummy circuit (1/%d of the rows, num_challenges %d) took %.2f s and "
+                  "verified; scaled linearly in rows" % (sample_log_n, int(scale), num_challenges, dt),
+        "sample_seconds": dt,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="commit", choices=["commit"])
+    ap.add_argument("--workload", default="prove", choices=["prove", "commit"])
+    ap.add_argument("--challenges", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cols", type=int, default=135)
     ap.add_argument("--cpu-sample-log-n", type=int, default=None)
@@ -83,19 +109,36 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from plonky2_goldibear_amd import GpuContext, PolynomialBatch
+    from plonky2_goldibear_amd import CircuitData, GpuContext, PolynomialBatch
+    from plonky2_goldibear_amd import dummy_circuit as DC
 
     ncols, log_n, rate_bits, cap_height = args.cols, args.log_n, 3, 4
     n = 1 << log_n
     ctx = GpuContext(local_rank)
-    host = splitmix64_matrix((0xC0FFEE ^ (ncols << 32) ^ log_n) + rank, ncols, n)
-    dev = torch.from_numpy(host.view(np.int64)).to("cuda:%d" % local_rank)
-    del host
-    torch.cuda.synchronize()
+    proof_len = 0
+    if args.workload == "prove":
+        ncols = 135
+        cs, k_is, pi_row, _ = DC.build_dummy_circuit(log_n)
+        cs_dev = torch.from_numpy(cs.view(np.int64)).to("cuda:%d" % local_rank)
+        circuit = CircuitData(ctx, log_n, cs_dev, k_is, num_challenges=args.challenges)  # build(): once per circuit
+        del cs, cs_dev
+        wit = DC.dummy_witness(log_n, pi_row, seed=rank)
+        dev = torch.from_numpy(wit.view(np.int64)).to("cuda:%d" % local_rank)
+        del wit
+        torch.cuda.synchronize()
 
-    def step():
-        b = PolynomialBatch.from_values(ctx, dev, rate_bits, cap_height)
-        b.free()
+        def step():
+            nonlocal proof_len
+            proof_len = len(circuit.prove(dev))
+    else:
+        host = splitmix64_matrix((0xC0FFEE ^ (ncols << 32) ^ log_n) + rank, ncols, n)
+        dev = torch.from_numpy(host.view(np.int64)).to("cuda:%d" % local_rank)
+        del host
+        torch.cuda.synchronize()
+
+        def step():
+            b = PolynomialBatch.from_values(ctx, dev, rate_bits, cap_height)
+            b.free()
 
     def barrier():
         ctx.synchronize()
@@ -118,38 +161,58 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    scopes = {s: ctx.scope_ms(s) for s in ("IFFT", "FFT + blinding", "build Merkle tree")}
+    scope_names = ("IFFT", "FFT + blinding", "build Merkle tree", "compute wires commitment", "compute partial products",
+                   "compute quotient polys", "construct the opening set", "compute opening proofs",
+                   "find proof-of-work witness", "fri query rounds")
+    scopes = {s: ctx.scope_ms(s) for s in scope_names}
     ctx.set_profiling(False)
 
     if rank == 0:
         steps = args.steps
         ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps
         merkle_ms = scopes["build Merkle tree"][0] / steps
-        alg_bytes = (2 + (1 << rate_bits)) * n * 8 * ncols  # (2 + 2^r) n s per column
-        achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
         N = n << rate_bits
-        perms = N * (-(-ncols // 8)) + (N - (1 << cap_height))  # leaf sponge + internal nodes
+        if args.workload == "prove":
+            c = args.challenges
+            nzs, nq = c * 10, c * 8
+            # from_values (2 + 2^r) n s per column (wires, zs/pp), from_coeffs (1 + 2^r) n s (quotient
+            # chunks), + the final polynomial's 2 coordinate columns; the quotient's per-coset inverse NTTs and the
+            # small FRI layers are not counted (conservative)
+            alg_bytes = ((2 + 8) * (135 + nzs) + (1 + 8) * (nq + 2)) * n * 8
+            perms = sum(N * (-(-w // 8)) + (N - 16) for w in (135, nzs, nq)) + sum(
+                (N >> (4 * (l + 1))) * 4 + ((N >> (4 * (l + 1))) - 16) for l in range((log_n - 5 + 3) // 4))
+            metric = "proofs/s"
+            workload = ("prove(): 2^%d-row Goldilocks dummy circuit (2^%d+1 NoopGates), standard_recursion_config_gl with "
+                        "num_challenges=%d, Poseidon-12, witness resident in HBM -> proof bytes (%d B)" % (log_n, log_n - 1, c, proof_len))
+        else:
+            alg_bytes = (2 + (1 << rate_bits)) * n * 8 * ncols  # (2 + 2^r) n s per column
+            perms = N * (-(-ncols // 8)) + (N - (1 << cap_height))  # leaf sponge + internal nodes
+            metric = "commits/s (PolynomialBatch::from_values, wires oracle of the 2^%d-row circuit)" % log_n
+            workload = "from_values: %d cols x 2^%d rows Goldilocks, rate_bits 3, cap_height 4, Poseidon-12" % (ncols, log_n)
+        achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
         out = {
-            "metric": "commits/s (PolynomialBatch::from_values, wires oracle of the 2^%d-row circuit)" % log_n,
-            "value": world * steps / dt, "unit": "commits/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "from_values: %d cols x 2^%d rows Goldilocks, rate_bits 3, cap_height 4, Poseidon-12" % (ncols, log_n),
-                       "field": "goldilocks", "log_n": log_n, "cols": ncols, "rate_bits": rate_bits, "cap_height": cap_height,
-                       "sharding": "one independent circuit per GPU, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "NTT pass = k_gl_intt_p1+p2+p3 (IFFT) + k_gl_lde_pa+pb (FFT + blinding)",
+            "metric": metric, "value": world * steps / dt, "unit": metric.split(" ")[0], "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": workload, "field": "goldilocks", "log_n": log_n, "rate_bits": rate_bits,
+                       "cap_height": cap_height, "sharding": "one independent circuit per GPU, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "NTT pass = k_gl_intt_p1+p2+p3 (IFFT) + k_gl_lde_pa+pb (FFT + blinding), all commitments of the step",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes": alg_bytes, "ms": ntt_ms},
-            "scopes_ms_per_step": {"IFFT": scopes["IFFT"][0] / steps, "FFT + blinding": scopes["FFT + blinding"][0] / steps,
-                                   "build Merkle tree": merkle_ms},
+            "scopes_ms_per_step": {k: v[0] / steps for k, v in scopes.items() if v[1]},
             "merkle": {"permutations": perms, "Gperm_per_s": perms / (merkle_ms * 1e-3) / 1e9},
         }
         if not args.no_cpu_baseline:
             sample = args.cpu_sample_log_n
-            if sample is None:
-                cores = os.cpu_count() or 1
-                sample = max(10, min(log_n, 19, 13 + (cores.bit_length() - 1)))  # sized for ~10-30 s of CPU work
-            out["cpu_baseline"] = cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample)
+            cores = os.cpu_count() or 1
+            if args.workload == "prove":
+                if sample is None:
+                    sample = max(8, min(log_n, 16, 10 + (cores.bit_length() - 1)))  # sized for ~10-30 s of CPU work
+                out["cpu_baseline"] = cpu_baseline_prove(log_n, args.challenges, sample)
+            else:
+                if sample is None:
+                    sample = max(10, min(log_n, 19, 13 + (cores.bit_length() - 1)))
+                out["cpu_baseline"] = cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

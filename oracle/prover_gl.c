@@ -136,31 +136,42 @@ int gbo_gl_prove_dummy(const gbo_circuit_cfg *cfg, const gl_t *constants_sigmas 
     /* ---- prover.rs:480-546: Z and partial products.  zs_pp columns: [Z_0..Z_{c-1}, pp_{0,0..}, pp_{1,0..}, ...] */
     const size_t nzs = (size_t)c * (1 + num_prods);
     gl_t *zs_vals = malloc(nzs * n * sizeof(gl_t));
-    for (unsigned i = 0; i < c && !rc; i++) {
-        gl_t z_x = 1;
-        for (size_t row = 0; row < n; row++) {
-            gl_t x = subgroup[row];
-            gl_t chunk_prod[64];
-            for (unsigned m = 0; m < nchunks; m++) chunk_prod[m] = 1;
-            for (unsigned j = 0; j < nr; j++) {
-                gl_t wv = witness[(size_t)j * n + row];
-                gl_t num = gl_add(gl_add(wv, gl_mul(betas[i], gl_mul(k_is[j], x))), gammas[i]);
-                gl_t den = gl_add(gl_add(wv, gl_mul(betas[i], sigma_cols[(size_t)j * n + row])), gammas[i]);
-                if (den == 0) { rc = 1; break; }
-                gl_t q = gl_mul(num, gl_inv(den));
-                chunk_prod[j / qdf] = gl_mul(chunk_prod[j / qdf], q);
+    {
+        /* per-row chunk products in parallel (Rayon par_iter over the subgroup, prover.rs:497-528), then the
+         * sequential running product (:531-539) */
+        gl_t *cp = malloc((size_t)nchunks * n * sizeof(gl_t));
+        for (unsigned i = 0; i < c && !rc; i++) {
+            int bad = 0;
+#pragma omp parallel for schedule(static) reduction(|:bad)
+            for (size_t row = 0; row < n; row++) {
+                gl_t x = subgroup[row];
+                gl_t chunk_prod[64];
+                for (unsigned m = 0; m < nchunks; m++) chunk_prod[m] = 1;
+                for (unsigned j = 0; j < nr; j++) {
+                    gl_t wv = witness[(size_t)j * n + row];
+                    gl_t num = gl_add(gl_add(wv, gl_mul(betas[i], gl_mul(k_is[j], x))), gammas[i]);
+                    gl_t den = gl_add(gl_add(wv, gl_mul(betas[i], sigma_cols[(size_t)j * n + row])), gammas[i]);
+                    if (den == 0) { bad = 1; den = 1; }
+                    gl_t q = gl_mul(num, gl_inv(den));
+                    chunk_prod[j / qdf] = gl_mul(chunk_prod[j / qdf], q);
+                }
+                for (unsigned m = 0; m < nchunks; m++) cp[(size_t)m * n + row] = chunk_prod[m];
             }
-            if (rc) break;
+            if (bad) { rc = 1; break; }
             /* partial_products_and_z_gx (util/partial_products.rs:29-38) then swap Z(gx) <-> Z(x) (:537-538) */
-            gl_t acc = z_x;
+            gl_t z_x = 1;
             gl_t *Z = zs_vals + (size_t)i * n;
-            Z[row] = z_x;
-            for (unsigned m = 0; m < nchunks; m++) {
-                acc = gl_mul(acc, chunk_prod[m]);
-                if (m < num_prods) zs_vals[((size_t)c + (size_t)i * num_prods + m) * n + row] = acc;
+            for (size_t row = 0; row < n; row++) {
+                gl_t acc = z_x;
+                Z[row] = z_x;
+                for (unsigned m = 0; m < nchunks; m++) {
+                    acc = gl_mul(acc, cp[(size_t)m * n + row]);
+                    if (m < num_prods) zs_vals[((size_t)c + (size_t)i * num_prods + m) * n + row] = acc;
+                }
+                z_x = acc;
             }
-            z_x = acc;
         }
+        free(cp);
     }
     if (rc) goto done_early;
     if ((rc = batch_commit(&zs, zs_vals, nzs, lg, r, capH, 0))) goto done_early;    /* prover.rs:328-339 */
@@ -175,11 +186,15 @@ int gbo_gl_prove_dummy(const gbo_circuit_cfg *cfg, const gl_t *constants_sigmas 
         gl_t zh[64], zh_inv[64];
         gl_t wr = gl_two_adic_generator(r), xr = 1;
         for (unsigned i = 0; i < (1u << r); i++) { zh[i] = gl_sub(gl_mul(g_pow_n, xr), 1); zh_inv[i] = gl_inv(zh[i]); xr = gl_mul(xr, wr); }
-        gl_t wN = gl_two_adic_generator(lgN), pt = 1;
+        gl_t wN = gl_two_adic_generator(lgN);
         const unsigned nterms = c + c * nchunks + HOUT; /* z_1 terms, partial product terms, gate constraints (max = 4) */
-        gl_t *terms = malloc(nterms * sizeof(gl_t));
         const unsigned nsel = cfg->num_selectors;
-        for (size_t i = 0; i < N; i++, pt = gl_mul(pt, wN)) {
+        /* Rayon par_chunks(BATCH_SIZE = 32) over the points (prover.rs:791-797) */
+#pragma omp parallel for schedule(static)
+        for (size_t i0 = 0; i0 < N; i0 += 32) {
+        gl_t terms[256];
+        gl_t pt = gl_pow(wN, i0);
+        for (size_t i = i0; i < i0 + 32 && i < N; i++, pt = gl_mul(pt, wN)) {
             gl_t x = gl_mul(GL_GENERATOR, pt); /* shifted_x */
             size_t i_next = (i + ((size_t)1 << r)) % N;
             const gl_t *lcs = batch_lde(&cs, i, 1), *lw = batch_lde(&wires, i, 1), *lz = batch_lde(&zs, i, 1), *nz = batch_lde(&zs, i_next, 1);
@@ -225,7 +240,8 @@ int gbo_gl_prove_dummy(const gbo_circuit_cfg *cfg, const gl_t *constants_sigmas 
                 qvals[(size_t)k * N + i] = gl_mul(cum, zh_inv[i % (1u << r)]);
             }
         }
-        free(terms);
+        }
+        if (nterms > 256) rc = -11;
     }
     /* coset_ifft (prover.rs:921-925), trim_to_len + chunks (:361-374): c * qdf chunk polys of n coefficients */
     qchunks = malloc((size_t)c * qdf * n * sizeof(gl_t));

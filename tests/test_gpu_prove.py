@@ -83,3 +83,25 @@ def test_error_behaviour(ctx):
     # InvZeroPermArg (prover.rs:512-514): make w + beta*sigma + gamma hit zero is infeasible to force without
     # knowing beta; instead check the plumbing: PermArgZeroError is a GoldibearError subclass
     assert issubclass(PermArgZeroError, Exception)
+
+
+def test_full_size_2pow20_proof_verifies(ctx):
+    """BASELINE configs[2]: 2^20-row dummy circuit, num_challenges = 3, full prove() on one GPU.
+    Too large for the CPU oracle prover in a test, so parity is through the verifier (size-independent
+    property: the proof verifies) plus determinism (same witness -> same bytes)."""
+    from plonky2_goldibear_amd import dummy_circuit as DC
+    circ = D.DummyCircuit(20, D.CircuitConfig(num_challenges=3))
+    cs, k_is, pi_row, _ = DC.build_dummy_circuit(20)
+    assert pi_row == circ.pi_row and (k_is == circ.k_is).all()
+    assert (cs[:, :4096] == circ.constants_sigmas[:, :4096]).all() and (cs[:, pi_row - 2:pi_row + 4] == circ.constants_sigmas[:, pi_row - 2:pi_row + 4]).all()
+    gpu = CircuitData(ctx, 20, cs, k_is, num_challenges=3)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    w = circ.witness(seed=7)
+    proof = gpu.prove(w)
+    stats = {}
+    assert D.verify(circ, proof, stats)
+    assert stats["merkle_paths"] == 28 * (4 + 4)
+    assert gpu.prove(w) == proof
+    gpu.free()
+    ctx.trim()
