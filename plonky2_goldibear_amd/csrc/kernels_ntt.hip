@@ -221,6 +221,11 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb(const u64* __restrict__ c
 
 // ------------------------------------------------------------------ host launchers
 
+// radix-16 register kernels (kernels_ntt16.hip); return false when the shape is not covered
+bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
+bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, hipStream_t stream);
+void gl_lde_pb_r16(u64* lde, size_t ntiles, const GlNttTables& t, hipStream_t stream);
+
 static InvGeom inv_geom(u32 L) {
     InvGeom g;
     g.L = L;
@@ -244,6 +249,7 @@ void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, co
                            t.n_inv);
         return;
     }
+    if (gl_intt_columns_r16(src, coeffs, scratch, ncols, t, stream)) return;
     InvGeom g = inv_geom(L);
     const u32 LL = g.LB + g.LC;
     u64* p1_dst = g.LB ? coeffs : scratch;
@@ -266,10 +272,10 @@ void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables
                            t.tw4096_fwd, ct.pow_lo);
         return;
     }
-    hipLaunchKernelGGL(k_gl_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
-                       t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-    hipLaunchKernelGGL(k_gl_lde_pb<false>, dim3((u32)(ncols << (r + L - 12))), dim3(THREADS), 0, stream, coeffs, lde, L,
-                       r, t.tw4096_fwd, ct.pow_lo);
+    if (!gl_lde_pa_r16(coeffs, lde, ncols, t, ct, stream))
+        hipLaunchKernelGGL(k_gl_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
+                           t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+    gl_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
 }
 
 }  // namespace gbk
