@@ -8,11 +8,13 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <tuple>
 #include <utility>
 #include <vector>
 
+#include "bb_field.hpp"
 #include "gl_field.hpp"
 #include "kernels.hpp"
 
@@ -40,6 +42,14 @@ struct GlCosetSet {
     gbk::GlCosetTables t{};
     std::vector<void*> owned;
 };
+struct BbTableSet {
+    gbk::BbNttTables t{};
+    std::vector<void*> owned;
+};
+struct BbCosetSet {
+    gbk::BbCosetTables t{};
+    std::vector<void*> owned;
+};
 
 }  // namespace
 
@@ -53,6 +63,9 @@ struct gb_ctx {
     u64* tw4096_inv = nullptr;
     std::map<u32, GlTableSet> gl_tables;                    // by log_n
     std::map<std::tuple<u32, u32, u64, int>, GlCosetSet> gl_cosets;  // by (log_n, rate_bits, shift, inverse)
+    u32 *bb_tw4096_fwd = nullptr, *bb_tw4096_inv = nullptr;
+    std::map<u32, BbTableSet> bb_tables;
+    std::map<std::pair<u32, u32>, BbCosetSet> bb_cosets;
     std::multimap<size_t, void*> pool;                      // freed batch blocks by size (stream-ordered reuse)
     DeviceBuf scratch;                                      // grow-only workspace
     DeviceBuf small;                                        // small gather staging (rows, siblings)
@@ -222,7 +235,79 @@ gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u64 shift, bool i
     return GB_OK;
 }
 
+// ---- BabyBear tables (Montgomery form) ----
+gb_status upload32(gb_ctx* ctx, const std::vector<u32>& host, u32** dev, std::vector<void*>* owned) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, host.size() * sizeof(u32)));
+    HIP_TRY(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(u32), hipMemcpyHostToDevice));
+    *dev = static_cast<u32*>(p);
+    if (owned) owned->push_back(p);
+    return GB_OK;
+}
+std::vector<u32> bb_powers(u32 base_mont, size_t count) {
+    std::vector<u32> v(count);
+    u32 x = bb::R1;
+    for (size_t i = 0; i < count; i++) {
+        v[i] = x;
+        x = bb::mul(x, base_mont);
+    }
+    return v;
+}
+gb_status bb_tables_for(gb_ctx* ctx, u32 log_n, const gbk::BbNttTables** out) {
+    auto it = ctx->bb_tables.find(log_n);
+    if (it != ctx->bb_tables.end()) { *out = &it->second.t; return GB_OK; }
+    gb_status s;
+    if (!ctx->bb_tw4096_fwd) {
+        u32 w = bb::two_adic_generator(12);
+        if ((s = upload32(ctx, bb_powers(w, 4096), &ctx->bb_tw4096_fwd, nullptr))) return s;
+        if ((s = upload32(ctx, bb_powers(bb::inv(w), 4096), &ctx->bb_tw4096_inv, nullptr))) return s;
+    }
+    BbTableSet set;
+    set.t.log_n = log_n;
+    set.t.tw4096_fwd = ctx->bb_tw4096_fwd;
+    set.t.tw4096_inv = ctx->bb_tw4096_inv;
+    u32 w = bb::two_adic_generator(log_n), wi = bb::inv(w);
+    size_t n = (size_t)1 << log_n, nhi = n > 1024 ? n / 1024 : 1;
+    u32 *lo_f, *hi_f, *lo_i, *hi_i;
+    if ((s = upload32(ctx, bb_powers(w, 1024), &lo_f, &set.owned))) return s;
+    if ((s = upload32(ctx, bb_powers(bb::pow(w, 1024), nhi), &hi_f, &set.owned))) return s;
+    if ((s = upload32(ctx, bb_powers(wi, 1024), &lo_i, &set.owned))) return s;
+    if ((s = upload32(ctx, bb_powers(bb::pow(wi, 1024), nhi), &hi_i, &set.owned))) return s;
+    set.t.tw_lo_fwd = lo_f; set.t.tw_hi_fwd = hi_f; set.t.tw_lo_inv = lo_i; set.t.tw_hi_inv = hi_i;
+    set.t.n_inv = bb::inv(bb::to_mont((u32)(n % bb::P)));
+    auto res = ctx->bb_tables.emplace(log_n, std::move(set));
+    *out = &res.first->second.t;
+    return GB_OK;
+}
+gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, const gbk::BbCosetTables** out) {
+    auto key = std::make_pair(log_n, rate_bits);
+    auto it = ctx->bb_cosets.find(key);
+    if (it != ctx->bb_cosets.end()) { *out = &it->second.t; return GB_OK; }
+    size_t n = (size_t)1 << log_n;
+    size_t nlo = n < 4096 ? n : 4096, nhi = n > 4096 ? n / 4096 : 1;
+    u32 nc = 1u << rate_bits;
+    u32 wN = bb::two_adic_generator(log_n + rate_bits);
+    std::vector<u32> lo(nc * nlo), hi(nc * nhi);
+    for (u32 c = 0; c < nc; c++) {
+        u32 s = bb::mul(bb::to_mont(bb::GENERATOR), bb::pow(wN, bitrev32(c, rate_bits)));
+        std::vector<u32> pl = bb_powers(s, nlo), ph = bb_powers(bb::pow(s, 4096), nhi);
+        std::memcpy(&lo[c * nlo], pl.data(), nlo * sizeof(u32));
+        std::memcpy(&hi[c * nhi], ph.data(), nhi * sizeof(u32));
+    }
+    BbCosetSet set;
+    set.t.rate_bits = rate_bits;
+    u32 *dlo, *dhi;
+    gb_status s;
+    if ((s = upload32(ctx, lo, &dlo, &set.owned))) return s;
+    if ((s = upload32(ctx, hi, &dhi, &set.owned))) return s;
+    set.t.pow_lo = dlo; set.t.pow_hi = dhi;
+    auto res = ctx->bb_cosets.emplace(key, std::move(set));
+    *out = &res.first->second.t;
+    return GB_OK;
+}
+
 inline size_t hout(u32 field) { return field == GB_GOLDILOCKS ? 4 : 8; }
+inline size_t esize(u32 field) { return field == GB_GOLDILOCKS ? 8 : 4; }
 inline size_t level_offset(u64 N, u32 k) { return (size_t)(2 * N - ((2 * N) >> k)); }
 
 gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
@@ -230,10 +315,11 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     if (!out) return fail(ctx, GB_ERR_INVALID, "null out");
     *out = nullptr;
-    if (field != GB_GOLDILOCKS) return fail(ctx, GB_ERR_UNSUPPORTED, "field not implemented yet");
+    if (field != GB_GOLDILOCKS && field != GB_BABYBEAR) return fail(ctx, GB_ERR_INVALID, "unknown field tag");
     if (ncols == 0) return fail(ctx, GB_ERR_INVALID, "from_values/from_coeffs needs at least one polynomial (oracle.rs:101)");
     if (!cols) return fail(ctx, GB_ERR_INVALID, "null cols");
-    if (log_n + rate_bits > 32) return fail(ctx, GB_ERR_INVALID, "LDE size exceeds the field's two-adicity (32)");
+    if (log_n + rate_bits > (field == GB_GOLDILOCKS ? 32u : 27u))
+        return fail(ctx, GB_ERR_INVALID, "LDE size exceeds the field's two-adicity (32 Goldilocks / 27 BabyBear)");
     if (cap_height > log_n + rate_bits)
         return fail(ctx, GB_ERR_INVALID, "cap_height should be at most log2(leaves.len()) (merkle_tree.rs:154-157)");
     if (log_n > 20) return fail(ctx, GB_ERR_UNSUPPORTED, "log_n > 20 not implemented");
@@ -252,9 +338,10 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     auto cleanup = [&](gb_status s) { gb_batch_free(b); return s; };
 
     void* p = nullptr;
-    b->coeffs_bytes = ncols * n * sizeof(u64);
-    b->lde_bytes = width * N * sizeof(u64);
-    b->levels_bytes = 2 * N * 4 * sizeof(u64);
+    const size_t es = esize(field);
+    b->coeffs_bytes = ncols * n * es;
+    b->lde_bytes = width * N * es;
+    b->levels_bytes = 2 * N * 4 * sizeof(u64);  // 32-byte digests for both hashers
     if (pool_alloc(ctx, b->coeffs_bytes, &p) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc coeffs"));
     b->coeffs = (u64*)p;
     if (pool_alloc(ctx, b->lde_bytes, &p) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc lde"));
@@ -262,13 +349,59 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     if (pool_alloc(ctx, b->levels_bytes, &p) != hipSuccess) return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc digests"));
     b->levels = (u64*)p;
 
+    gb_status s;
+    hipStream_t st = ctx->stream;
+    if (field == GB_BABYBEAR) {
+        // same flow over u32 Montgomery words; inputs are converted on the way in
+        const gbk::BbNttTables* bt;
+        const gbk::BbCosetTables* bc;
+        if ((s = bb_tables_for(ctx, log_n, &bt))) return cleanup(s);
+        if ((s = bb_cosets_for(ctx, log_n, rate_bits, &bc))) return cleanup(s);
+        u32* coeffs = (u32*)b->coeffs;
+        u32* lde = (u32*)b->lde;
+        const size_t in_bytes = ncols * n * 4, scr_bytes = std::max(in_bytes, (size_t)nsalt * N * 4);
+        if ((s = ensure(ctx, ctx->scratch, 2 * scr_bytes))) return cleanup(s);
+        u32* scr = (u32*)ctx->scratch.p;
+        const u32* in_dev = static_cast<const u32*>(cols);
+        if (!dev_in) {
+            if (hipMemcpyAsync(scr, cols, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+                return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+            in_dev = scr;
+        }
+        gbk::bb_to_mont(in_dev, coeffs, ncols * n, st);
+        if (!is_coeffs) {
+            Scope sc(ctx, "IFFT");
+            gbk::bb_intt_columns(coeffs, coeffs, scr + scr_bytes / 4, ncols, *bt, st);
+        }
+        {
+            Scope sc(ctx, "FFT + blinding");
+            gbk::bb_lde_columns(coeffs, lde, ncols, *bt, *bc, st);
+            if (nsalt) {
+                const u32* sdev = static_cast<const u32*>(salts);
+                if (!dev_in) {
+                    if (hipMemcpyAsync(scr, salts, (size_t)nsalt * N * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+                        return cleanup(fail(ctx, GB_ERR_HIP, "copy of salts failed"));
+                    sdev = scr;
+                }
+                gbk::bb_bitrev_copy_to_mont(sdev, lde + ncols * N, log_N, nsalt, st);
+            }
+        }
+        {
+            Scope sc(ctx, "build Merkle tree");
+            u32* lv = (u32*)b->levels;
+            gbk::bb_merkle_leaves(lde, N, (u32)width, N, lv, st);
+            for (u32 k = 0; k < log_N - cap_height; k++)
+                gbk::bb_merkle_level(lv + 8 * level_offset(N, k), lv + 8 * level_offset(N, k + 1), N >> (k + 1), st);
+        }
+        if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, GB_ERR_HIP, "kernel launch failed"));
+        *out = b;
+        return GB_OK;
+    }
     const gbk::GlNttTables* tabs;
     const gbk::GlCosetTables* cos;
-    gb_status s;
     if ((s = gl_tables_for(ctx, log_n, &tabs))) return cleanup(s);
     if ((s = gl_cosets_for(ctx, log_n, rate_bits, gl::GENERATOR, false, &cos))) return cleanup(s);
 
-    hipStream_t st = ctx->stream;
     const u64* src = static_cast<const u64*>(cols);
     if (!dev_in || is_coeffs) {
         // host input, or coefficients the batch must own a copy of
@@ -338,6 +471,10 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     gb_ctx_scope_reset(ctx);
     for (auto& kv : ctx->gl_tables) for (void* p : kv.second.owned) hipFree(p);
     for (auto& kv : ctx->gl_cosets) for (void* p : kv.second.owned) hipFree(p);
+    for (auto& kv : ctx->bb_tables) for (void* p : kv.second.owned) hipFree(p);
+    for (auto& kv : ctx->bb_cosets) for (void* p : kv.second.owned) hipFree(p);
+    if (ctx->bb_tw4096_fwd) hipFree(ctx->bb_tw4096_fwd);
+    if (ctx->bb_tw4096_inv) hipFree(ctx->bb_tw4096_inv);
     if (ctx->tw4096_fwd) hipFree(ctx->tw4096_fwd);
     if (ctx->tw4096_inv) hipFree(ctx->tw4096_inv);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
@@ -445,9 +582,8 @@ gb_status gb_batch_cap(gb_batch* b, void* out) {
     if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
     gb_ctx* ctx = b->ctx;
     const u64 N = (u64)1 << (b->log_n + b->rate_bits);
-    const size_t H = hout(b->field);
-    const u64* cap = b->levels + H * level_offset(N, b->log_n + b->rate_bits - b->cap_height);
-    HIP_TRY(ctx, hipMemcpyAsync(out, cap, ((size_t)1 << b->cap_height) * H * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    const u64* cap = b->levels + 4 * level_offset(N, b->log_n + b->rate_bits - b->cap_height);  // 32 B per digest
+    HIP_TRY(ctx, hipMemcpyAsync(out, cap, ((size_t)1 << b->cap_height) * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
 }
@@ -457,6 +593,14 @@ gb_status gb_batch_coeffs(gb_batch* b, size_t col, void* out) {
     gb_ctx* ctx = b->ctx;
     if (col >= b->ncols) return fail(ctx, GB_ERR_INVALID, "polynomial index out of range");
     const size_t n = (size_t)1 << b->log_n;
+    if (b->field == GB_BABYBEAR) {
+        gb_status s = ensure(ctx, ctx->scratch, n * 4);
+        if (s) return s;
+        gbk::bb_from_mont((const u32*)b->coeffs + col * n, (u32*)ctx->scratch.p, n, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return GB_OK;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(out, b->coeffs + col * n, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
@@ -468,8 +612,11 @@ static gb_status read_row(gb_batch* b, u64 leaf, u32 width, void* out) {
     gb_status s = ensure(ctx, ctx->small, 64 * 1024);
     if (s) return s;
     if (width * sizeof(u64) > ctx->small.bytes) return fail(ctx, GB_ERR_UNSUPPORTED, "row too wide");
-    gbk::gl_gather_row(b->lde, N, width, leaf, (u64*)ctx->small.p, ctx->stream);
-    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->small.p, width * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    if (b->field == GB_BABYBEAR)
+        gbk::bb_gather_row((const u32*)b->lde, N, width, leaf, (u32*)ctx->small.p, ctx->stream);
+    else
+        gbk::gl_gather_row(b->lde, N, width, leaf, (u64*)ctx->small.p, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->small.p, width * esize(b->field), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
 }
@@ -500,7 +647,7 @@ gb_status gb_batch_leaf(gb_batch* b, uint64_t leaf_index, void* row, void* sibli
         gb_status s = ensure(ctx, ctx->small, 64 * 1024);
         if (s) return s;
         gbk::gl_gather_siblings(b->levels, bits, b->cap_height, leaf_index, (u64*)ctx->small.p, ctx->stream);
-        HIP_TRY(ctx, hipMemcpyAsync(siblings, ctx->small.p, layers * hout(b->field) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(siblings, ctx->small.p, (size_t)layers * 32, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return GB_OK;
@@ -513,7 +660,7 @@ gb_status gb_batch_digests(gb_batch* b, void* out) {
     const u64 N = (u64)1 << bits;
     const size_t total = 2 * (N - ((u64)1 << b->cap_height));
     if (!total) return GB_OK;
-    const size_t bytes = total * hout(b->field) * sizeof(u64);
+    const size_t bytes = total * 32;
     gb_status s = ensure(ctx, ctx->scratch, bytes);
     if (s) return s;
     gbk::gl_digests_to_reference_layout(b->levels, (u64*)ctx->scratch.p, bits, b->cap_height, ctx->stream);
@@ -527,10 +674,13 @@ gb_status gb_batch_leaves(gb_batch* b, void* out) {
     gb_ctx* ctx = b->ctx;
     const u64 N = (u64)1 << (b->log_n + b->rate_bits);
     const u32 width = (u32)(b->ncols + b->nsalt);
-    const size_t bytes = (size_t)N * width * sizeof(u64);
+    const size_t bytes = (size_t)N * width * esize(b->field);
     gb_status s = ensure(ctx, ctx->scratch, bytes);
     if (s) return s;
-    gbk::u64_transpose_to_rows(b->lde, N, width, N, (u64*)ctx->scratch.p, ctx->stream);
+    if (b->field == GB_BABYBEAR)
+        gbk::bb_transpose_to_rows((const u32*)b->lde, N, width, N, (u32*)ctx->scratch.p, ctx->stream);
+    else
+        gbk::u64_transpose_to_rows(b->lde, N, width, N, (u64*)ctx->scratch.p, ctx->stream);
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
@@ -546,9 +696,21 @@ gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** di
 
 gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uint64_t count) {
     if (!ctx || !in || !out) return fail(ctx, GB_ERR_INVALID, "null argument");
-    if (field != GB_GOLDILOCKS) return fail(ctx, GB_ERR_UNSUPPORTED, "field not implemented yet");
+    if (field != GB_GOLDILOCKS && field != GB_BABYBEAR) return fail(ctx, GB_ERR_INVALID, "unknown field tag");
     if (!count) return GB_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (field == GB_BABYBEAR) {
+        const size_t bytes = count * 16 * sizeof(u32);
+        gb_status s = ensure(ctx, ctx->scratch, 2 * bytes);
+        if (s) return s;
+        u32* din = (u32*)ctx->scratch.p;
+        u32* dout = din + count * 16;
+        HIP_TRY(ctx, hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+        gbk::bb_poseidon2_permute(din, dout, count, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return GB_OK;
+    }
     const size_t bytes = count * 12 * sizeof(u64);
     gb_status s = ensure(ctx, ctx->scratch, 2 * bytes);
     if (s) return s;

@@ -1,0 +1,67 @@
+// BabyBear field p = 2^31 - 2^27 + 1 in 32-bit Montgomery form (R = 2^32) for gfx950 device code
+// and the host-side table builders.
+//
+// Replaces what the reference takes from p3-baby-bear / p3-monty-31 (Cargo.toml:17-24, unpinned):
+// generator 31, two_adic_generator(27) = 0x1a427a41 - recalled from upstream, self-consistent, NOT pinned
+// by any fixture in the reference.  Device-resident BabyBear data (coefficients, LDE)
+// is kept in Montgomery form; digests, caps and everything that crosses the C ABI is canonical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bb {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+static constexpr u32 P = 0x78000001u;          // 2013265921
+static constexpr u32 PINV = 0x88000001u;       // P^-1 mod 2^32
+static constexpr u32 R1 = 0x0ffffffeu;         // 2^32 mod P  (Montgomery form of 1)
+static constexpr u32 R2 = 0x45dddde3u;         // 2^64 mod P
+static constexpr u32 GENERATOR = 31;           // F::generator(), the LDE coset shift
+static constexpr u32 TWO_ADIC_GEN_27 = 0x1a427a41u;
+
+__host__ __device__ __forceinline__ u32 add(u32 a, u32 b) {  // a, b < P
+    u32 s = a + b;
+    u32 t = s - P;
+    return t < s ? t : s;  // min(s, s - P) as unsigned: s - P wraps high when s < P
+}
+__host__ __device__ __forceinline__ u32 sub(u32 a, u32 b) {
+    u32 d = a - b;
+    u32 t = d + P;
+    return a >= b ? d : t;
+}
+__host__ __device__ __forceinline__ u32 neg(u32 a) { return a ? P - a : 0; }
+
+// t < P * 2^32  ->  t * 2^-32 mod P, canonical
+__host__ __device__ __forceinline__ u32 reduce(u64 t) {
+    u32 m = (u32)t * PINV;
+    u32 u = (u32)(((u64)m * P) >> 32);
+    u32 hi = (u32)(t >> 32);
+    u32 d = hi - u;
+    return hi >= u ? d : d + P;
+}
+// Montgomery product: (a R)(b R) -> (ab R)
+__host__ __device__ __forceinline__ u32 mul(u32 a, u32 b) { return reduce((u64)a * b); }
+__host__ __device__ __forceinline__ u32 sqr(u32 a) { return mul(a, a); }
+__host__ __device__ __forceinline__ u32 to_mont(u32 x) { return mul(x, R2); }  // canonical -> Montgomery
+__host__ __device__ __forceinline__ u32 from_mont(u32 x) { return reduce((u64)x); }
+
+__host__ __device__ inline u32 pow(u32 b, u64 e) {  // Montgomery in/out
+    u32 r = R1;
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+__host__ __device__ inline u32 inv(u32 a) { return pow(a, P - 2); }
+// F::two_adic_generator(bits) in Montgomery form
+__host__ __device__ inline u32 two_adic_generator(unsigned bits) {
+    u32 g = to_mont(TWO_ADIC_GEN_27);
+    for (unsigned i = bits; i < 27; i++) g = sqr(g);
+    return g;
+}
+
+}  // namespace bb

@@ -60,6 +60,27 @@ void u64_transpose_to_rows(const u64* cols, size_t col_stride, u32 width, u64 ro
 // raw permutation of `count` states (tests / microbenchmarks)
 void gl_poseidon_permute(const u64* in, u64* out, u64 count, hipStream_t stream);
 
+// ---------------------------------------------------------------- BabyBear (kernels_bb.hip); element data in Montgomery form
+struct BbNttTables {
+    u32 log_n;
+    const u32 *tw4096_fwd, *tw4096_inv, *tw_lo_fwd, *tw_hi_fwd, *tw_lo_inv, *tw_hi_inv;
+    u32 n_inv;
+};
+struct BbCosetTables {
+    u32 rate_bits;
+    const u32 *pow_lo, *pow_hi;
+};
+void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
+void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream);
+void bb_merkle_leaves(const u32* cols, size_t col_stride, u32 width, u64 num_leaves, u32* out, hipStream_t stream);
+void bb_merkle_level(const u32* in, u32* out, u64 num_out, hipStream_t stream);
+void bb_poseidon2_permute(const u32* in, u32* out, u64 count, hipStream_t stream);  // canonical in/out
+void bb_to_mont(const u32* src, u32* dst, size_t n, hipStream_t stream);
+void bb_from_mont(const u32* src, u32* dst, size_t n, hipStream_t stream);
+void bb_gather_row(const u32* cols, size_t col_stride, u32 width, u64 index, u32* dst, hipStream_t stream);  // -> canonical
+void bb_bitrev_copy_to_mont(const u32* src, u32* dst, u32 bits, size_t ncols, hipStream_t stream);
+void bb_transpose_to_rows(const u32* cols, size_t col_stride, u32 width, u64 rows, u32* dst, hipStream_t stream);  // -> canonical
+
 // ---------------------------------------------------------------- prover (kernels_prover.hip)
 
 static constexpr u32 MAX_CHUNKS = 32, MAX_CHALLENGES = 16, MAX_RATE = 16;

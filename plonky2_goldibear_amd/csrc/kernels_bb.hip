@@ -1,0 +1,333 @@
+// BabyBear kernels for gfx950: LDS-tiled NTT / LDE passes (same pass structure and layouts as
+// kernels_ntt.hip, 32-bit Montgomery arithmetic) and the Poseidon2-16 Merkle tree (H = 8).
+//
+// Replaces, for F = BabyBear, the same reference code as the Goldilocks kernels:
+// fri/oracle.rs:68-150 (IFFT, FFT + blinding, transpose + bit-reverse folded into the leaf order),
+// hash/merkle_tree.rs:86-181 with Poseidon2BabyBearHash (hash/poseidon2_babybear.rs:163-176).
+// Device-resident element data is in Montgomery form; digests are canonical.
+#include "kernels.hpp"
+#include "poseidon2_bb.hpp"
+
+namespace gbk {
+
+static constexpr int THREADS = 256;
+static constexpr int TILE = 4096;
+
+__device__ __forceinline__ u32 brevb(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// ------------------------------------------------------------------ NTT (see kernels_ntt.hip for the derivation)
+
+__device__ __forceinline__ void bb_lds_dft(u32* sh, u32 tile_elems, u32 p, u32 m, const u32* __restrict__ tw) {
+    const u32 half = tile_elems >> 1;
+    for (u32 l = 0; l < m; l++) {
+        const u32 bitpos = p + m - 1 - l;
+        const u32 hmask = (1u << (m - 1 - l)) - 1;
+        const u32 lowmask = (1u << bitpos) - 1;
+        for (u32 q = threadIdx.x; q < half; q += THREADS) {
+            u32 e1 = ((q >> bitpos) << (bitpos + 1)) | (q & lowmask);
+            u32 e2 = e1 | (1u << bitpos);
+            u32 j = (e1 >> p) & hmask;
+            u32 a = sh[e1], b = sh[e2];
+            u32 d = bb::sub(a, b);
+            if (j) d = bb::mul(d, tw[(j << l) << (12 - m)]);
+            sh[e1] = bb::add(a, b);
+            sh[e2] = d;
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ u32 bb_tw_split(const u32* __restrict__ hi, const u32* __restrict__ lo, u32 e) {
+    u32 eh = e >> 10, el = e & 1023;
+    u32 w = lo[el];
+    return eh ? bb::mul(w, hi[eh]) : w;
+}
+
+struct BbInvGeom {
+    u32 L, LA, LB, LC;
+};
+
+__global__ __launch_bounds__(THREADS) void k_bb_intt_p1(const u32* __restrict__ src, u32* __restrict__ dst, BbInvGeom g,
+                                                        const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                        const u32* __restrict__ tw_lo) {
+    __shared__ u32 sh[TILE];
+    const u32 LL = g.LB + g.LC;
+    const u32 tiles_per_col = 1u << (LL - 4);
+    const size_t col = blockIdx.x / tiles_per_col;
+    const u32 tg = blockIdx.x % tiles_per_col;
+    const size_t base = (col << g.L) + ((size_t)tg << 4);
+    const u32 rows = 1u << g.LA;
+    const u32 j = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    for (u32 a = r0; a < rows; a += 16) sh[a * 16 + j] = src[base + ((size_t)a << LL) + j];
+    __syncthreads();
+    bb_lds_dft(sh, rows * 16, 4, g.LA, tw4096);
+    const u32 l = (tg << 4) + j;
+    for (u32 ka = r0; ka < rows; ka += 16) {
+        u32 v = sh[brevb(ka, g.LA) * 16 + j];
+        u32 e = ka * l;
+        if (e) v = bb::mul(v, bb_tw_split(tw_hi, tw_lo, e));
+        dst[base + ((size_t)ka << LL) + j] = v;
+    }
+}
+__global__ __launch_bounds__(THREADS) void k_bb_intt_p2(const u32* __restrict__ src, u32* __restrict__ dst, BbInvGeom g,
+                                                        const u32* __restrict__ tw4096) {
+    __shared__ u32 sh[TILE];
+    const u32 LL = g.LB + g.LC;
+    const u32 n_ga = 1u << (g.LA - 4), n_gc = 1u << (g.LC - 4);
+    const size_t col = blockIdx.x / (n_ga * n_gc);
+    const u32 rem = blockIdx.x % (n_ga * n_gc);
+    const u32 ga = rem / n_gc, gc = rem % n_gc;
+    const size_t cbase = col << g.L;
+    const u32 nb = 1u << g.LB;
+    const u32 jc = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    for (u32 r = r0; r < 16 * nb; r += 16) {
+        u32 ia = r >> g.LB, b = r & (nb - 1);
+        sh[r * 16 + jc] = src[cbase + ((size_t)(16 * ga + ia) << LL) + ((size_t)b << g.LC) + 16 * gc + jc];
+    }
+    __syncthreads();
+    bb_lds_dft(sh, 16 * nb * 16, 4, g.LB, tw4096);
+    const u32 c = 16 * gc + jc;
+    for (u32 r = r0; r < 16 * nb; r += 16) {
+        u32 ia = r >> g.LB, kb = r & (nb - 1);
+        u32 v = sh[(ia * nb + brevb(kb, g.LB)) * 16 + jc];
+        u32 e = c * kb;
+        if (e) v = bb::mul(v, tw4096[e << (12 - LL)]);
+        dst[cbase + ((size_t)kb << (g.LA + g.LC)) + ((size_t)(16 * ga + ia) << g.LC) + c] = v;
+    }
+}
+__global__ __launch_bounds__(THREADS) void k_bb_intt_p3(const u32* __restrict__ src, u32* __restrict__ dst, BbInvGeom g,
+                                                        const u32* __restrict__ tw4096, u32 n_inv) {
+    __shared__ u32 sh[TILE];
+    const u32 n_ga = 1u << (g.LA - 4), nb = 1u << g.LB, nc = 1u << g.LC;
+    const size_t col = blockIdx.x / (nb * n_ga);
+    const u32 rem = blockIdx.x % (nb * n_ga);
+    const u32 kb = rem / n_ga, ga = rem % n_ga;
+    const size_t cbase = col << g.L;
+    const size_t sbase = cbase + ((size_t)kb << (g.LA + g.LC)) + ((size_t)(16 * ga) << g.LC);
+    for (u32 t = threadIdx.x; t < 16 * nc; t += THREADS) sh[t] = src[sbase + t];
+    __syncthreads();
+    bb_lds_dft(sh, 16 * nc, 0, g.LC, tw4096);
+    const u32 ia = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    for (u32 kc = r0; kc < nc; kc += 16) {
+        u32 v = bb::mul(sh[ia * nc + brevb(kc, g.LC)], n_inv);
+        dst[cbase + ((size_t)kc << (g.LA + g.LB)) + ((size_t)kb << g.LA) + 16 * ga + ia] = v;
+    }
+}
+__global__ __launch_bounds__(THREADS) void k_bb_ntt_small(const u32* __restrict__ src, u32* __restrict__ dst, u32 L,
+                                                          const u32* __restrict__ tw4096, u32 scale) {
+    __shared__ u32 sh[TILE];
+    const u32 n = 1u << L;
+    const size_t base = (size_t)blockIdx.x << L;
+    for (u32 t = threadIdx.x; t < n; t += THREADS) sh[t] = src[base + t];
+    __syncthreads();
+    bb_lds_dft(sh, n, 0, L, tw4096);
+    for (u32 k = threadIdx.x; k < n; k += THREADS) dst[base + k] = bb::mul(sh[brevb(k, L)], scale);
+}
+__global__ __launch_bounds__(THREADS) void k_bb_lde_pa(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 L, u32 rate_bits,
+                                                       const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                       const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
+                                                       const u32* __restrict__ pow_hi) {
+    __shared__ u32 sh[TILE];
+    const u32 LA = L - 12;
+    const u32 rows = 1u << LA;
+    const size_t col = blockIdx.x >> 8;
+    const u32 tg = blockIdx.x & 255;
+    const u32 j = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    const u32 l = (tg << 4) + j;
+    const size_t n = (size_t)1 << L;
+    const u32* cin = coeffs + col * n + l;
+    u32 orig[16];
+#pragma unroll
+    for (u32 it = 0; it < 16; it++) {
+        u32 a = r0 + 16 * it;
+        orig[it] = a < rows ? cin[(size_t)a << 12] : 0;
+    }
+    const u32 ncosets = 1u << rate_bits;
+    for (u32 c = 0; c < ncosets; c++) {
+        const u32* ph = pow_hi + (size_t)c * rows;
+#pragma unroll
+        for (u32 it = 0; it < 16; it++) {
+            u32 a = r0 + 16 * it;
+            if (a < rows) sh[a * 16 + j] = a ? bb::mul(orig[it], ph[a]) : orig[it];
+        }
+        __syncthreads();
+        bb_lds_dft(sh, rows * 16, 4, LA, tw4096);
+        const u32 sl = pow_lo[(size_t)c * 4096 + l];
+        u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+#pragma unroll
+        for (u32 it = 0; it < 16; it++) {
+            u32 pa = r0 + 16 * it;
+            if (pa < rows) {
+                u32 e = brevb(pa, LA) * l;
+                u32 f = e ? bb::mul(sl, bb_tw_split(tw_hi, tw_lo, e)) : sl;
+                out[(size_t)pa << 12] = bb::mul(sh[pa * 16 + j], f);
+            }
+        }
+        __syncthreads();
+    }
+}
+template <bool FROM_COEFFS>
+__global__ __launch_bounds__(THREADS) void k_bb_lde_pb(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 L, u32 rate_bits,
+                                                       const u32* __restrict__ tw4096, const u32* __restrict__ pow_lo) {
+    __shared__ u32 sh[TILE];
+    const u32 LT = L < 12 ? L : 12;
+    const u32 te = 1u << LT;
+    const size_t tile = blockIdx.x;
+    u32* p = lde + (tile << LT);
+    if (FROM_COEFFS) {
+        const size_t col = tile >> rate_bits;
+        const u32 c = (u32)(tile & ((1u << rate_bits) - 1));
+        const u32* cin = coeffs + (col << L);
+        const u32* pl = pow_lo + ((size_t)c << LT);
+        for (u32 t = threadIdx.x; t < te; t += THREADS) sh[t] = bb::mul(cin[t], pl[t]);
+    } else {
+        for (u32 t = threadIdx.x; t < te; t += THREADS) sh[t] = p[t];
+    }
+    __syncthreads();
+    bb_lds_dft(sh, te, 0, LT, tw4096);
+    for (u32 t = threadIdx.x; t < te; t += THREADS) p[t] = sh[t];
+}
+
+// ------------------------------------------------------------------ Merkle (Poseidon2, rate 8, digest 8 x u32 canonical)
+
+__global__ __launch_bounds__(256) void k_bb_merkle_leaves(const u32* __restrict__ cols, size_t col_stride, u32 width, u64 num_leaves,
+                                                          u32* __restrict__ out) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u32 s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    if (width <= 8) {  // hash_or_noop (plonk/config.rs:70-84), NUM_HASH_OUT_ELTS = 8
+        for (u32 c = 0; c < width; c++) s[c] = cols[(size_t)c * col_stride + j];
+    } else {
+        u32 c0 = 0;
+        for (; c0 + 8 <= width; c0 += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            poseidon2_bb::permute(s);
+        }
+        if (c0 < width) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            poseidon2_bb::permute(s);
+        }
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + 8 * j);
+    o[0] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+    o[1] = make_uint4(bb::from_mont(s[4]), bb::from_mont(s[5]), bb::from_mont(s[6]), bb::from_mont(s[7]));
+}
+__global__ __launch_bounds__(256) void k_bb_merkle_level(const u32* __restrict__ in, u32* __restrict__ out, u64 num_out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_out) return;
+    const uint4* p = reinterpret_cast<const uint4*>(in + 16 * i);
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    u32 s[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = bb::to_mont(s[k]);
+    poseidon2_bb::permute(s);
+    uint4* o = reinterpret_cast<uint4*>(out + 8 * i);
+    o[0] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+    o[1] = make_uint4(bb::from_mont(s[4]), bb::from_mont(s[5]), bb::from_mont(s[6]), bb::from_mont(s[7]));
+}
+__global__ __launch_bounds__(256) void k_bb_permute(const u32* __restrict__ in, u32* __restrict__ out, u64 count) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u32 s[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] = bb::to_mont(in[16 * i + e]);
+    poseidon2_bb::permute(s);
+#pragma unroll
+    for (int e = 0; e < 16; e++) out[16 * i + e] = bb::from_mont(s[e]);
+}
+
+// ------------------------------------------------------------------ conversions / gathers (u32)
+__global__ void k_bb_to_mont(const u32* __restrict__ src, u32* __restrict__ dst, size_t n) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) dst[g] = bb::to_mont(src[g]);
+}
+__global__ void k_bb_from_mont(const u32* __restrict__ src, u32* __restrict__ dst, size_t n) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) dst[g] = bb::from_mont(src[g]);
+}
+__global__ void k_bb_gather_row(const u32* __restrict__ cols, size_t col_stride, u32 width, u64 index, u32* dst) {
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < width) dst[c] = bb::from_mont(cols[(size_t)c * col_stride + index]);
+}
+__global__ void k_bb_bitrev_copy_to_mont(const u32* __restrict__ src, u32* __restrict__ dst, u32 bits, size_t total) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    size_t col = g >> bits;
+    u64 j = g & (((u64)1 << bits) - 1);
+    u64 r = bits ? (__brevll(j) >> (64 - bits)) : 0;
+    dst[g] = bb::to_mont(src[(col << bits) + r]);
+}
+__global__ void k_bb_transpose_to_rows(const u32* __restrict__ cols, size_t col_stride, u32 width, u64 rows, u32* __restrict__ dst) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rows * width) return;
+    u64 r = g / width;
+    u32 c = (u32)(g % width);
+    dst[g] = bb::from_mont(cols[(size_t)c * col_stride + r]);
+}
+
+// ------------------------------------------------------------------ launchers
+static inline u32 nblk(size_t n, u32 bs) { return (u32)((n + bs - 1) / bs); }
+
+void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
+    const u32 L = t.log_n;
+    if (!ncols) return;
+    if (L <= 12) {
+        hipLaunchKernelGGL(k_bb_ntt_small, dim3((u32)ncols), dim3(THREADS), 0, stream, src, coeffs, L, t.tw4096_inv, t.n_inv);
+        return;
+    }
+    BbInvGeom g{L, L <= 16 ? L - 8 : 8, L <= 16 ? 0 : L - 16, 8};
+    const u32 LL = g.LB + g.LC;
+    u32* p1_dst = g.LB ? coeffs : scratch;
+    hipLaunchKernelGGL(k_bb_intt_p1, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv,
+                       t.tw_hi_inv, t.tw_lo_inv);
+    if (g.LB)
+        hipLaunchKernelGGL(k_bb_intt_p2, dim3((u32)(ncols << (g.LA - 4 + g.LC - 4))), dim3(THREADS), 0, stream, coeffs, scratch,
+                           g, t.tw4096_inv);
+    hipLaunchKernelGGL(k_bb_intt_p3, dim3((u32)(ncols << (g.LB + g.LA - 4))), dim3(THREADS), 0, stream, scratch, coeffs, g,
+                       t.tw4096_inv, t.n_inv);
+}
+void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream) {
+    const u32 L = t.log_n, r = ct.rate_bits;
+    if (!ncols) return;
+    if (L <= 12) {
+        hipLaunchKernelGGL(k_bb_lde_pb<true>, dim3((u32)(ncols << r)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
+                           ct.pow_lo);
+        return;
+    }
+    hipLaunchKernelGGL(k_bb_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
+                       t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+    hipLaunchKernelGGL(k_bb_lde_pb<false>, dim3((u32)(ncols << (r + L - 12))), dim3(THREADS), 0, stream, coeffs, lde, L, r,
+                       t.tw4096_fwd, ct.pow_lo);
+}
+void bb_merkle_leaves(const u32* cols, size_t col_stride, u32 width, u64 num_leaves, u32* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bb_merkle_leaves, dim3(nblk(num_leaves, 256)), dim3(256), 0, stream, cols, col_stride, width, num_leaves, out);
+}
+void bb_merkle_level(const u32* in, u32* out, u64 num_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bb_merkle_level, dim3(nblk(num_out, 256)), dim3(256), 0, stream, in, out, num_out);
+}
+void bb_poseidon2_permute(const u32* in, u32* out, u64 count, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bb_permute, dim3(nblk(count, 256)), dim3(256), 0, stream, in, out, count);
+}
+void bb_to_mont(const u32* src, u32* dst, size_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_bb_to_mont, dim3(nblk(n, 256)), dim3(256), 0, stream, src, dst, n);
+}
+void bb_from_mont(const u32* src, u32* dst, size_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_bb_from_mont, dim3(nblk(n, 256)), dim3(256), 0, stream, src, dst, n);
+}
+void bb_gather_row(const u32* cols, size_t col_stride, u32 width, u64 index, u32* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bb_gather_row, dim3(nblk(width, 64)), dim3(64), 0, stream, cols, col_stride, width, index, dst);
+}
+void bb_bitrev_copy_to_mont(const u32* src, u32* dst, u32 bits, size_t ncols, hipStream_t stream) {
+    size_t total = ncols << bits;
+    if (total) hipLaunchKernelGGL(k_bb_bitrev_copy_to_mont, dim3(nblk(total, 256)), dim3(256), 0, stream, src, dst, bits, total);
+}
+void bb_transpose_to_rows(const u32* cols, size_t col_stride, u32 width, u64 rows, u32* dst, hipStream_t stream) {
+    if (rows && width)
+        hipLaunchKernelGGL(k_bb_transpose_to_rows, dim3(nblk(rows * width, 256)), dim3(256), 0, stream, cols, col_stride, width, rows, dst);
+}
+
+}  // namespace gbk

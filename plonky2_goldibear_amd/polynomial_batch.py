@@ -80,18 +80,24 @@ class GpuContext:
 
     def permute(self, states, field=N.GB_GOLDILOCKS):
         """PoseidonGoldilocks::poseidon on each row of `states` [count][12]."""
-        x = np.ascontiguousarray(states, dtype=np.uint64)
+        x = np.ascontiguousarray(states, dtype=_dtype(field))
         out = np.empty_like(x)
         N.check(self._lib.gb_permute(self.handle, field, x.ctypes.data, out.ctypes.data, x.shape[0]), self.handle)
         return out
 
 
-def _as_input(x):
-    """numpy array (host) or torch CUDA tensor (device, int64/uint64 bit pattern) -> (ptr, shape, flags, keepalive)"""
+def _dtype(field):
+    return np.uint64 if field == N.GB_GOLDILOCKS else np.uint32
+
+
+def _as_input(x, field=N.GB_GOLDILOCKS):
+    """numpy array (host) or torch CUDA tensor (device, same-width integer bit pattern) -> (ptr, shape, flags, keepalive)"""
+    dt = _dtype(field)
     if isinstance(x, np.ndarray) or not hasattr(x, "data_ptr"):
-        a = np.ascontiguousarray(x, dtype=np.uint64)
+        a = np.ascontiguousarray(x, dtype=dt)
         return a.ctypes.data, a.shape, N.GB_INPUT_HOST, a
-    assert x.is_cuda and x.is_contiguous() and x.element_size() == 8, "device input must be a contiguous 8-byte CUDA tensor"
+    assert x.is_cuda and x.is_contiguous() and x.element_size() == np.dtype(dt).itemsize, \
+        "device input must be a contiguous CUDA tensor of the field's word size"
     return x.data_ptr(), tuple(x.shape), N.GB_INPUT_DEVICE, x
 
 
@@ -104,7 +110,7 @@ class MerkleTree:
     @property
     def cap(self):
         b = self._b
-        out = np.empty((1 << b.cap_height, b._hout), dtype=np.uint64)
+        out = np.empty((1 << b.cap_height, b._hout), dtype=b._dt)
         N.check(b._lib.gb_batch_cap(b.handle, out.ctypes.data), b.ctx.handle)
         return out
 
@@ -113,14 +119,14 @@ class MerkleTree:
         """The reference's interleaved digest vector (merkle_tree.rs:50-58), copied to the host."""
         b = self._b
         n = 2 * ((1 << (b.degree_log + b.rate_bits)) - (1 << b.cap_height))
-        out = np.empty((n, b._hout), dtype=np.uint64)
+        out = np.empty((n, b._hout), dtype=b._dt)
         N.check(b._lib.gb_batch_digests(b.handle, out.ctypes.data), b.ctx.handle)
         return out
 
     @property
     def leaves(self):
         b = self._b
-        out = np.empty((1 << (b.degree_log + b.rate_bits), b.width), dtype=np.uint64)
+        out = np.empty((1 << (b.degree_log + b.rate_bits), b.width), dtype=b._dt)
         N.check(b._lib.gb_batch_leaves(b.handle, out.ctypes.data), b.ctx.handle)
         return out
 
@@ -142,13 +148,14 @@ class PolynomialBatch:
         self.field, self.num_polys, self.degree_log = f.value, nc.value, dl.value
         self.rate_bits, self.cap_height, self.blinding = rb.value, ch.value, bool(bl.value)
         self._hout = 4 if self.field == N.GB_GOLDILOCKS else 8
+        self._dt = _dtype(self.field)
         self.width = self.num_polys + (N.GB_SALT_SIZE if self.blinding else 0)
         self.merkle_tree = MerkleTree(self)
         _live_batches.add(self)
 
     @classmethod
     def _commit(cls, fn_name, ctx, cols, rate_bits, cap_height, salts, field):
-        ptr, shape, flags, keep = _as_input(cols)
+        ptr, shape, flags, keep = _as_input(cols, field)
         if len(shape) != 2:
             raise N.ShapeError(N.GB_ERR_INVALID, "expected a [num_polys][n] matrix")
         ncols, n = shape
@@ -157,7 +164,7 @@ class PolynomialBatch:
             raise N.ShapeError(N.GB_ERR_INVALID, "polynomial length must be a power of two (util log2_strict)")
         sptr, skeep = None, None
         if salts is not None:
-            sptr, sshape, sflags, skeep = _as_input(salts)
+            sptr, sshape, sflags, skeep = _as_input(salts, field)
             if tuple(sshape) != (N.GB_SALT_SIZE, n << rate_bits) or sflags != flags:
                 raise N.ShapeError(N.GB_ERR_INVALID, "salts must be [4][n << rate_bits] in the same memory space as the columns")
         h = C.c_void_p()
@@ -187,7 +194,7 @@ class PolynomialBatch:
 
     def polynomial(self, col):
         """.polynomials[col].coeffs"""
-        out = np.empty(1 << self.degree_log, dtype=np.uint64)
+        out = np.empty(1 << self.degree_log, dtype=self._dt)
         N.check(self._lib.gb_batch_coeffs(self.handle, col, out.ctypes.data), self.ctx.handle)
         return out
 
@@ -197,14 +204,14 @@ class PolynomialBatch:
 
     def get_lde_values(self, index, step):
         """oracle.rs:153-158"""
-        out = np.empty(self.num_polys, dtype=np.uint64)
+        out = np.empty(self.num_polys, dtype=self._dt)
         N.check(self._lib.gb_batch_lde_values(self.handle, index, step, out.ctypes.data), self.ctx.handle)
         return out
 
     def _leaf(self, i):
-        row = np.empty(self.width, dtype=np.uint64)
+        row = np.empty(self.width, dtype=self._dt)
         layers = self.degree_log + self.rate_bits - self.cap_height
-        sib = np.empty((max(layers, 1), self._hout), dtype=np.uint64)
+        sib = np.empty((max(layers, 1), self._hout), dtype=self._dt)
         n = C.c_uint32()
         N.check(self._lib.gb_batch_leaf(self.handle, i, row.ctypes.data, sib.ctypes.data, C.byref(n)), self.ctx.handle)
         return row, sib[: n.value]
