@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="prove", choices=["prove", "commit"])
     ap.add_argument("--challenges", type=int, default=3)
+    ap.add_argument("--field", default="goldilocks", choices=["goldilocks", "babybear"])
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cols", type=int, default=135)
     ap.add_argument("--cpu-sample-log-n", type=int, default=None)
@@ -132,12 +133,18 @@ def main():
             proof_len = len(circuit.prove(dev))
     else:
         host = splitmix64_matrix((0xC0FFEE ^ (ncols << 32) ^ log_n) + rank, ncols, n)
-        dev = torch.from_numpy(host.view(np.int64)).to("cuda:%d" % local_rank)
+        ftag = 0
+        if args.field == "babybear":
+            ftag = 1
+            host = (host % np.uint64(2013265921)).astype(np.uint32)
+            dev = torch.from_numpy(host.view(np.int32)).to("cuda:%d" % local_rank)
+        else:
+            dev = torch.from_numpy(host.view(np.int64)).to("cuda:%d" % local_rank)
         del host
         torch.cuda.synchronize()
 
         def step():
-            b = PolynomialBatch.from_values(ctx, dev, rate_bits, cap_height)
+            b = PolynomialBatch.from_values(ctx, dev, rate_bits, cap_height, field=ftag)
             b.free()
 
     def barrier():
@@ -185,16 +192,18 @@ def main():
             workload = ("prove(): 2^%d-row Goldilocks dummy circuit (2^%d+1 NoopGates), standard_recursion_config_gl with "
                         "num_challenges=%d, Poseidon-12, witness resident in HBM -> proof bytes (%d B)" % (log_n, log_n - 1, c, proof_len))
         else:
-            alg_bytes = (2 + (1 << rate_bits)) * n * 8 * ncols  # (2 + 2^r) n s per column
+            esz = 4 if args.field == "babybear" else 8
+            alg_bytes = (2 + (1 << rate_bits)) * n * esz * ncols  # (2 + 2^r) n s per column
             perms = N * (-(-ncols // 8)) + (N - (1 << cap_height))  # leaf sponge + internal nodes
             metric = "commits/s (PolynomialBatch::from_values, wires oracle of the 2^%d-row circuit)" % log_n
-            workload = "from_values: %d cols x 2^%d rows Goldilocks, rate_bits 3, cap_height 4, Poseidon-12" % (ncols, log_n)
+            workload = "from_values: %d cols x 2^%d rows %s, rate_bits 3, cap_height 4, %s" % (
+                ncols, log_n, args.field, "Poseidon2-16" if args.field == "babybear" else "Poseidon-12")
         achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
         out = {
             "metric": metric, "value": world * steps / dt, "unit": metric.split(" ")[0], "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload, "field": "goldilocks", "log_n": log_n, "rate_bits": rate_bits,
+            "vs_baseline": None, "dtype": "u32" if args.field == "babybear" else "u64", "data": "synthetic",
+            "config": {"workload": workload, "field": args.field, "log_n": log_n, "rate_bits": rate_bits,
                        "cap_height": cap_height, "sharding": "one independent circuit per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": "NTT pass = k_gl_intt_p1+p2+p3 (IFFT) + k_gl_lde_pa+pb (FFT + blinding), all commitments of the step",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -223,3 +223,48 @@ def verify(circ, proof_bytes, stats=None):
     caps = [[[int(x) for x in h] for h in circ.constants_sigmas_cap], proof["wires_cap"], proof["zs_cap"], proof["quotient_cap"]]
     V.verify_fri(proof, ch, caps, cd, stats)
     return True
+
+
+# ----------------------------------------------------------------------------- test-form dummy circuit (digest KAT)
+def test_form_constants_sigmas(num_noops=16000, cfg=None):
+    """constants||sigmas VALUES of the reference's test-form dummy circuit
+    (recursion/recursive_verifier.rs:666-697): `num_noops` NoopGates, PoseidonGate added to the gate set, four
+    public inputs all equal to the `zero` target.  build() then (circuit_builder.rs:1126-1178):
+      row n0   PoseidonGate   in-circuit hash of the 4 public inputs: swap wire (24) and the 12 input wires all
+                              tied to the `zero` constant target (hash/poseidon_goldilocks.rs:1116-1143)
+      row n0+1 PublicInputGate wires 0..3 tied to the Poseidon outputs (wires 12..15)
+      row n0+2 ConstantGate{2} wire 0 tied to `zero`
+    gates sorted by (degree, id) = [Noop, Constant, PublicInput, Poseidon]; 7 + 4 - 1 > 9 so two selector
+    groups [0..3), [3..4) (gates/selectors.rs:168-206) with UNUSED_SELECTOR = 2^32 - 1 elsewhere.
+    Returns (constants_sigmas [4 + routed][n], degree_bits)."""
+    cfg = cfg or CircuitConfig()
+    rows_used = num_noops + 3
+    degree_bits = (rows_used - 1).bit_length()
+    n = 1 << degree_bits
+    pos_row, pi_row, const_row = num_noops, num_noops + 1, num_noops + 2
+    UNUSED = (1 << 32) - 1
+    s0 = np.zeros(n, dtype=np.uint64)            # NoopGate = index 0 (padding rows are NoopGates too)
+    s0[const_row], s0[pi_row], s0[pos_row] = 1, 2, UNUSED
+    s1 = np.full(n, UNUSED, dtype=np.uint64)
+    s1[pos_row] = 3
+    consts = np.zeros((cfg.num_constants, n), dtype=np.uint64)
+    k_is = np.array([pow(7, i, P) for i in range(cfg.num_routed_wires)], dtype=np.uint64)
+    sub = O.powers(pow(1753635133440165772, 1 << (32 - degree_bits), P), n)
+    sig = np.empty((cfg.num_routed_wires, n), dtype=np.uint64)
+    for j in range(cfg.num_routed_wires):
+        sig[j] = O.scale_vec(sub, int(k_is[j]))
+    # copy classes, members in (row, column) order (permutation_argument.rs:84-101)
+    classes = [[(pos_row, c) for c in range(12)] + [(pos_row, 24), (const_row, 0)]]
+    classes += [[(pos_row, 12 + i), (pi_row, i)] for i in range(4)]
+    for cls in classes:
+        for t, (row, col) in enumerate(cls):
+            nrow, ncol = cls[(t + 1) % len(cls)]
+            sig[col, row] = int(k_is[ncol]) * int(sub[nrow]) % P
+    return np.concatenate([s0[None, :], s1[None, :], consts, sig]).astype(np.uint64), degree_bits
+
+
+def circuit_digest_from_cap(cap, degree_bits):
+    """circuit_builder.rs:1300-1312 with the empty domain separator"""
+    dom = O.hash_no_pad(np.array([1, 0, 0, 0, 0, 0, 0, 1], dtype=np.uint64))
+    parts = np.concatenate([np.asarray(cap, dtype=np.uint64).ravel(), dom, np.array([degree_bits], dtype=np.uint64)])
+    return O.hash_no_pad(parts)

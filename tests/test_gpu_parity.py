@@ -137,3 +137,13 @@ def test_full_size_2pow20_properties(ctx):
         assert O.merkle_verify(row, int(i), cap, sib)
     again = PolynomialBatch.from_coeffs(ctx, gpu.polynomials, 3, 4)
     assert (again.merkle_tree.cap == cap).all()
+
+
+def test_circuit_digest_kat_gpu(ctx, kats):
+    """The reference's own golden value (recursion/recursive_verifier.rs:427-436): the constants||sigmas
+    commitment of the 16 000-NoopGate test-form circuit, computed on the GPU, hashes to the pinned digest."""
+    from oracle import plonk_dummy as D
+    want = kats["circuit_digest_gl"][0]
+    cs, degree_bits = D.test_form_constants_sigmas(16000)
+    gpu = PolynomialBatch.from_values(ctx, cs, 3, 4)
+    assert D.circuit_digest_from_cap(gpu.merkle_tree.cap, degree_bits).tolist() == want["digest"]
