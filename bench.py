@@ -110,7 +110,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from plonky2_goldibear_amd import CircuitData, GpuContext, PolynomialBatch
+    from plonky2_goldibear_amd import CircuitData, GpuContext, PolynomialBatch, sharding
     from plonky2_goldibear_amd import dummy_circuit as DC
 
     ncols, log_n, rate_bits, cap_height = args.cols, args.log_n, 3, 4
@@ -150,8 +150,7 @@ def main():
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        sharding.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -162,11 +161,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(time.perf_counter() - t0)  # whole job = the slowest rank
 
     scope_names = ("IFFT", "FFT + blinding", "build Merkle tree", "compute wires commitment", "compute partial products",
                    "compute quotient polys", "construct the opening set", "compute opening proofs",
@@ -199,6 +194,15 @@ def main():
             workload = "from_values: %d cols x 2^%d rows %s, rate_bits 3, cap_height 4, %s" % (
                 ncols, log_n, args.field, "Poseidon2-16" if args.field == "babybear" else "Poseidon-12")
         achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
+        # physical HBM bytes per column, measured once with rocprofv3 PMC passes (profiles/r01_ntt_traffic_pmc.json)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_ntt_traffic_pmc.json")
+        if args.field == "goldilocks" and log_n == 20 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if args.workload == "prove":
+                traffic = tj["ifft_bytes_per_column"] * (135 + nzs) + tj["lde_bytes_per_column"] * (135 + nzs + nq + 2)
+            else:
+                traffic = (tj["ifft_bytes_per_column"] + tj["lde_bytes_per_column"]) * ncols
         out = {
             "metric": metric, "value": world * steps / dt, "unit": metric.split(" ")[0], "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -207,7 +211,7 @@ def main():
                        "cap_height": cap_height, "sharding": "one independent circuit per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": "NTT pass = k_gl_intt_p1+p2+p3 (IFFT) + k_gl_lde_pa+pb (FFT + blinding), all commitments of the step",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": alg_bytes, "ms": ntt_ms},
+                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "ms": ntt_ms},
             "scopes_ms_per_step": {k: v[0] / steps for k, v in scopes.items() if v[1]},
             "merkle": {"permutations": perms, "Gperm_per_s": perms / (merkle_ms * 1e-3) / 1e9},
         }
