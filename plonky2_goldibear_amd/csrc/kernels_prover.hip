@@ -151,10 +151,13 @@ __global__ __launch_bounds__(256) void k_zs_finalize(ZsParams p, const u64* __re
 
 // One thread per LDE point, addressed by its leaf index j.  Writes the (unshifted) quotient value to
 // qv[(k * R + coset) * n + il], il = natural index of the point inside its coset block.
+// C = num_challenges and CH = chunk size (quotient_degree_factor) are compile-time so that the per-challenge
+// accumulators stay in registers and a chunk's 2*CH loads are issued together.
+template <u32 C, u32 CH>
 __global__ __launch_bounds__(256) void k_quotient(QuotientParams p, const u64* __restrict__ cs, const u64* __restrict__ wires,
                                                   const u64* __restrict__ zs, const u64* __restrict__ uni,
                                                   u64* __restrict__ qv) {
-    const u32 lgn = p.log_n, r = p.rate_bits, c = p.num_challenges;
+    const u32 lgn = p.log_n, r = p.rate_bits;
     const size_t n = (size_t)1 << lgn, N = n << r;
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
@@ -168,69 +171,100 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams p, const u64* _
     // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash 4]
     const u32 nr = p.num_routed, nterms = p.nterms, R = 1u << r;
     const u64* betas = uni;
-    const u64* gammas = uni + c;
-    const u64* bk = gammas + c;
-    const u64* apow = bk + (size_t)c * nr;
-    const u64* zh = apow + (size_t)c * nterms;
+    const u64* gammas = uni + C;
+    const u64* bk = gammas + C;
+    const u64* apow = bk + (size_t)C * nr;
+    const u64* zh = apow + (size_t)C * nterms;
     const u64* zh_inv = zh + R;
     const u64* pi_hash = zh_inv + R;
 
-    u64 acc[MAX_CHALLENGES];
-    for (u32 k = 0; k < c; k++) acc[k] = 0;
+    u64 acc[C];
+#pragma unroll
+    for (u32 k = 0; k < C; k++) acc[k] = 0;
     u32 t = 0;
     // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61)
     const u64 l0 = gl::mul(zh[imod], gl::inv(gl::mul((u64)(n % gl::P), gl::sub(x, 1))));
-    for (u32 k = 0; k < c; k++, t++) {
-        u64 term = gl::mul(l0, gl::sub(zs[(size_t)k * N + j], 1));
-        for (u32 k2 = 0; k2 < c; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + t]));
+    u64 zk[C];
+#pragma unroll
+    for (u32 k = 0; k < C; k++) zk[k] = zs[(size_t)k * N + j];
+#pragma unroll
+    for (u32 k = 0; k < C; k++, t++) {
+        u64 term = gl::mul(l0, gl::sub(zk[k], 1));
+#pragma unroll
+        for (u32 k2 = 0; k2 < C; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + t]));
     }
-    // partial-product checks (util/partial_products.rs:53-77); term index = c + k * nchunks + m
+    // partial-product checks (util/partial_products.rs:53-77); term index = C + k * nchunks + m
     const u32 num_prods = p.nchunks - 1;
+    u64 prev[C];
+#pragma unroll
+    for (u32 k = 0; k < C; k++) prev[k] = zk[k];
     for (u32 m = 0; m < p.nchunks; m++) {
-        u64 np[MAX_CHALLENGES], dp[MAX_CHALLENGES];
-        for (u32 k = 0; k < c; k++) np[k] = dp[k] = 1;
-        const u32 j1 = min((m + 1) * p.chunk, nr);
-        for (u32 w = m * p.chunk; w < j1; w++) {
-            const u64 wv = wires[(size_t)w * N + j];
-            const u64 sg = cs[(size_t)(p.num_constants + w) * N + j];
-            for (u32 k = 0; k < c; k++) {
-                u64 num = gl::add(gl::add(wv, gl::mul(bk[k * nr + w], x)), gammas[k]);
-                u64 den = gl::add(gl::add(wv, gl::mul(betas[k], sg)), gammas[k]);
-                np[k] = gl::mul(np[k], num);
-                dp[k] = gl::mul(dp[k], den);
+        u64 wv[CH], sg[CH];
+        const u32 w0 = m * CH;
+#pragma unroll
+        for (u32 q = 0; q < CH; q++) {
+            const u32 w = w0 + q < nr ? w0 + q : nr - 1;  // clamp: the tail chunk re-reads the last wire, masked below
+            wv[q] = wires[(size_t)w * N + j];
+            sg[q] = cs[(size_t)(p.num_constants + w) * N + j];
+        }
+        u64 next[C];
+#pragma unroll
+        for (u32 k = 0; k < C; k++)
+            next[k] = m == num_prods ? zs[(size_t)k * N + jn] : zs[((size_t)C + (size_t)k * num_prods + m) * N + j];
+        u64 np[C], dp[C];
+#pragma unroll
+        for (u32 k = 0; k < C; k++) np[k] = dp[k] = 1;
+#pragma unroll
+        for (u32 q = 0; q < CH; q++) {
+            if (w0 + q < nr) {
+#pragma unroll
+                for (u32 k = 0; k < C; k++) {
+                    u64 num = gl::add(gl::add(wv[q], gl::mul(bk[k * nr + w0 + q], x)), gammas[k]);
+                    u64 den = gl::add(gl::add(wv[q], gl::mul(betas[k], sg[q])), gammas[k]);
+                    np[k] = gl::mul(np[k], num);
+                    dp[k] = gl::mul(dp[k], den);
+                }
             }
         }
-        for (u32 k = 0; k < c; k++) {
-            const u64 prev = m == 0 ? zs[(size_t)k * N + j] : zs[((size_t)c + (size_t)k * num_prods + m - 1) * N + j];
-            const u64 next = m == num_prods ? zs[(size_t)k * N + jn] : zs[((size_t)c + (size_t)k * num_prods + m) * N + j];
-            const u64 term = gl::sub(gl::mul(prev, np[k]), gl::mul(next, dp[k]));
-            const u32 tt = c + k * p.nchunks + m;
-            for (u32 k2 = 0; k2 < c; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + tt]));
+#pragma unroll
+        for (u32 k = 0; k < C; k++) {
+            const u64 term = gl::sub(gl::mul(prev[k], np[k]), gl::mul(next[k], dp[k]));
+            const u32 tt = C + k * p.nchunks + m;
+#pragma unroll
+            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + tt]));
+            prev[k] = next[k];
         }
     }
-    t = c + c * p.nchunks;
+    t = C + C * p.nchunks;
     // gate constraints: filter * unfiltered, summed per constraint index (vanishing_poly.rs:741-774,
     // gates/gate.rs:188-215,391-404).  One selector group {0,1,2}; no UNUSED factor (single selector).
     {
         const u64 s = cs[j];  // constants[0] = selector
         u64 f[3];
+#pragma unroll
         for (u32 g = 0; g < 3; g++) {
             u64 v = 1;
+#pragma unroll
             for (u32 ii = 0; ii < 3; ii++)
                 if (ii != g) v = gl::mul(v, gl::sub((u64)ii, s));
             f[g] = v;
         }
+        const u64 f_pi = p.gate_pi == 0 ? f[0] : (p.gate_pi == 1 ? f[1] : f[2]);
+        const u64 f_c = p.gate_constant == 0 ? f[0] : (p.gate_constant == 1 ? f[1] : f[2]);
+#pragma unroll
         for (u32 cj = 0; cj < 4; cj++, t++) {
             const u64 wv = wires[(size_t)cj * N + j];
-            u64 term = gl::mul(f[p.gate_pi], gl::sub(wv, pi_hash[cj]));
+            u64 term = gl::mul(f_pi, gl::sub(wv, pi_hash[cj]));
             if (cj < p.num_gate_consts) {
                 const u64 kc = cs[(size_t)(p.num_selectors + cj) * N + j];
-                term = gl::add(term, gl::mul(f[p.gate_constant], gl::sub(kc, wv)));
+                term = gl::add(term, gl::mul(f_c, gl::sub(kc, wv)));
             }
-            for (u32 k2 = 0; k2 < c; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + t]));
+#pragma unroll
+            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + t]));
         }
     }
-    for (u32 k = 0; k < c; k++) qv[(((size_t)k << r) + cidx) * n + il] = gl::mul(acc[k], zh_inv[imod]);
+#pragma unroll
+    for (u32 k = 0; k < C; k++) qv[(((size_t)k << r) + cidx) * n + il] = gl::mul(acc[k], zh_inv[imod]);
 }
 
 // After the per-block natural->natural inverse NTTs: a_c[t] are the coefficients of R_c(s_c X).
@@ -497,7 +531,23 @@ void gl_zs_partial_products(const ZsParams& p, const u64* witness, const u64* si
 void gl_quotient_values(const QuotientParams& p, const u64* cs, const u64* wires, const u64* zs, const u64* uniforms, u64* qv,
                         hipStream_t st) {
     const size_t N = (size_t)1 << (p.log_n + p.rate_bits);
-    hipLaunchKernelGGL(k_quotient, dim3(nblk(N, 256)), dim3(256), 0, st, p, cs, wires, zs, uniforms, qv);
+    const dim3 grid(nblk(N, 256)), block(256);
+#define GB_Q(CC, HH) hipLaunchKernelGGL((k_quotient<CC, HH>), grid, block, 0, st, p, cs, wires, zs, uniforms, qv)
+    if (p.chunk == 8) {
+        switch (p.num_challenges) {
+            case 1: GB_Q(1, 8); return;
+            case 2: GB_Q(2, 8); return;
+            case 3: GB_Q(3, 8); return;
+            case 4: GB_Q(4, 8); return;
+            default: break;
+        }
+    }
+    if (p.chunk == 16 && p.num_challenges <= 2) {
+        if (p.num_challenges == 1) GB_Q(1, 16); else GB_Q(2, 16);
+        return;
+    }
+    // (gb_circuit_create rejects other shapes)
+#undef GB_Q
 }
 
 void gl_quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const u64* a, const u64* mat, const CosetPow& inv_shift,
