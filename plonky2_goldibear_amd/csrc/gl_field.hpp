@@ -19,15 +19,19 @@ static constexpr u64 TWO_ADIC_GEN_32 = 1753635133440165772ULL;  // order 2^32
 
 __host__ __device__ __forceinline__ u64 canon(u64 x) { return x >= P ? x - P : x; }
 
-// a, b canonical -> canonical
+// a, b canonical -> canonical.  s - p == s + EPS (mod 2^64), so both the wrapped case (a + b >= 2^64) and the
+// s >= p case select s + EPS; written with carry builtins: 50 vs 64 cycles per wave-butterfly
+// (tools/microbench_addsub.hip).
 __host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
-    u64 s = a + b;
-    if (s < a) s += EPS;
-    return canon(s);
+    u64 s, u;
+    bool c = __builtin_uaddll_overflow(a, b, &s);
+    bool c2 = __builtin_uaddll_overflow(s, EPS, &u);
+    return (c | c2) ? u : s;
 }
 __host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
-    u64 d = a - b;
-    return a >= b ? d : d + P;
+    u64 d;
+    bool br = __builtin_usubll_overflow(a, b, &d);
+    return d - (br ? EPS : 0);  // + p
 }
 __host__ __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }
 
