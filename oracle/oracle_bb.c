@@ -246,3 +246,34 @@ int gbo_bb_commit(const bb_t *cols, size_t ncols, unsigned log_n, unsigned rate_
 uint32_t gbo_bb_mul(uint32_t a, uint32_t b) { return bb_mul(a, b); }
 uint32_t gbo_bb_powu(uint32_t a, uint64_t e) { return bb_pow(a, e); }
 uint32_t gbo_bb_two_adic_generator(unsigned bits) { return bb_two_adic_generator(bits); }
+
+/* ------------------------------------------------------------------ Challenger (iop/challenger.rs:18-150), width 16, rate 8 */
+typedef struct { bb_t state[W]; bb_t in[RATE]; int nin; bb_t out[RATE]; int nout; } gbo_bb_challenger;
+void gbo_bb_challenger_init(gbo_bb_challenger *c) { memset(c, 0, sizeof *c); }
+static void bb_duplexing(gbo_bb_challenger *c) {
+    for (int i = 0; i < c->nin; i++) c->state[i] = c->in[i];
+    c->nin = 0;
+    gbo_bb_poseidon2(c->state, c->state);
+    memcpy(c->out, c->state, RATE * sizeof(bb_t));
+    c->nout = RATE;
+}
+void gbo_bb_challenger_observe(gbo_bb_challenger *c, const bb_t *e, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        c->nout = 0;
+        c->in[c->nin++] = e[i];
+        if (c->nin == RATE) bb_duplexing(c);
+    }
+}
+bb_t gbo_bb_challenger_get(gbo_bb_challenger *c) {
+    if (c->nin != 0 || c->nout == 0) bb_duplexing(c);
+    return c->out[--c->nout];
+}
+/* field/src/polynomial/mod.rs:62-72 */
+void gbo_bb_coset_ifft(bb_t *v, unsigned lg_n, bb_t shift) {
+    size_t n = (size_t)1 << lg_n;
+    gbo_bb_ifft(v, lg_n);
+    bb_t si = bb_inv(shift), p = 1;
+    for (size_t i = 0; i < n; i++) { v[i] = bb_mul(v[i], p); p = bb_mul(p, si); }
+}
+void gbo_bb_powers(bb_t base, size_t n, bb_t *out) { bb_t x = 1; for (size_t i = 0; i < n; i++) { out[i] = x; x = bb_mul(x, base); } }
+void gbo_bb_scale_vec(const bb_t *a, bb_t k, size_t n, bb_t *out) { for (size_t i = 0; i < n; i++) out[i] = bb_mul(a[i], k); }

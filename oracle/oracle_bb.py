@@ -32,6 +32,8 @@ def lib():
         L.gbo_bb_commit.restype = C.c_int
         L.gbo_bb_two_adic_generator.argtypes = [C.c_uint]
         L.gbo_bb_two_adic_generator.restype = C.c_uint32
+        L.gbo_bb_powers.argtypes = [C.c_uint32, C.c_size_t, _u32p]
+        L.gbo_bb_scale_vec.argtypes = [_u32p, C.c_uint32, C.c_size_t, _u32p]
         _done = True
     return L
 
@@ -99,6 +101,19 @@ def merkle_verify(leaf, index, cap, siblings):
 def fill(seed, count):
     """synthetic canonical BabyBear elements (SplitMix64 reduced mod p)"""
     return (O.splitmix64_fill(seed, count, modulus=(1 << 64) - 1) % np.uint64(BB_P)).astype(np.uint32)
+
+
+def powers(base, n):
+    out = np.empty(n, dtype=np.uint32)
+    lib().gbo_bb_powers(int(base), n, out)
+    return out
+
+
+def scale_vec(a, k):
+    a = _a(a)
+    out = np.empty_like(a)
+    lib().gbo_bb_scale_vec(a, int(k), a.size, out)
+    return out
 
 
 class PolynomialBatch:

@@ -17,8 +17,9 @@ import numpy as np
 
 from . import oracle as O
 from . import verifier as V
+from .fields import BB, GL
 
-P = O.GL_P
+P = O.GL_P  # test-form digest KAT below is Goldilocks only
 
 
 class CircuitConfig:
@@ -30,6 +31,14 @@ class CircuitConfig:
                  security_bits=100):
         self.__dict__.update(locals())
         del self.__dict__["self"]
+
+    @classmethod
+    def babybear(cls, num_challenges=6, **kw):
+        """recursion_config_bb_narrow (circuit_data.rs:130-138): 167 wires, 41 routed, arity 8, 6 challenges
+        (31-bit field: (31 - degree_bits) * num_challenges >= 100 needs 10 at 2^20 rows)."""
+        d = dict(num_challenges=num_challenges, num_wires=167, num_routed_wires=41, arity_bits=3)
+        d.update(kw)
+        return cls(**d)
 
 
 def reduction_arity_bits(cfg, degree_bits):
@@ -46,35 +55,36 @@ class DummyCircuit:
 
     GATE_NOOP, GATE_CONSTANT, GATE_PI = 0, 1, 2  # sorted by (degree, id): Noop(0), "ConstantGate {..}"(1), "PublicInputGate<4>"(1)
 
-    def __init__(self, degree_bits, cfg=None, check_security=True):
-        cfg = cfg or CircuitConfig()
+    def __init__(self, degree_bits, cfg=None, check_security=True, F=GL):
+        cfg = cfg or (CircuitConfig() if F is GL else CircuitConfig.babybear())
         assert degree_bits >= 3
         if check_security:  # circuit_builder.rs:1187-1192
-            assert (64 - degree_bits) * cfg.num_challenges >= cfg.security_bits, "num_challenges too small for this degree"
-        self.cfg, self.degree_bits = cfg, degree_bits
+            assert (F.order_bits - degree_bits) * cfg.num_challenges >= cfg.security_bits, "num_challenges too small for this degree"
+        self.cfg, self.degree_bits, self.F = cfg, degree_bits, F
+        P, dt, M, H = F.P, F.dtype, F.mod, F.hout
         n = 1 << degree_bits
         self.n = n
         num_noops = (1 << (degree_bits - 1)) + 1
         self.pi_row, self.const_row = num_noops, num_noops + 1
         assert self.const_row < n
         # selector column: gate index per row; constants: all zero (the only constant is 0)
-        sel = np.zeros(n, dtype=np.uint64)
+        sel = np.zeros(n, dtype=dt)
         sel[self.pi_row] = self.GATE_PI
         sel[self.const_row] = self.GATE_CONSTANT
-        consts = np.zeros((cfg.num_constants, n), dtype=np.uint64)
+        consts = np.zeros((cfg.num_constants, n), dtype=dt)
         self.num_constants = 1 + cfg.num_constants
-        self.k_is = np.array([pow(7, i, P) for i in range(cfg.num_routed_wires)], dtype=np.uint64)
-        w = pow(1753635133440165772, 1 << (32 - degree_bits), P)
-        self.subgroup = sub = O.powers(w, n)
-        # sigma: identity except the single copy class {(pi,0..3), (const,0)} in (row, column) order
-        sig = np.empty((cfg.num_routed_wires, n), dtype=np.uint64)
+        self.k_is = np.array([pow(F.generator, i, P) for i in range(cfg.num_routed_wires)], dtype=dt)
+        w = F.two_adic_generator(degree_bits)
+        self.subgroup = sub = M.powers(w, n)
+        # sigma: identity except the single copy class {(pi,0..H-1), (const,0)} in (row, column) order
+        sig = np.empty((cfg.num_routed_wires, n), dtype=dt)
         for j in range(cfg.num_routed_wires):
-            sig[j] = O.scale_vec(sub, int(self.k_is[j]))
-        cls = [(self.pi_row, 0), (self.pi_row, 1), (self.pi_row, 2), (self.pi_row, 3), (self.const_row, 0)]
+            sig[j] = M.scale_vec(sub, int(self.k_is[j]))
+        cls = [(self.pi_row, j) for j in range(H)] + [(self.const_row, 0)]
         for t, (row, col) in enumerate(cls):
             nrow, ncol = cls[(t + 1) % len(cls)]
             sig[col, row] = int(self.k_is[ncol]) * int(sub[nrow]) % P
-        self.constants_sigmas = np.concatenate([sel[None, :], consts, sig]).astype(np.uint64)
+        self.constants_sigmas = np.concatenate([sel[None, :], consts, sig]).astype(dt)
         self.sigma = sig
         self.num_partial_products = -(-cfg.num_routed_wires // cfg.max_quotient_degree_factor) - 1
         self.reduction_arity_bits = reduction_arity_bits(cfg, degree_bits)
@@ -83,26 +93,28 @@ class DummyCircuit:
 
     def set_cap(self, cap):
         """circuit_digest = hash_no_pad(cap.flatten() ++ hash_pad(domain_sep = []) ++ [degree_bits])"""
-        cap = np.asarray(cap, dtype=np.uint64)
+        F = self.F
+        cap = np.asarray(cap, dtype=F.dtype)
         self.constants_sigmas_cap = cap
-        dom = O.hash_no_pad(np.array([1, 0, 0, 0, 0, 0, 0, 1], dtype=np.uint64))  # hash_pad([]) (config.rs:58-66)
-        parts = np.concatenate([cap.ravel(), dom, np.array([self.degree_bits], dtype=np.uint64)])
-        self._digest = O.hash_no_pad(parts)
+        dom = F.hash_no_pad(np.array([1, 0, 0, 0, 0, 0, 0, 1], dtype=F.dtype))  # hash_pad([]) (config.rs:58-66), rate 8
+        parts = np.concatenate([cap.ravel(), dom, np.array([self.degree_bits], dtype=F.dtype)])
+        self._digest = F.hash_no_pad(parts)
         return self._digest
 
     @property
     def circuit_digest(self):
         if self._digest is None:
-            b = O.PolynomialBatch.from_values(self.constants_sigmas, self.cfg.rate_bits, self.cfg.cap_height)
+            b = self.F.mod.PolynomialBatch.from_values(self.constants_sigmas, self.cfg.rate_bits, self.cfg.cap_height)
             self.set_cap(b.cap)
         return self._digest
 
     def witness(self, seed=0):
-        """MatrixWitness wire_values[column][row]: zeros except the PublicInputGate row's wires 4..,
-        filled from SplitMix64 (stands in for RandomValueGenerator's F::rand(), SURVEY.md 8(d))."""
-        cfg = self.cfg
-        w = np.zeros((cfg.num_wires, self.n), dtype=np.uint64)
-        w[4:, self.pi_row] = O.splitmix64_fill(0x9E3779B97F4A7C15 + seed, cfg.num_wires - 4)
+        """MatrixWitness wire_values[column][row]: zeros except the PublicInputGate row's wires H..
+        (circuit_builder.rs:1065-1080), filled from SplitMix64 (stands in for RandomValueGenerator's F::rand(),
+        SURVEY.md 8(d))."""
+        cfg, H = self.cfg, self.F.hout
+        w = np.zeros((cfg.num_wires, self.n), dtype=self.F.dtype)
+        w[H:, self.pi_row] = self.F.fill(0x9E3779B97F4A7C15 + seed, cfg.num_wires - H)
         return w
 
     def common_data(self):
@@ -131,17 +143,18 @@ class DummyCircuit:
 def prove_cpu(circ, witness, public_inputs=()):
     """Run the CPU oracle prover; returns (proof_bytes, debug challenges)."""
     L = O.lib()
-    fn = L.gbo_gl_prove_dummy
+    F = circ.F
+    fn = getattr(L, F.prove_symbol)
     fn.restype = C.c_int
     c = circ.cfg.num_challenges
     cs = np.ascontiguousarray(circ.constants_sigmas)
-    wit = np.ascontiguousarray(witness, dtype=np.uint64)
-    pis = np.ascontiguousarray(list(public_inputs) or [0], dtype=np.uint64)
+    wit = np.ascontiguousarray(witness, dtype=F.dtype)
+    pis = np.ascontiguousarray(list(public_inputs) or [0], dtype=F.dtype)
     dig = np.ascontiguousarray(circ.circuit_digest)
     cap = 64 << 20
     out = np.zeros(cap, dtype=np.uint8)
     out_len = C.c_size_t()
-    dbg = np.zeros(3 * c + 5, dtype=np.uint64)
+    dbg = np.zeros(3 * c + 2 * F.D + 1, dtype=F.dtype)  # betas, gammas, alphas, zeta, fri_alpha, pow response
     rc = fn(circ.c_cfg(), cs.ctypes.data_as(C.c_void_p), dig.ctypes.data_as(C.c_void_p), circ.k_is.ctypes.data_as(C.c_void_p),
             wit.ctypes.data_as(C.c_void_p), pis.ctypes.data_as(C.c_void_p), C.c_size_t(len(public_inputs)),
             out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p))
@@ -154,7 +167,9 @@ def prove_cpu(circ, witness, public_inputs=()):
 def eval_vanishing_poly(circ, zeta, openings, pi_hash, betas, gammas, alphas):
     """plonk/vanishing_poly.rs:40-170 for the dummy gate set, at an extension point."""
     cfg = circ.cfg
-    e = V
+    e = circ.F
+    H = e.hout
+    one, zero = e.one, e.zero
     n = circ.n
     consts, wires, sig = openings["constants"], openings["wires"], openings["plonk_sigmas"]
     zs, zs_next, pps = openings["plonk_zs"], openings["plonk_zs_next"], openings["partial_products"]
@@ -162,9 +177,9 @@ def eval_vanishing_poly(circ, zeta, openings, pi_hash, betas, gammas, alphas):
     # gate constraints (filter * unfiltered; compute_filter gates/gate.rs:391-404)
     s = consts[0]
     gc = consts[1:]
-    cons = [(0, 0)] * 4
+    cons = [zero] * max(H, cfg.num_constants)
     for g in range(3):
-        f = (1, 0)
+        f = one
         for i in range(3):
             if i != g:
                 f = e.emul(f, e.esub(e.efrom(i), s))
@@ -172,30 +187,30 @@ def eval_vanishing_poly(circ, zeta, openings, pi_hash, betas, gammas, alphas):
             for j in range(cfg.num_constants):
                 cons[j] = e.eadd(cons[j], e.emul(f, e.esub(gc[j], wires[j])))
         elif g == circ.GATE_PI:
-            for j in range(4):
+            for j in range(H):
                 cons[j] = e.eadd(cons[j], e.emul(f, e.esub(wires[j], e.efrom(int(pi_hash[j])))))
     # eval_l_0 (plonk_common.rs:56-66)
     zn = e.epow(zeta, n)
-    if zeta == (1, 0):
-        l0 = (1, 0)
+    if zeta == one:
+        l0 = one
     else:
-        l0 = e.ediv(e.esub(zn, (1, 0)), e.emul(e.efrom(n), e.esub(zeta, (1, 0))))
+        l0 = e.ediv(e.esub(zn, one), e.emul(e.efrom(n), e.esub(zeta, one)))
     z1_terms, pp_terms = [], []
     for i in range(cfg.num_challenges):
-        z1_terms.append(e.emul(l0, e.esub(zs[i], (1, 0))))
+        z1_terms.append(e.emul(l0, e.esub(zs[i], one)))
         nums = [e.eadd(e.eadd(wires[j], e.emul(e.efrom(betas[i]), e.emul(e.efrom(int(circ.k_is[j])), zeta))), e.efrom(gammas[i]))
                 for j in range(cfg.num_routed_wires)]
         dens = [e.eadd(e.eadd(wires[j], e.emul(e.efrom(betas[i]), sig[j])), e.efrom(gammas[i])) for j in range(cfg.num_routed_wires)]
         accs = [zs[i]] + pps[i * num_prods:(i + 1) * num_prods] + [zs_next[i]]
         for m in range(num_prods + 1):
-            npd, dpd = (1, 0), (1, 0)
+            npd, dpd = one, one
             for j in range(m * qdf, min((m + 1) * qdf, cfg.num_routed_wires)):
                 npd, dpd = e.emul(npd, nums[j]), e.emul(dpd, dens[j])
             pp_terms.append(e.esub(e.emul(accs[m], npd), e.emul(accs[m + 1], dpd)))
     terms = z1_terms + pp_terms + cons
     out = []
     for a in alphas:
-        cum = (0, 0)
+        cum = zero
         for t in reversed(terms):
             cum = e.eadd(t, e.emul(cum, e.efrom(a)))
         out.append(cum)
@@ -205,23 +220,24 @@ def eval_vanishing_poly(circ, zeta, openings, pi_hash, betas, gammas, alphas):
 def verify(circ, proof_bytes, stats=None):
     """plonk/verifier.rs:17-128: transcript, vanishing identity at zeta, FRI.  Raises AssertionError."""
     cd = circ.common_data()
-    proof, pis = V.read_proof_with_pis(proof_bytes, cd)
+    F = circ.F
+    proof, pis = V.read_proof_with_pis(proof_bytes, cd, F)
     assert len(pis) == 0
-    ch = V.get_challenges(proof, pis, circ.circuit_digest, cd)
-    pi_hash = O.hash_no_pad(np.zeros(0, np.uint64))
+    ch = V.get_challenges(proof, pis, circ.circuit_digest, cd, F)
+    pi_hash = F.hash_no_pad(np.zeros(0, F.dtype))
     van = eval_vanishing_poly(circ, ch["plonk_zeta"], proof["openings"], pi_hash, ch["plonk_betas"], ch["plonk_gammas"],
                               ch["plonk_alphas"])
-    zeta_pow = V.epow(ch["plonk_zeta"], circ.n)
-    z_h = V.esub(zeta_pow, (1, 0))
+    zeta_pow = F.epow(ch["plonk_zeta"], circ.n)
+    z_h = F.esub(zeta_pow, F.one)
     q = proof["openings"]["quotient_polys"]
     qdf = circ.cfg.max_quotient_degree_factor
     for i in range(circ.cfg.num_challenges):
-        acc = (0, 0)
+        acc = F.zero
         for t in reversed(q[i * qdf:(i + 1) * qdf]):
-            acc = V.eadd(V.emul(acc, zeta_pow), t)
-        assert van[i] == V.emul(z_h, acc), "vanishing(zeta) != Z_H(zeta) * quotient(zeta) for challenge %d" % i
+            acc = F.eadd(F.emul(acc, zeta_pow), t)
+        assert van[i] == F.emul(z_h, acc), "vanishing(zeta) != Z_H(zeta) * quotient(zeta) for challenge %d" % i
     caps = [[[int(x) for x in h] for h in circ.constants_sigmas_cap], proof["wires_cap"], proof["zs_cap"], proof["quotient_cap"]]
-    V.verify_fri(proof, ch, caps, cd, stats)
+    V.verify_fri(proof, ch, caps, cd, stats, F)
     return True
 
 

@@ -1,0 +1,449 @@
+/* TEST ORACLE - field-generic body of the CPU restatement of the reference prover for the dummy circuit's
+ * gate set {NoopGate, ConstantGate, PublicInputGate}.  Included by prover_gl.c (Goldilocks, D = 2, Poseidon-12)
+ * and prover_bb.c (BabyBear, D = 4, Poseidon2-16) after they define the F_ / E_ / X_ macros.
+ *
+ * Test infrastructure only.  Follows, in order (paths relative to /root/reference/plonky2/src):
+ *   plonk/prover.rs:228-447      internal_prove_with_partition_witness
+ *   plonk/prover.rs:480-546      wires_permutation_partial_products_and_zs
+ *   plonk/prover.rs:712-926      compute_quotient_polys
+ *   plonk/vanishing_poly.rs:177-346 eval_vanishing_poly_base_batch, gates/gate.rs:188-215,391-404
+ *   plonk/proof.rs:346-440       OpeningSet::new / to_fri_openings
+ *   fri/oracle.rs:187-246        prove_openings
+ *   fri/prover.rs:22-255         fri_proof (commit phase, PoW with the MINIMUM nonce, queries)
+ *   util/serialization/mod.rs:2103-2151 proof byte layout
+ * Checked by oracle/verifier.py (pinned, for Goldilocks, by the reference's serialized regression proof).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef GBO_CIRCUIT_CFG_DEFINED
+#define GBO_CIRCUIT_CFG_DEFINED
+typedef struct {
+    unsigned num_wires, num_routed, num_constants /* const/sigma constants incl. selectors */, num_challenges;
+    unsigned rate_bits, cap_height, pow_bits, num_queries, arity_bits, final_poly_bits, quotient_degree_factor;
+    unsigned degree_bits;
+    unsigned num_selectors;      /* 1 */
+    unsigned gate_noop, gate_constant, gate_pi; /* indices in the sorted gate list (selector values) */
+    unsigned num_gate_consts;    /* ConstantGate num_consts */
+} gbo_circuit_cfg;
+#endif
+
+
+typedef struct {
+    size_t ncols;
+    unsigned log_n, rate_bits, cap_height;
+    F_T *coeffs, *leaves, *digests, *cap;
+} batch_t;
+
+static size_t rev_bits_sz(size_t x, unsigned bits) {
+    size_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+static int batch_commit(batch_t *b, const F_T *cols, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                        int is_coeffs) {
+    size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->coeffs = malloc(ncols * n * sizeof(F_T));
+    b->leaves = malloc(N * ncols * sizeof(F_T));
+    b->digests = malloc((2 * (N - ((size_t)1 << cap_height)) + 1) * HOUT * sizeof(F_T));
+    b->cap = malloc(((size_t)HOUT << cap_height) * sizeof(F_T));
+    if (!b->coeffs || !b->leaves || !b->digests || !b->cap) return -2;
+    return X_COMMIT(cols, ncols, log_n, rate_bits, cap_height, is_coeffs, NULL, b->coeffs, b->leaves, b->digests, b->cap);
+}
+static void batch_free(batch_t *b) { free(b->coeffs); free(b->leaves); free(b->digests); free(b->cap); }
+/* fri/oracle.rs:153-158 */
+static const F_T *batch_lde(const batch_t *b, size_t index, size_t step) {
+    unsigned bits = b->log_n + b->rate_bits;
+    return b->leaves + rev_bits_sz(index * step, bits) * b->ncols;
+}
+
+static E_T challenger_ext(challenger_t *c) { E_T r; for (int k = 0; k < D; k++) r.c[k] = X_CH_GET(c); return r; }
+
+typedef struct { uint8_t *p; size_t len, cap; } buf_t;
+static void put(buf_t *b, const void *src, size_t n) {
+    if (b->len + n <= b->cap) memcpy(b->p + b->len, src, n);
+    b->len += n;
+}
+static void put_u64(buf_t *b, uint64_t x) { put(b, &x, 8); }
+static void put_f(buf_t *b, F_T x) { put(b, &x, sizeof(F_T)); }
+static void put_u8(buf_t *b, uint8_t x) { put(b, &x, 1); }
+static void put_ext(buf_t *b, E_T x) { for (int k = 0; k < D; k++) put_f(b, x.c[k]); }
+
+/* poly eval of base coefficients at an extension point: p.to_extension().eval(z) (plonk/proof.rs:359-363) */
+static E_T eval_base_poly_ext(const F_T *c, size_t n, E_T z) {
+    E_T acc = E_FROM(0);
+    for (size_t i = n; i-- > 0;) acc = E_ADD(E_MUL(acc, z), E_FROM(c[i]));
+    return acc;
+}
+
+/* Status: 0 ok, 1 = InvZeroPermArg (plonk/prover.rs:512-514), 2 = opening point in subgroup, <0 internal */
+int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs][n] values*/,
+                       const F_T *circuit_digest, const F_T *k_is, const F_T *witness /*[num_wires][n]*/,
+                       const F_T *public_inputs, size_t num_public_inputs, uint8_t *out, size_t out_cap, size_t *out_len,
+                       F_T *debug_out /* optional: [betas c][gammas c][alphas c][zeta D][fri_alpha D][pow 1] */) {
+    const unsigned c = cfg->num_challenges, r = cfg->rate_bits, lg = cfg->degree_bits, capH = cfg->cap_height;
+    const size_t n = (size_t)1 << lg, N = n << r;
+    const unsigned lgN = lg + r;
+    const unsigned nw = cfg->num_wires, nr = cfg->num_routed, ncs = cfg->num_constants + nr;
+    const unsigned qdf = cfg->quotient_degree_factor;
+    const unsigned num_prods = (nr + qdf - 1) / qdf - 1; /* util/partial_products.rs:41-48 */
+    const unsigned nchunks = num_prods + 1;
+    if (((size_t)1 << r) != qdf) return -10; /* step = 1 case only (prover.rs:746-749) */
+    buf_t ob = {out, 0, out_cap};
+    int rc = 0;
+    F_T *qvals = NULL, *qchunks = NULL, *fc0 = NULL, *fc1 = NULL, *fri_caps = NULL;
+    E_T *final_poly = NULL, *values = NULL, *o_cs = NULL, *o_w = NULL, *o_z = NULL, *o_zn = NULL, *o_q = NULL;
+    F_T **tree_leaves = NULL, **tree_digests = NULL;
+    unsigned *tree_log = NULL;
+    unsigned narity = 0, arity_bits_list[32];
+
+    F_T pi_hash[HOUT];
+    X_HASH_NO_PAD(public_inputs, num_public_inputs, pi_hash); /* prover.rs:244 */
+
+    batch_t cs = {0}, wires = {0}, zs = {0}, quot = {0};
+    if ((rc = batch_commit(&cs, constants_sigmas, ncs, lg, r, capH, 0))) return rc;   /* circuit_builder.rs:1230-1239 */
+    if ((rc = batch_commit(&wires, witness, nw, lg, r, capH, 0))) return rc;          /* prover.rs:261-272 */
+
+    challenger_t ch;
+    X_CH_INIT(&ch);
+    X_CH_OBSERVE(&ch, circuit_digest, HOUT);
+    X_CH_OBSERVE(&ch, pi_hash, HOUT);
+    X_CH_OBSERVE(&ch, wires.cap, (size_t)HOUT << capH);
+    F_T *betas = malloc(c * sizeof(F_T)), *gammas = malloc(c * sizeof(F_T)), *alphas = malloc(c * sizeof(F_T));
+    for (unsigned i = 0; i < c; i++) betas[i] = X_CH_GET(&ch);
+    for (unsigned i = 0; i < c; i++) gammas[i] = X_CH_GET(&ch);
+
+    /* sigma values per row: ProverOnlyCircuitData.sigmas[row][j] = sigma_vecs[j][row] */
+    const F_T *sigma_cols = constants_sigmas + (size_t)cfg->num_constants * n;
+    F_T *subgroup = malloc(n * sizeof(F_T));
+    { F_T w = F_TWO_ADIC(lg), x = 1; for (size_t i = 0; i < n; i++) { subgroup[i] = x; x = F_MUL(x, w); } }
+
+    /* ---- prover.rs:480-546: Z and partial products.  zs_pp columns: [Z_0..Z_{c-1}, pp_{0,0..}, pp_{1,0..}, ...] */
+    const size_t nzs = (size_t)c * (1 + num_prods);
+    F_T *zs_vals = malloc(nzs * n * sizeof(F_T));
+    {
+        /* per-row chunk products in parallel (Rayon par_iter over the subgroup, prover.rs:497-528), then the
+         * sequential running product (:531-539) */
+        F_T *cp = malloc((size_t)nchunks * n * sizeof(F_T));
+        for (unsigned i = 0; i < c && !rc; i++) {
+            int bad = 0;
+#pragma omp parallel for schedule(static) reduction(|:bad)
+            for (size_t row = 0; row < n; row++) {
+                F_T x = subgroup[row];
+                F_T chunk_prod[64];
+                for (unsigned m = 0; m < nchunks; m++) chunk_prod[m] = 1;
+                for (unsigned j = 0; j < nr; j++) {
+                    F_T wv = witness[(size_t)j * n + row];
+                    F_T num = F_ADD(F_ADD(wv, F_MUL(betas[i], F_MUL(k_is[j], x))), gammas[i]);
+                    F_T den = F_ADD(F_ADD(wv, F_MUL(betas[i], sigma_cols[(size_t)j * n + row])), gammas[i]);
+                    if (den == 0) { bad = 1; den = 1; }
+                    F_T q = F_MUL(num, F_INV(den));
+                    chunk_prod[j / qdf] = F_MUL(chunk_prod[j / qdf], q);
+                }
+                for (unsigned m = 0; m < nchunks; m++) cp[(size_t)m * n + row] = chunk_prod[m];
+            }
+            if (bad) { rc = 1; break; }
+            /* partial_products_and_z_gx (util/partial_products.rs:29-38) then swap Z(gx) <-> Z(x) (:537-538) */
+            F_T z_x = 1;
+            F_T *Z = zs_vals + (size_t)i * n;
+            for (size_t row = 0; row < n; row++) {
+                F_T acc = z_x;
+                Z[row] = z_x;
+                for (unsigned m = 0; m < nchunks; m++) {
+                    acc = F_MUL(acc, cp[(size_t)m * n + row]);
+                    if (m < num_prods) zs_vals[((size_t)c + (size_t)i * num_prods + m) * n + row] = acc;
+                }
+                z_x = acc;
+            }
+        }
+        free(cp);
+    }
+    if (rc) goto done_early;
+    if ((rc = batch_commit(&zs, zs_vals, nzs, lg, r, capH, 0))) goto done_early;    /* prover.rs:328-339 */
+    X_CH_OBSERVE(&ch, zs.cap, (size_t)HOUT << capH);
+    for (unsigned i = 0; i < c; i++) alphas[i] = X_CH_GET(&ch);
+
+    /* ---- prover.rs:712-926 compute_quotient_polys: step = 1, next_step = 2^r, lde_size = N */
+    qvals = malloc((size_t)c * N * sizeof(F_T));
+    {
+        /* ZeroPolyOnCoset (field/src/zero_poly_coset.rs:22-62) */
+        F_T g_pow_n = F_POW(F_GENERATOR, n);
+        F_T zh[64], zh_inv[64];
+        F_T wr = F_TWO_ADIC(r), xr = 1;
+        for (unsigned i = 0; i < (1u << r); i++) { zh[i] = F_SUB(F_MUL(g_pow_n, xr), 1); zh_inv[i] = F_INV(zh[i]); xr = F_MUL(xr, wr); }
+        F_T wN = F_TWO_ADIC(lgN);
+        const unsigned nterms = c + c * nchunks + HOUT; /* z_1 terms, partial product terms, gate constraints (max = 4) */
+        const unsigned nsel = cfg->num_selectors;
+        /* Rayon par_chunks(BATCH_SIZE = 32) over the points (prover.rs:791-797) */
+#pragma omp parallel for schedule(static)
+        for (size_t i0 = 0; i0 < N; i0 += 32) {
+        F_T terms[256];
+        F_T pt = F_POW(wN, i0);
+        for (size_t i = i0; i < i0 + 32 && i < N; i++, pt = F_MUL(pt, wN)) {
+            F_T x = F_MUL(F_GENERATOR, pt); /* shifted_x */
+            size_t i_next = (i + ((size_t)1 << r)) % N;
+            const F_T *lcs = batch_lde(&cs, i, 1), *lw = batch_lde(&wires, i, 1), *lz = batch_lde(&zs, i, 1), *nz = batch_lde(&zs, i_next, 1);
+            const F_T *consts = lcs, *sig = lcs + cfg->num_constants;
+            unsigned t = 0;
+            /* eval_l_0 (zero_poly_coset.rs:58-61) */
+            F_T l0 = F_MUL(zh[i % (1u << r)], F_INV(F_MUL(F_FROM_U64(n), F_SUB(x, 1))));
+            for (unsigned k = 0; k < c; k++) terms[t++] = F_MUL(l0, F_SUB(lz[k], 1));
+            for (unsigned k = 0; k < c; k++) {
+                /* check_partial_products (util/partial_products.rs:53-77) */
+                for (unsigned m = 0; m < nchunks; m++) {
+                    F_T np = 1, dp = 1;
+                    for (unsigned j = m * qdf; j < nr && j < (m + 1) * qdf; j++) {
+                        np = F_MUL(np, F_ADD(F_ADD(lw[j], F_MUL(betas[k], F_MUL(k_is[j], x))), gammas[k]));
+                        dp = F_MUL(dp, F_ADD(F_ADD(lw[j], F_MUL(betas[k], sig[j])), gammas[k]));
+                    }
+                    F_T prev = m == 0 ? lz[k] : lz[c + k * num_prods + m - 1];
+                    F_T next = m == nchunks - 1 ? nz[k] : lz[c + k * num_prods + m];
+                    terms[t++] = F_SUB(F_MUL(prev, np), F_MUL(next, dp));
+                }
+            }
+            /* gate constraints (vanishing_poly.rs:741-774): filter * unfiltered, summed per constraint index */
+            {
+                F_T s = consts[0]; /* selector polynomial of the single group */
+                const F_T *gc = consts + nsel; /* remove_prefix(num_selectors) */
+                unsigned ng = 3;
+                F_T cons[HOUT] = {0, 0, 0, 0};
+                for (unsigned g = 0; g < ng; g++) {
+                    /* compute_filter (gates/gate.rs:391-404): prod_{i in group, i != g} (i - s); single selector => no UNUSED term */
+                    F_T f = 1;
+                    for (unsigned ii = 0; ii < ng; ii++) if (ii != g) f = F_MUL(f, F_SUB((F_T)ii, s));
+                    if (g == cfg->gate_constant)
+                        for (unsigned j = 0; j < cfg->num_gate_consts; j++) cons[j] = F_ADD(cons[j], F_MUL(f, F_SUB(gc[j], lw[j])));
+                    else if (g == cfg->gate_pi)
+                        for (unsigned j = 0; j < HOUT; j++) cons[j] = F_ADD(cons[j], F_MUL(f, F_SUB(lw[j], pi_hash[j])));
+                }
+                for (unsigned j = 0; j < HOUT; j++) terms[t++] = cons[j];
+            }
+            /* reduce_with_powers_multi (plonk_common.rs:105-122), then * 1/Z_H (prover.rs:909-916) */
+            for (unsigned k = 0; k < c; k++) {
+                F_T cum = 0;
+                for (unsigned tt = t; tt-- > 0;) cum = F_ADD(terms[tt], F_MUL(cum, alphas[k]));
+                qvals[(size_t)k * N + i] = F_MUL(cum, zh_inv[i % (1u << r)]);
+            }
+        }
+        }
+        if (nterms > 256) rc = -11;
+    }
+    /* coset_ifft (prover.rs:921-925), trim_to_len + chunks (:361-374): c * qdf chunk polys of n coefficients */
+    qchunks = malloc((size_t)c * qdf * n * sizeof(F_T));
+    for (unsigned k = 0; k < c; k++) {
+        X_COSET_IFFT(qvals + (size_t)k * N, lgN, F_GENERATOR);
+        memcpy(qchunks + (size_t)k * qdf * n, qvals + (size_t)k * N, (size_t)qdf * n * sizeof(F_T));
+    }
+    if ((rc = batch_commit(&quot, qchunks, (size_t)c * qdf, lg, r, capH, 1))) goto done;   /* prover.rs:376-387 */
+    X_CH_OBSERVE(&ch, quot.cap, (size_t)HOUT << capH);
+    E_T zeta = challenger_ext(&ch);
+    {
+        E_T zn = zeta;
+        for (unsigned i = 0; i < lg; i++) zn = E_MUL(zn, zn);
+        { int is_one = zn.c[0] == 1; for (int k = 1; k < D; k++) is_one &= zn.c[k] == 0; if (is_one) { rc = 2; goto done; } }
+    }
+    E_T g_ext = E_FROM(F_TWO_ADIC(lg));
+    E_T zeta_next = E_MUL(g_ext, zeta);
+
+    /* ---- OpeningSet::new (plonk/proof.rs:346-387) */
+    const size_t nq = (size_t)c * qdf;
+    o_cs = malloc(ncs * sizeof(E_T)); o_w = malloc(nw * sizeof(E_T)); o_z = malloc(nzs * sizeof(E_T));
+    o_zn = malloc(nzs * sizeof(E_T)); o_q = malloc(nq * sizeof(E_T));
+#pragma omp parallel for
+    for (size_t j = 0; j < ncs; j++) o_cs[j] = eval_base_poly_ext(cs.coeffs + j * n, n, zeta);
+#pragma omp parallel for
+    for (size_t j = 0; j < nw; j++) o_w[j] = eval_base_poly_ext(wires.coeffs + j * n, n, zeta);
+#pragma omp parallel for
+    for (size_t j = 0; j < nzs; j++) { o_z[j] = eval_base_poly_ext(zs.coeffs + j * n, n, zeta); o_zn[j] = eval_base_poly_ext(zs.coeffs + j * n, n, zeta_next); }
+#pragma omp parallel for
+    for (size_t j = 0; j < nq; j++) o_q[j] = eval_base_poly_ext(quot.coeffs + j * n, n, zeta);
+
+    /* proof bytes so far: caps + openings (serialization/mod.rs:2103-2118, 1514-1529) */
+    put(&ob, wires.cap, ((size_t)HOUT << capH) * sizeof(F_T));
+    put(&ob, zs.cap, ((size_t)HOUT << capH) * sizeof(F_T));
+    put(&ob, quot.cap, ((size_t)HOUT << capH) * sizeof(F_T));
+    for (size_t j = 0; j < cfg->num_constants; j++) put_ext(&ob, o_cs[j]);           /* constants */
+    for (size_t j = cfg->num_constants; j < ncs; j++) put_ext(&ob, o_cs[j]);         /* plonk_sigmas */
+    for (size_t j = 0; j < nw; j++) put_ext(&ob, o_w[j]);                            /* wires */
+    for (size_t j = 0; j < c; j++) put_ext(&ob, o_z[j]);                             /* plonk_zs */
+    for (size_t j = 0; j < c; j++) put_ext(&ob, o_zn[j]);                            /* plonk_zs_next */
+    /* lookup_zs, lookup_zs_next: empty */
+    for (size_t j = c; j < nzs; j++) put_ext(&ob, o_z[j]);                           /* partial_products */
+    for (size_t j = 0; j < nq; j++) put_ext(&ob, o_q[j]);                            /* quotient_polys */
+
+    /* observe_openings(to_fri_openings) (plonk/proof.rs:388-440, fri/challenges.rs:15-23) */
+    for (size_t j = 0; j < ncs; j++) X_CH_OBSERVE(&ch, o_cs[j].c, D);
+    for (size_t j = 0; j < nw; j++) X_CH_OBSERVE(&ch, o_w[j].c, D);
+    for (size_t j = 0; j < c; j++) X_CH_OBSERVE(&ch, o_z[j].c, D);
+    for (size_t j = c; j < nzs; j++) X_CH_OBSERVE(&ch, o_z[j].c, D);
+    for (size_t j = 0; j < nq; j++) X_CH_OBSERVE(&ch, o_q[j].c, D);
+    for (size_t j = 0; j < c; j++) X_CH_OBSERVE(&ch, o_zn[j].c, D);
+
+    /* ---- prove_openings (fri/oracle.rs:187-246) */
+    E_T fri_alpha = challenger_ext(&ch);
+    final_poly = calloc(N, sizeof(E_T)); /* lde(rate_bits): zero padded to N */
+    {
+        const batch_t *oracles[4] = {&cs, &wires, &zs, &quot};
+        const size_t counts[4] = {ncs, nw, nzs, nq};
+        E_T *comp = malloc(n * sizeof(E_T));
+        for (int batch = 0; batch < 2; batch++) {
+            /* reduce_polys_base (util/reducing.rs:89-103): sum_j alpha^j * poly_j, powers restart at 1 */
+            for (size_t t = 0; t < n; t++) comp[t] = E_FROM(0);
+            E_T ap = E_FROM(1);
+            size_t count = 0;
+            for (int o = 0; o < 4; o++) {
+                size_t lo = 0, hi = counts[o];
+                if (batch == 1) { if (o != 2) continue; hi = c; } /* fri_zs_polys: zs_range of oracle 2 (circuit_data.rs:760-767) */
+                for (size_t j = lo; j < hi; j++) {
+                    const F_T *p = oracles[o]->coeffs + j * n;
+                    for (size_t t = 0; t < n; t++) comp[t] = E_ADD(comp[t], E_SCALE(ap, p[t]));
+                    ap = E_MUL(ap, fri_alpha);
+                    count++;
+                }
+            }
+            /* divide_by_linear (field/src/polynomial/division.rs:75-88) + push zero */
+            E_T point = batch == 0 ? zeta : zeta_next;
+            E_T *q = malloc(n * sizeof(E_T));
+            E_T acc = E_FROM(0);
+            for (size_t t = n; t-- > 0;) { acc = E_ADD(E_MUL(acc, point), comp[t]); if (t > 0) q[t - 1] = acc; }
+            q[n - 1] = E_FROM(0);
+            /* alpha.shift_poly(&mut final_poly); final_poly += quotient (oracle.rs:222-223) */
+            E_T sh = E_POW(fri_alpha, count);
+            for (size_t t = 0; t < n; t++) final_poly[t] = E_ADD(E_MUL(final_poly[t], sh), q[t]);
+            free(q);
+        }
+        free(comp);
+    }
+    /* coset_fft in the extension field == base NTT on each coordinate (oracle.rs:226-231) */
+    fc0 = malloc((size_t)D * N * sizeof(F_T)); fc1 = NULL;
+    values = malloc(N * sizeof(E_T));
+    E_T *coeffs = final_poly;
+    size_t cur_len = N;
+    unsigned cur_lg = lgN;
+
+    /* ---- fri_committed_trees (fri/prover.rs:83-133) */
+    { /* ConstantArityBits (fri/reduction_strategies.rs:44-56) */
+        unsigned db = lg;
+        while (db > cfg->final_poly_bits && db + r >= capH + cfg->arity_bits) { arity_bits_list[narity++] = cfg->arity_bits; db -= cfg->arity_bits; }
+    }
+    tree_leaves = calloc(narity + 1, sizeof(F_T *)); tree_digests = calloc(narity + 1, sizeof(F_T *));
+    tree_log = calloc(narity + 1, sizeof(unsigned));
+    F_T shift = F_GENERATOR;
+    {
+        for (int k = 0; k < D; k++) {
+            for (size_t t = 0; t < N; t++) fc0[(size_t)k * N + t] = coeffs[t].c[k];
+            X_COSET_FFT(fc0 + (size_t)k * N, lgN, shift, 0);
+            for (size_t t = 0; t < N; t++) values[t].c[k] = fc0[(size_t)k * N + t];
+        }
+    }
+    fri_caps = malloc(narity * ((size_t)HOUT << capH) * sizeof(F_T) + 8);
+    for (unsigned li = 0; li < narity; li++) {
+        unsigned ab = arity_bits_list[li];
+        size_t arity = (size_t)1 << ab, nleaves = cur_len >> ab, width = arity * D;
+        F_T *lv = malloc(nleaves * width * sizeof(F_T));
+        /* reverse_index_bits_in_place(values); chunk by arity; flatten */
+        for (size_t i = 0; i < cur_len; i++) {
+            size_t src = rev_bits_sz(i, cur_lg);
+            for (int k = 0; k < D; k++) lv[i * D + k] = values[src].c[k];
+        }
+        F_T *dg = malloc((2 * (nleaves - ((size_t)1 << capH)) + 1) * HOUT * sizeof(F_T));
+        F_T *cap = fri_caps + li * ((size_t)HOUT << capH);
+        if ((rc = X_MERKLE_TREE(lv, cur_lg - ab, width, capH, dg, cap))) goto done;
+        tree_leaves[li] = lv; tree_digests[li] = dg; tree_log[li] = cur_lg - ab;
+        X_CH_OBSERVE(&ch, cap, (size_t)HOUT << capH);
+        E_T beta = challenger_ext(&ch);
+        /* fold: reduce_with_powers(chunk, beta) (plonk_common.rs:124-136) */
+        size_t new_len = cur_len >> ab;
+        for (size_t m = 0; m < new_len; m++) {
+            E_T s = E_FROM(0);
+            for (size_t t = arity; t-- > 0;) s = E_ADD(E_MUL(s, beta), coeffs[m * arity + t]);
+            coeffs[m] = s;
+        }
+        cur_len = new_len; cur_lg -= ab;
+        shift = F_POW(shift, arity);
+        for (int k = 0; k < D; k++) {
+            for (size_t t = 0; t < cur_len; t++) fc0[(size_t)k * cur_len + t] = coeffs[t].c[k];
+            X_COSET_FFT(fc0 + (size_t)k * cur_len, cur_lg, shift, 0);
+            for (size_t t = 0; t < cur_len; t++) values[t].c[k] = fc0[(size_t)k * cur_len + t];
+        }
+    }
+    size_t final_len = cur_len >> r;
+    for (size_t t = 0; t < final_len; t++) X_CH_OBSERVE(&ch, coeffs[t].c, D);
+
+    /* ---- fri_proof_of_work (fri/prover.rs:136-188): minimum nonce (== find_any with one thread) */
+    F_T pow_witness = 0;
+    {
+        unsigned min_lz = cfg->pow_bits + (64 - F_ORDER_BITS); /* fri/prover.rs:147 */
+        F_T st[SPONGE_W];
+        memcpy(st, ch.state, sizeof st);
+        for (int i = 0; i < ch.nin; i++) st[i] = ch.in[i];
+        int pos = ch.nin;
+        for (F_T cand = 0;; cand++) {
+            F_T s2[SPONGE_W];
+            memcpy(s2, st, sizeof s2);
+            s2[pos] = cand;
+            X_PERMUTE(s2, s2);
+            F_T resp = s2[7]; /* squeeze().last(): rate 8 */
+            unsigned lz = resp ? (unsigned)__builtin_clzll((unsigned long long)resp) : 64;
+            if (lz >= min_lz) { pow_witness = cand; break; }
+        }
+        X_CH_OBSERVE(&ch, &pow_witness, 1);
+        F_T resp = X_CH_GET(&ch);
+        unsigned lz = resp ? (unsigned)__builtin_clzll((unsigned long long)resp) : 64;
+        if (lz < min_lz) { rc = -20; goto done; }
+        if (debug_out) debug_out[3 * c + 2 * D] = resp;
+    }
+
+    /* FRI proof bytes (serialization/mod.rs:1679-1695): caps, query rounds, final poly, pow witness */
+    put(&ob, fri_caps, narity * ((size_t)HOUT << capH) * sizeof(F_T));
+    {
+        const batch_t *oracles[4] = {&cs, &wires, &zs, &quot};
+        F_T sib[64 * HOUT];
+        for (unsigned qi = 0; qi < cfg->num_queries; qi++) {
+            size_t x_index = (size_t)((uint64_t)X_CH_GET(&ch) % N);
+            for (int o = 0; o < 4; o++) {
+                const batch_t *b = oracles[o];
+                put(&ob, b->leaves + x_index * b->ncols, b->ncols * sizeof(F_T));
+                int ns = X_MERKLE_PROVE(b->digests, lgN, capH, x_index, sib);
+                put_u8(&ob, (uint8_t)ns);
+                put(&ob, sib, (size_t)ns * HOUT * sizeof(F_T));
+            }
+            size_t xi = x_index;
+            for (unsigned li = 0; li < narity; li++) {
+                unsigned ab = arity_bits_list[li];
+                size_t width = ((size_t)1 << ab) * D;
+                size_t leaf = xi >> ab;
+                put(&ob, tree_leaves[li] + leaf * width, width * sizeof(F_T));
+                int ns = X_MERKLE_PROVE(tree_digests[li], tree_log[li], capH, leaf, sib);
+                put_u8(&ob, (uint8_t)ns);
+                put(&ob, sib, (size_t)ns * HOUT * sizeof(F_T));
+                xi = leaf;
+            }
+        }
+    }
+    for (size_t t = 0; t < final_len; t++) put_ext(&ob, coeffs[t]);
+    put_f(&ob, pow_witness);
+    /* ProofWithPublicInputs (serialization/mod.rs:2134-2151) */
+    put_u64(&ob, num_public_inputs);
+    put(&ob, public_inputs, num_public_inputs * sizeof(F_T));
+    *out_len = ob.len;
+    if (ob.len > ob.cap) rc = -30;
+
+    if (debug_out) {
+        for (unsigned i = 0; i < c; i++) { debug_out[i] = betas[i]; debug_out[c + i] = gammas[i]; debug_out[2 * c + i] = alphas[i]; }
+        for (int k = 0; k < D; k++) { debug_out[3 * c + k] = zeta.c[k]; debug_out[3 * c + D + k] = fri_alpha.c[k]; }
+    }
+done:
+    if (tree_leaves) for (unsigned li = 0; li < narity; li++) { free(tree_leaves[li]); free(tree_digests[li]); }
+    free(tree_leaves); free(tree_digests); free(tree_log); free(fri_caps);
+    free(fc0); free(fc1); free(values);
+    free(o_cs); free(o_w); free(o_z); free(o_zn); free(o_q);
+    free(final_poly);
+    free(qvals); free(qchunks);
+done_early:
+    free(zs_vals); free(subgroup); free(betas); free(gammas); free(alphas);
+    batch_free(&cs); batch_free(&wires); batch_free(&zs); batch_free(&quot);
+    return rc;
+}

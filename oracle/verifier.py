@@ -18,63 +18,17 @@ import struct
 import numpy as np
 
 from . import oracle as O
+from .fields import BB, GL, Field  # noqa: F401
 
 P = O.GL_P
-W_EXT = 7
 SALT_SIZE = 4
 
-
-# ----------------------------------------------------------------------------- field helpers
-def fadd(a, b):
-    return (a + b) % P
-
-
-def fmul(a, b):
-    return (a * b) % P
-
-
-def finv(a):
-    return pow(a, P - 2, P)
-
-
-def eadd(a, b):
-    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
-
-
-def esub(a, b):
-    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
-
-
-def emul(a, b):
-    return ((a[0] * b[0] + W_EXT * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
-
-
-def einv(a):
-    n = (a[0] * a[0] - W_EXT * a[1] * a[1]) % P
-    ni = finv(n)
-    return (a[0] * ni % P, (-a[1]) * ni % P)
-
-
-def ediv(a, b):
-    return emul(a, einv(b))
-
-
-def epow(a, e):
-    r = (1, 0)
-    while e:
-        if e & 1:
-            r = emul(r, a)
-        a = emul(a, a)
-        e >>= 1
-    return r
-
-
-def efrom(x):
-    return (x % P, 0)
+# Goldilocks shorthands (the pinned field); every checker below takes F=GL|BB
+eadd, esub, emul, einv, ediv, epow, efrom = GL.eadd, GL.esub, GL.emul, GL.einv, GL.ediv, GL.epow, GL.efrom
 
 
 def two_adic_generator(bits):
-    return pow(1753635133440165772, 1 << (32 - bits), P)
+    return GL.two_adic_generator(bits)
 
 
 def reverse_bits(x, bits):
@@ -83,8 +37,8 @@ def reverse_bits(x, bits):
 
 # ----------------------------------------------------------------------------- byte reader
 class Reader:
-    def __init__(self, data):
-        self.d, self.o = memoryview(data), 0
+    def __init__(self, data, F=GL):
+        self.d, self.o, self.F = memoryview(data), 0, F
 
     def u8(self):
         v = self.d[self.o]
@@ -108,21 +62,21 @@ class Reader:
         return [self.usize() for _ in range(self.usize())]
 
     def field(self):
-        v = self.usize()
-        assert v < P, "non-canonical field element"
+        v = self.usize() if self.F.elem_bytes == 8 else self.u32()
+        assert v < self.F.P, "non-canonical field element"
         return v
 
     def field_vec(self, n):
         return [self.field() for _ in range(n)]
 
     def ext(self):
-        return (self.field(), self.field())
+        return tuple(self.field() for _ in range(self.F.D))
 
     def ext_vec(self, n):
         return [self.ext() for _ in range(n)]
 
     def hash(self):
-        return self.field_vec(4)
+        return self.field_vec(self.F.hout)
 
     def cap(self, h):
         return [self.hash() for _ in range(1 << h)]
@@ -146,9 +100,9 @@ def read_fri_config(r):
     return c
 
 
-def read_common_data(data):
+def read_common_data(data, F=GL):
     """CommonCircuitData up to (not including) the gate list - all the verifier restatement needs."""
-    r = Reader(data)
+    r = Reader(data, F)
     cfg = dict(num_wires=r.usize(), num_routed_wires=r.usize(), num_constants=r.usize(), security_bits=r.usize(),
                num_challenges=r.usize(), max_quotient_degree_factor=r.usize(), use_base_arithmetic_gate=r.bool(),
                zero_knowledge=r.bool())
@@ -167,16 +121,16 @@ def read_common_data(data):
     return cd
 
 
-def read_verifier_data(data):
-    r = Reader(data)
+def read_verifier_data(data, F=GL):
+    r = Reader(data, F)
     h = r.usize()
     vd = dict(constants_sigmas_cap=r.cap(h), circuit_digest=r.hash())
     assert r.done()
     return vd
 
 
-def read_proof_with_pis(data, cd):
-    r = Reader(data)
+def read_proof_with_pis(data, cd, F=GL):
+    r = Reader(data, F)
     cfg, fp = cd["config"], cd["fri_params"]
     ch = cfg["fri_config"]["cap_height"]
     c = cfg["num_challenges"]
@@ -207,12 +161,13 @@ def read_proof_with_pis(data, cd):
 
 
 # ----------------------------------------------------------------------------- writer (parity format)
-def write_proof_with_pis(pr, pis):
+def write_proof_with_pis(pr, pis, F=GL):
     """util/serialization/mod.rs:2103-2151 - the byte layout parity is judged on."""
     out = bytearray()
+    fmt = "<Q" if F.elem_bytes == 8 else "<I"
 
     def f(x):
-        out.extend(struct.pack("<Q", int(x)))
+        out.extend(struct.pack(fmt, int(x)))
 
     def fv(xs):
         for x in xs:
@@ -220,8 +175,7 @@ def write_proof_with_pis(pr, pis):
 
     def ev(xs):
         for x in xs:
-            f(x[0])
-            f(x[1])
+            fv(x)
 
     def cap(c):
         for h in c:
@@ -247,7 +201,7 @@ def write_proof_with_pis(pr, pis):
             ev(evals); mp(path)
     ev(fri["final_poly"])
     f(fri["pow_witness"])
-    f(len(pis))
+    out.extend(struct.pack("<Q", len(pis)))
     fv(pis)
     return bytes(out)
 
@@ -260,29 +214,29 @@ def fri_openings(o):
     return [zeta, nxt]
 
 
-def get_challenges(pr, pis, circuit_digest, cd):
+def get_challenges(pr, pis, circuit_digest, cd, F=GL):
     """plonk/get_challenges.rs:26-101 + fri/challenges.rs:24-68"""
     cfg = cd["config"]
     c = cfg["num_challenges"]
     assert cd["num_lookup_polys"] == 0, "lookups are out of scope"
-    ch = O.Challenger()
+    ch = F.Challenger()
     ch.observe_hash(circuit_digest)
-    ch.observe_hash(O.hash_no_pad(pis) if len(pis) else O.hash_no_pad(np.zeros(0, np.uint64)))
+    ch.observe_hash(F.hash_no_pad(np.asarray(pis, dtype=F.dtype)))
     ch.observe_cap(pr["wires_cap"])
     betas = ch.get_n_challenges(c)
     gammas = ch.get_n_challenges(c)
     ch.observe_cap(pr["zs_cap"])
     alphas = ch.get_n_challenges(c)
     ch.observe_cap(pr["quotient_cap"])
-    zeta = ch.get_extension_challenge()
+    zeta = ch.get_extension_challenge(F.D)
     for batch in fri_openings(pr["openings"]):
         ch.observe_elements([x for e in batch for x in e])
     fri = pr["opening_proof"]
-    fri_alpha = ch.get_extension_challenge()
+    fri_alpha = ch.get_extension_challenge(F.D)
     fri_betas = []
     for cap in fri["commit_phase_merkle_caps"]:
         ch.observe_cap(cap)
-        fri_betas.append(ch.get_extension_challenge())
+        fri_betas.append(ch.get_extension_challenge(F.D))
     ch.observe_elements([x for e in fri["final_poly"] for x in e])
     ch.observe_element(fri["pow_witness"])
     pow_response = ch.get_challenge()
@@ -292,7 +246,7 @@ def get_challenges(pr, pis, circuit_digest, cd):
                 fri_betas=fri_betas, fri_pow_response=pow_response, fri_query_indices=idx)
 
 
-def fri_instance(cd, zeta):
+def fri_instance(cd, zeta, F=GL):
     """plonk/circuit_data.rs:658-800: (oracle blinding flags, [(point, [(oracle, poly)])])"""
     cfg = cd["config"]
     c = cfg["num_challenges"]
@@ -301,96 +255,97 @@ def fri_instance(cd, zeta):
     n_q = c * cd["quotient_degree_factor"]
     all_polys = [(0, i) for i in range(n_pre)] + [(1, i) for i in range(cfg["num_wires"])] + \
                 [(2, i) for i in range(n_zs_pp)] + [(3, i) for i in range(n_q)]
-    g = two_adic_generator(cd["fri_params"]["degree_bits"])
-    zeta_next = emul(efrom(g), zeta)
+    g = F.two_adic_generator(cd["fri_params"]["degree_bits"])
+    zeta_next = F.emul(F.efrom(g), zeta)
     next_polys = [(2, i) for i in range(c)]
     blinding = [False, True, True, True]
     return blinding, [(zeta, all_polys), (zeta_next, next_polys)]
 
 
-def reduce_with_alpha(alpha, xs):
+def reduce_with_alpha(alpha, xs, F=GL):
     """util/reducing.rs:56-59 ReducingFactor::reduce (Horner from the back); returns (value, count)"""
-    acc = (0, 0)
+    acc = F.zero
     for x in reversed(xs):
-        acc = eadd(emul(alpha, acc), x)
+        acc = F.eadd(F.emul(alpha, acc), x)
     return acc, len(xs)
 
 
-def interpolate_eval(points, x):
+def interpolate_eval(points, x, F=GL):
     """Lagrange interpolation through `points` evaluated at x (== barycentric form of
     field/src/interpolation.rs used by fri/verifier.rs:23-49; exact arithmetic, same value)."""
-    total = (0, 0)
+    total = F.zero
     for i, (xi, yi) in enumerate(points):
-        num, den = (1, 0), (1, 0)
+        num, den = F.one, F.one
         for j, (xj, _) in enumerate(points):
             if i != j:
-                num = emul(num, esub(x, xj))
-                den = emul(den, esub(xi, xj))
-        total = eadd(total, emul(yi, ediv(num, den)))
+                num = F.emul(num, F.esub(x, xj))
+                den = F.emul(den, F.esub(xi, xj))
+        total = F.eadd(total, F.emul(yi, F.ediv(num, den)))
     return total
 
 
-def compute_evaluation(x, x_index_within_coset, arity_bits, evals, beta):
+def compute_evaluation(x, x_index_within_coset, arity_bits, evals, beta, F=GL):
     """fri/verifier.rs:23-49"""
     arity = 1 << arity_bits
-    g = two_adic_generator(arity_bits)
+    g = F.two_adic_generator(arity_bits)
     ev = [evals[reverse_bits(i, arity_bits)] for i in range(arity)]
     rev = reverse_bits(x_index_within_coset, arity_bits)
-    coset_start = fmul(x, pow(g, arity - rev, P))
-    pts = [(efrom(fmul(coset_start, pow(g, i, P))), ev[i]) for i in range(arity)]
-    return interpolate_eval(pts, beta)
+    coset_start = x * pow(g, arity - rev, F.P) % F.P
+    pts = [(F.efrom(coset_start * pow(g, i, F.P) % F.P), ev[i]) for i in range(arity)]
+    return interpolate_eval(pts, beta, F)
 
 
-def pow_ok(resp, bits):
-    """fri/verifier.rs:51-65: leading_zeros >= pow_bits + (64 - order.bits()) ; order.bits() = 64"""
+def pow_ok(resp, bits, F=GL):
+    """fri/verifier.rs:51-65: leading_zeros(u64) >= pow_bits + (64 - order.bits())"""
     lz = 64 - int(resp).bit_length()
-    return lz >= bits
+    return lz >= bits + (64 - F.order_bits)
 
 
-def verify_fri(pr, challenges, initial_caps, cd, stats=None):
+def verify_fri(pr, challenges, initial_caps, cd, stats=None, F=GL):
     """fri/verifier.rs:67-250.  Raises AssertionError on any failed check."""
     cfg, fp = cd["config"], cd["fri_params"]
+    P_ = F.P
     fri = pr["opening_proof"]
     log_n = fp["degree_bits"] + cfg["fri_config"]["rate_bits"]
-    assert pow_ok(challenges["fri_pow_response"], cfg["fri_config"]["proof_of_work_bits"]), "Invalid proof of work witness."
+    assert pow_ok(challenges["fri_pow_response"], cfg["fri_config"]["proof_of_work_bits"], F), "Invalid proof of work witness."
     assert len(fri["query_round_proofs"]) == cfg["fri_config"]["num_query_rounds"]
-    blinding, batches = fri_instance(cd, challenges["plonk_zeta"])
+    blinding, batches = fri_instance(cd, challenges["plonk_zeta"], F)
     alpha = challenges["fri_alpha"]
     openings = fri_openings(pr["openings"])
-    reduced_openings = [reduce_with_alpha(alpha, b)[0] for b in openings]
+    reduced_openings = [reduce_with_alpha(alpha, b, F)[0] for b in openings]
     n_paths = 0
     for x_index, rp in zip(challenges["fri_query_indices"], fri["query_round_proofs"]):
         for (vals, path), cap in zip(rp["initial_trees_proof"], initial_caps):
-            assert O.merkle_verify(vals, x_index, cap, path), "initial Merkle path"
+            assert F.merkle_verify(vals, x_index, cap, path), "initial Merkle path"
             n_paths += 1
-        subgroup_x = fmul(7, pow(two_adic_generator(log_n), reverse_bits(x_index, log_n), P))
+        subgroup_x = F.generator * pow(F.two_adic_generator(log_n), reverse_bits(x_index, log_n), P_) % P_
         # fri_combine_initial (fri/verifier.rs:121-165)
-        total, count = (0, 0), 0
+        total, count = F.zero, 0
         for (point, polys), red_open in zip(batches, reduced_openings):
             evs = []
             for (oi, pi) in polys:
                 vals = rp["initial_trees_proof"][oi][0]
                 salted = fp["hiding"] and blinding[oi]
                 unsalted = vals[: len(vals) - (SALT_SIZE if salted else 0)]
-                evs.append(efrom(unsalted[pi]))
-            red, count = reduce_with_alpha(alpha, evs)
-            total = emul(epow(alpha, count), total)  # alpha.shift(sum): count of THIS batch's reduce
-            total = eadd(total, ediv(esub(red, red_open), esub(efrom(subgroup_x), point)))
+                evs.append(F.efrom(unsalted[pi]))
+            red, count = reduce_with_alpha(alpha, evs, F)
+            total = F.emul(F.epow(alpha, count), total)  # alpha.shift(sum): count of THIS batch's reduce
+            total = F.eadd(total, F.ediv(F.esub(red, red_open), F.esub(F.efrom(subgroup_x), point)))
         old_eval = total
         xi = x_index
         for i, ab in enumerate(fp["reduction_arity_bits"]):
             evals, path = rp["steps"][i]
             coset_index, within = xi >> ab, xi & ((1 << ab) - 1)
             assert evals[within] == old_eval, "FRI consistency (layer %d)" % i
-            old_eval = compute_evaluation(subgroup_x, within, ab, evals, challenges["fri_betas"][i])
+            old_eval = compute_evaluation(subgroup_x, within, ab, evals, challenges["fri_betas"][i], F)
             flat = [x for e in evals for x in e]
-            assert O.merkle_verify(flat, coset_index, fri["commit_phase_merkle_caps"][i], path), "FRI layer Merkle path"
+            assert F.merkle_verify(flat, coset_index, fri["commit_phase_merkle_caps"][i], path), "FRI layer Merkle path"
             n_paths += 1
-            subgroup_x = pow(subgroup_x, 1 << ab, P)
+            subgroup_x = pow(subgroup_x, 1 << ab, P_)
             xi = coset_index
-        acc = (0, 0)
+        acc = F.zero
         for cf in reversed(fri["final_poly"]):
-            acc = eadd(emul(acc, efrom(subgroup_x)), cf)
+            acc = F.eadd(F.emul(acc, F.efrom(subgroup_x)), cf)
         assert acc == old_eval, "Final polynomial evaluation is invalid."
     if stats is not None:
         stats["merkle_paths"] = n_paths
