@@ -30,7 +30,7 @@ def sources():
 
 
 def _deps():
-    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".inc"))]
     hdr.append(os.path.join(os.path.dirname(HERE), "include", "goldibear_gpu.h"))
     return hdr
 

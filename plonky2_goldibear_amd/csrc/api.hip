@@ -65,7 +65,7 @@ struct gb_ctx {
     std::map<std::tuple<u32, u32, u64, int>, GlCosetSet> gl_cosets;  // by (log_n, rate_bits, shift, inverse)
     u32 *bb_tw4096_fwd = nullptr, *bb_tw4096_inv = nullptr;
     std::map<u32, BbTableSet> bb_tables;
-    std::map<std::pair<u32, u32>, BbCosetSet> bb_cosets;
+    std::map<std::tuple<u32, u32, u32, int>, BbCosetSet> bb_cosets;  // by (log_n, rate_bits, shift (Montgomery), inverse)
     std::multimap<size_t, void*> pool;                      // freed batch blocks by size (stream-ordered reuse)
     DeviceBuf scratch;                                      // grow-only workspace
     DeviceBuf small;                                        // small gather staging (rows, siblings)
@@ -279,8 +279,8 @@ gb_status bb_tables_for(gb_ctx* ctx, u32 log_n, const gbk::BbNttTables** out) {
     *out = &res.first->second.t;
     return GB_OK;
 }
-gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, const gbk::BbCosetTables** out) {
-    auto key = std::make_pair(log_n, rate_bits);
+gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u32 shift_mont, bool inverse, const gbk::BbCosetTables** out) {
+    auto key = std::make_tuple(log_n, rate_bits, shift_mont, inverse ? 1 : 0);
     auto it = ctx->bb_cosets.find(key);
     if (it != ctx->bb_cosets.end()) { *out = &it->second.t; return GB_OK; }
     size_t n = (size_t)1 << log_n;
@@ -289,7 +289,8 @@ gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, const gbk::BbCose
     u32 wN = bb::two_adic_generator(log_n + rate_bits);
     std::vector<u32> lo(nc * nlo), hi(nc * nhi);
     for (u32 c = 0; c < nc; c++) {
-        u32 s = bb::mul(bb::to_mont(bb::GENERATOR), bb::pow(wN, bitrev32(c, rate_bits)));
+        u32 s = bb::mul(shift_mont, bb::pow(wN, bitrev32(c, rate_bits)));
+        if (inverse) s = bb::inv(s);
         std::vector<u32> pl = bb_powers(s, nlo), ph = bb_powers(bb::pow(s, 4096), nhi);
         std::memcpy(&lo[c * nlo], pl.data(), nlo * sizeof(u32));
         std::memcpy(&hi[c * nhi], ph.data(), nhi * sizeof(u32));
@@ -305,6 +306,9 @@ gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, const gbk::BbCose
     *out = &res.first->second.t;
     return GB_OK;
 }
+
+// internal flag (not part of the C ABI): device input already in the field's device form (BabyBear: Montgomery)
+static constexpr uint32_t GB_INPUT_DEVICE_FORM = 0x100;
 
 inline size_t hout(u32 field) { return field == GB_GOLDILOCKS ? 4 : 8; }
 inline size_t esize(u32 field) { return field == GB_GOLDILOCKS ? 8 : 4; }
@@ -356,7 +360,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         const gbk::BbNttTables* bt;
         const gbk::BbCosetTables* bc;
         if ((s = bb_tables_for(ctx, log_n, &bt))) return cleanup(s);
-        if ((s = bb_cosets_for(ctx, log_n, rate_bits, &bc))) return cleanup(s);
+        if ((s = bb_cosets_for(ctx, log_n, rate_bits, bb::to_mont(bb::GENERATOR), false, &bc))) return cleanup(s);
         u32* coeffs = (u32*)b->coeffs;
         u32* lde = (u32*)b->lde;
         const size_t in_bytes = ncols * n * 4, scr_bytes = std::max(in_bytes, (size_t)nsalt * N * 4);
@@ -368,7 +372,12 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
             in_dev = scr;
         }
-        gbk::bb_to_mont(in_dev, coeffs, ncols * n, st);
+        if (flags & GB_INPUT_DEVICE_FORM) {  // prover-internal: already Montgomery words on the device
+            if (hipMemcpyAsync(coeffs, in_dev, in_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+        } else {
+            gbk::bb_to_mont(in_dev, coeffs, ncols * n, st);
+        }
         if (!is_coeffs) {
             Scope sc(ctx, "IFFT");
             gbk::bb_intt_columns(coeffs, coeffs, scr + scr_bytes / 4, ncols, *bt, st);
@@ -547,12 +556,12 @@ gb_status gb_ctx_scope_reset(gb_ctx* ctx) {
 
 gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                            uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
-    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, false, out);
+    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, false, out);
 }
 
 gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                            uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
-    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, true, out);
+    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, true, out);
 }
 
 gb_status gb_batch_free(gb_batch* b) {

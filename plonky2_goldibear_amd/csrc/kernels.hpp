@@ -5,10 +5,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
-namespace gbk {
+#include "field_traits.hpp"
 
-typedef unsigned long long u64;
-typedef unsigned int u32;
+namespace gbk {
 
 // ---------------------------------------------------------------- Goldilocks NTT / LDE (kernels_ntt.hip)
 
@@ -82,62 +81,93 @@ void bb_bitrev_copy_to_mont(const u32* src, u32* dst, u32 bits, size_t ncols, hi
 void bb_transpose_to_rows(const u32* cols, size_t col_stride, u32 width, u64 rows, u32* dst, hipStream_t stream);  // -> canonical
 
 // ---------------------------------------------------------------- prover (kernels_prover.hip)
+// Templated on the field traits of field_traits.hpp (GlF / BbF); element pointers are in the field's device form.
 
 static constexpr u32 MAX_CHUNKS = 32, MAX_CHALLENGES = 16, MAX_RATE = 16;
 
+template <class F>
 struct PowTab {      // base^e = lo[e & (2^lo_bits - 1)] * hi[e >> lo_bits]
-    const u64* lo;
-    const u64* hi;
+    const typename F::T* lo;
+    const typename F::T* hi;
     u32 lo_bits;
 };
-struct ExtPowTab {   // same for an extension-field base; entries are (c0, c1) pairs
-    const u64* lo;
-    const u64* hi;
+template <class F>
+struct ExtPowTab {   // same for an extension-field base
+    const typename F::E* lo;
+    const typename F::E* hi;
     u32 lo_bits;
 };
+template <class F>
 struct CosetPow {    // per coset c: shift_c^t = lo[c][t % nlo] * hi[c][t / nlo]
-    const u64* lo;
-    const u64* hi;
+    const typename F::T* lo;
+    const typename F::T* hi;
     u32 nlo, nhi;
 };
+template <class F>
 struct ZsParams {
     u32 log_n, num_routed, num_challenges, chunk /* quotient_degree_factor */, nchunks;
-    PowTab w_n;      // subgroup generator powers
+    PowTab<F> w_n;   // subgroup generator powers
 };
+template <class F>
 struct QuotientParams {
     u32 log_n, rate_bits, num_challenges, num_routed, num_constants /* selectors + constants */, num_selectors;
     u32 chunk, nchunks, nterms;
     u32 gate_constant, gate_pi, num_gate_consts;
-    PowTab w_N;      // LDE domain generator powers
+    PowTab<F> w_N;   // LDE domain generator powers
 };
+template <class F>
 struct PolyGroups {
-    const u64* ptr[4];
+    const typename F::T* ptr[4];
     u32 ncols[4];
     u32 ngroups;
 };
-struct PowState {
-    u64 s[12];
+template <class F>
+struct PowState {    // canonical sponge state before the candidate is written at `pos`
+    typename F::T s[F::SPONGE_W];
     u32 pos;
 };
 
-void gl_zs_partial_products(const ZsParams& p, const u64* witness, const u64* sigma, const u64* k_is, const u64* betas,
-                            const u64* gammas, u64* q_tmp, u64* zloc_tmp, u64* totals_tmp, u32* err, u64* out, hipStream_t st);
-void gl_quotient_values(const QuotientParams& p, const u64* cs, const u64* wires, const u64* zs, const u64* uniforms, u64* qv,
-                        hipStream_t st);
-void gl_quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const u64* a, const u64* mat, const CosetPow& inv_shift,
-                         u64* out, hipStream_t st);
-void gl_ext_pow_table(const ExtPowTab& z, size_t n, u64* table, hipStream_t st);
-void gl_eval_columns(const u64* coeffs, size_t ncols, size_t n, const u64* ztab, u64* partial_tmp, u64* out, hipStream_t st);
-void gl_reduce_polys(const PolyGroups& g, size_t n, const u64* apow, u64* comp, hipStream_t st);
-void gl_divide_by_linear_accumulate(const u64* comp, size_t n, const ExtPowTab& z, const ExtPowTab& zinv, const u64 shift[2],
-                                    int first, u64* sloc_tmp, u64* totals_tmp, u64* final_poly, hipStream_t st);
-void gl_ext_split(const u64* src, size_t n, u64* dst, hipStream_t st);
-void gl_fri_leaves(const u64* v0, const u64* v1, u32 arity_bits, u64 num_leaves, u64* out, hipStream_t st);
-void gl_fri_fold(const u64* in, size_t in_len, u32 arity_bits, const u64 beta[2], u64* out, hipStream_t st);
-void gl_pow_grind(const PowState& s, u64 start, u64 count, u32 min_lz, u64* result, hipStream_t st);
-void gl_gather_rows_multi(const u64* cols, size_t stride, u32 width, const u64* idx, u32 nidx, u64* rows, hipStream_t st);
-void gl_gather_fri_leaves(const u64* v0, const u64* v1, u32 arity_bits, const u64* idx, u32 nidx, u64* out, hipStream_t st);
-void gl_gather_siblings_multi(const u64* levels, u32 log_leaves, u32 cap_height, const u64* idx, u32 nidx, u64* out,
-                              hipStream_t st);
+template <class F>
+void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, const typename F::T* sigma, const typename F::T* k_is,
+                         const typename F::T* betas, const typename F::T* gammas, typename F::T* q_tmp, typename F::T* zloc_tmp,
+                         typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st);
+// false if (chunk, num_challenges) has no compiled specialisation (see quotient_shape_supported)
+template <class F>
+bool quotient_values(const QuotientParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* zs,
+                     const typename F::T* uniforms, typename F::T* qv, hipStream_t st);
+bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges);
+template <class F>
+void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typename F::T* a, const typename F::T* mat,
+                      const CosetPow<F>& inv_shift, typename F::T* out, hipStream_t st);
+template <class F>
+void ext_pow_table(const ExtPowTab<F>& z, size_t n, typename F::E* table, hipStream_t st);
+template <class F>
+void eval_columns(const typename F::T* coeffs, size_t ncols, size_t n, const typename F::E* ztab, typename F::E* partial_tmp,
+                  typename F::E* out, hipStream_t st);
+template <class F>
+void reduce_polys(const PolyGroups<F>& g, size_t n, const typename F::E* apow, typename F::E* comp, hipStream_t st);
+template <class F>
+void divide_by_linear_accumulate(const typename F::E* comp, size_t n, const ExtPowTab<F>& z, const ExtPowTab<F>& zinv,
+                                 typename F::E shift, int first, typename F::E* sloc_tmp, typename F::E* totals_tmp,
+                                 typename F::E* final_poly, hipStream_t st);
+template <class F>
+void ext_split(const typename F::E* src, size_t n, typename F::T* dst, hipStream_t st);
+// vals = [D][len] coordinate columns in leaf order
+template <class F>
+void fri_leaves(const typename F::T* vals, size_t len, u32 arity_bits, u64 num_leaves, typename F::T* out, hipStream_t st);
+template <class F>
+void fri_fold(const typename F::T* in, size_t in_len, u32 arity_bits, typename F::E beta, typename F::T* out, hipStream_t st);
+template <class F>
+void pow_grind(const PowState<F>& s, u64 start, u64 count, u32 min_lz, u64* result, hipStream_t st);
+// gathers write CANONICAL values
+template <class F>
+void gather_rows_multi(const typename F::T* cols, size_t stride, u32 width, const u64* idx, u32 nidx, typename F::T* rows,
+                       hipStream_t st);
+template <class F>
+void gather_fri_leaves(const typename F::T* vals, size_t len, u32 arity_bits, const u64* idx, u32 nidx, typename F::T* out,
+                       hipStream_t st);
+template <class F>
+void gather_siblings_multi(const typename F::T* levels, u32 log_leaves, u32 cap_height, const u64* idx, u32 nidx, typename F::T* out,
+                           hipStream_t st);
 
 }  // namespace gbk

@@ -1,4 +1,6 @@
-// Prover kernels for gfx950 (Goldilocks, D = 2): everything of prove() between the commitments.
+// Prover kernels for gfx950: everything of prove() between the commitments.  Written once against the field
+// traits of field_traits.hpp and instantiated for Goldilocks (D = 2, Poseidon-12, canonical u64) and BabyBear
+// (D = 4, Poseidon2-16, 32-bit Montgomery words).
 //
 //   k_zs_*          wires_permutation_partial_products_and_zs        plonk/prover.rs:480-546
 //   k_quotient      compute_quotient_polys + eval_vanishing_poly_base_batch for the gate set
@@ -9,140 +11,150 @@
 //   k_fri_*         fri_committed_trees fold + leaf hashing          fri/prover.rs:83-133
 //   k_pow_grind     fri_proof_of_work (minimum nonce)                fri/prover.rs:136-188
 //   k_gather_*      fri_prover_query_rounds                          fri/prover.rs:190-255
-// All data is column-major; LDE matrices are in leaf order (see kernels_ntt.hip).
+// All data is column-major; LDE matrices are in leaf order (see kernels_ntt.hip).  Element data is in the
+// field's device form (F::T); digests and everything gathered for the proof bytes are canonical.
 #include "kernels.hpp"
+#include "poseidon2_bb.hpp"
 #include "poseidon_gl.hpp"
 
 namespace gbk {
 
-using gl::ext2;
-
 __device__ __forceinline__ u32 brev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-__device__ __forceinline__ u64 pow_split(const PowTab& t, u64 e) {
-    u64 lo = t.lo[e & ((1u << t.lo_bits) - 1)];
+template <class F>
+__device__ __forceinline__ typename F::T pow_split(const PowTab<F>& t, u64 e) {
+    typename F::T lo = t.lo[e & ((1u << t.lo_bits) - 1)];
     u64 h = e >> t.lo_bits;
-    return h ? gl::mul(lo, t.hi[h]) : lo;
+    return h ? F::mul(lo, t.hi[h]) : lo;
 }
-__device__ __forceinline__ ext2 pow_split(const ExtPowTab& t, u64 e) {
-    const ext2* lo = reinterpret_cast<const ext2*>(t.lo);
-    const ext2* hi = reinterpret_cast<const ext2*>(t.hi);
-    ext2 l = lo[e & ((1u << t.lo_bits) - 1)];
+template <class F>
+__device__ __forceinline__ typename F::E pow_split(const ExtPowTab<F>& t, u64 e) {
+    typename F::E l = t.lo[e & ((1u << t.lo_bits) - 1)];
     u64 h = e >> t.lo_bits;
-    return h ? gl::mul(l, hi[h]) : l;
+    return h ? F::emul(l, t.hi[h]) : l;
 }
 
 // ------------------------------------------------------------------ Z and partial products
 
 // grid (ceil(n/256), c). q[ch][m][row] = prod_{j in chunk m} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)
-__global__ __launch_bounds__(256) void k_zs_quotients(ZsParams p, const u64* __restrict__ witness, const u64* __restrict__ sigma,
-                                                      const u64* __restrict__ k_is, const u64* __restrict__ betas,
-                                                      const u64* __restrict__ gammas, u64* __restrict__ q, u32* __restrict__ err) {
+template <class F>
+__global__ __launch_bounds__(256) void k_zs_quotients(ZsParams<F> p, const typename F::T* __restrict__ witness,
+                                                      const typename F::T* __restrict__ sigma, const typename F::T* __restrict__ k_is,
+                                                      const typename F::T* __restrict__ betas, const typename F::T* __restrict__ gammas,
+                                                      typename F::T* __restrict__ q, u32* __restrict__ err) {
+    typedef typename F::T T;
     const u32 row = blockIdx.x * 256 + threadIdx.x;
     const u32 ch = blockIdx.y;
     const size_t n = (size_t)1 << p.log_n;
     if (row >= n) return;
-    const u64 beta = betas[ch], gamma = gammas[ch];
-    const u64 bx = gl::mul(beta, pow_split(p.w_n, row));
-    u64 N[MAX_CHUNKS], Dn[MAX_CHUNKS];
+    const T beta = betas[ch], gamma = gammas[ch];
+    const T bx = F::mul(beta, pow_split(p.w_n, row));
+    T N[MAX_CHUNKS], Dn[MAX_CHUNKS];
     for (u32 m = 0; m < p.nchunks; m++) {
-        u64 np = 1, dp = 1;
+        T np = F::one(), dp = F::one();
         const u32 j1 = min((m + 1) * p.chunk, p.num_routed);
         for (u32 j = m * p.chunk; j < j1; j++) {
-            u64 w = witness[(size_t)j * n + row];
-            u64 num = gl::add(gl::add(w, gl::mul(bx, k_is[j])), gamma);
-            u64 den = gl::add(gl::add(w, gl::mul(beta, sigma[(size_t)j * n + row])), gamma);
-            np = gl::mul(np, num);
-            dp = gl::mul(dp, den);
+            T w = witness[(size_t)j * n + row];
+            T num = F::add(F::add(w, F::mul(bx, k_is[j])), gamma);
+            T den = F::add(F::add(w, F::mul(beta, sigma[(size_t)j * n + row])), gamma);
+            np = F::mul(np, num);
+            dp = F::mul(dp, den);
         }
         N[m] = np;
         Dn[m] = dp;
     }
     // Montgomery batch inversion of the chunk denominators
-    u64 pref[MAX_CHUNKS];
-    u64 acc = 1;
+    T pref[MAX_CHUNKS];
+    T acc = F::one();
     for (u32 m = 0; m < p.nchunks; m++) {
         pref[m] = acc;
-        acc = gl::mul(acc, Dn[m]);
+        acc = F::mul(acc, Dn[m]);
     }
-    if (acc == 0) {  // some denominator is zero: ProverError::InvZeroPermArg (prover.rs:512-514)
+    if (acc == F::zero()) {  // some denominator is zero: ProverError::InvZeroPermArg (prover.rs:512-514)
         atomicOr(err, 1u);
         return;
     }
-    u64 inv_run = gl::inv(acc);
+    T inv_run = F::inv(acc);
     for (u32 m = p.nchunks; m-- > 0;) {
-        u64 dinv = gl::mul(inv_run, pref[m]);
-        inv_run = gl::mul(inv_run, Dn[m]);
-        q[((size_t)ch * p.nchunks + m) * n + row] = gl::mul(N[m], dinv);
+        T dinv = F::mul(inv_run, pref[m]);
+        inv_run = F::mul(inv_run, Dn[m]);
+        q[((size_t)ch * p.nchunks + m) * n + row] = F::mul(N[m], dinv);
     }
 }
 
 // exclusive prefix product over rows of R(row) = prod_m q[ch][m][row], blocks of 1024 rows.
 // grid (ceil(n/1024), c): zloc[ch][row] = prod of R over earlier rows of the same block; totals[ch][block]
-__global__ __launch_bounds__(256) void k_zs_scan_local(ZsParams p, const u64* __restrict__ q, u64* __restrict__ zloc,
-                                                       u64* __restrict__ totals) {
-    __shared__ u64 sh[256];
+template <class F>
+__global__ __launch_bounds__(256) void k_zs_scan_local(ZsParams<F> p, const typename F::T* __restrict__ q,
+                                                       typename F::T* __restrict__ zloc, typename F::T* __restrict__ totals) {
+    typedef typename F::T T;
+    __shared__ T sh[256];
     const size_t n = (size_t)1 << p.log_n;
     const u32 ch = blockIdx.y;
     const size_t row0 = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    u64 r[4];
+    T r[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        u64 v = 1;
+        T v = F::one();
         if (row0 + k < n)
-            for (u32 m = 0; m < p.nchunks; m++) v = gl::mul(v, q[((size_t)ch * p.nchunks + m) * n + row0 + k]);
+            for (u32 m = 0; m < p.nchunks; m++) v = F::mul(v, q[((size_t)ch * p.nchunks + m) * n + row0 + k]);
         r[k] = v;
     }
-    u64 mine = gl::mul(gl::mul(r[0], r[1]), gl::mul(r[2], r[3]));
+    T mine = F::mul(F::mul(r[0], r[1]), F::mul(r[2], r[3]));
     sh[threadIdx.x] = mine;
     __syncthreads();
     for (u32 off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
-        u64 v = sh[threadIdx.x];
-        u64 o = threadIdx.x >= off ? sh[threadIdx.x - off] : 1;
+        T v = sh[threadIdx.x];
+        T o = threadIdx.x >= off ? sh[threadIdx.x - off] : F::one();
         __syncthreads();
-        sh[threadIdx.x] = gl::mul(v, o);
+        sh[threadIdx.x] = F::mul(v, o);
         __syncthreads();
     }
-    u64 excl = threadIdx.x ? sh[threadIdx.x - 1] : 1;
+    T excl = threadIdx.x ? sh[threadIdx.x - 1] : F::one();
     if (threadIdx.x == 255) totals[(size_t)ch * gridDim.x + blockIdx.x] = sh[255];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (row0 + k < n) zloc[(size_t)ch * n + row0 + k] = excl;
-        excl = gl::mul(excl, r[k]);
+        excl = F::mul(excl, r[k]);
     }
 }
 
 // grid (c), 1024 threads: totals[ch][b] <- exclusive prefix product (nblocks <= 1024)
-__global__ __launch_bounds__(1024) void k_zs_scan_totals(u64* __restrict__ totals, u32 nblocks) {
-    __shared__ u64 sh[1024];
-    u64* t = totals + (size_t)blockIdx.x * nblocks;
-    u64 mine = threadIdx.x < nblocks ? t[threadIdx.x] : 1;
+template <class F>
+__global__ __launch_bounds__(1024) void k_zs_scan_totals(typename F::T* __restrict__ totals, u32 nblocks) {
+    typedef typename F::T T;
+    __shared__ T sh[1024];
+    T* t = totals + (size_t)blockIdx.x * nblocks;
+    T mine = threadIdx.x < nblocks ? t[threadIdx.x] : F::one();
     sh[threadIdx.x] = mine;
     __syncthreads();
     for (u32 off = 1; off < 1024; off <<= 1) {
-        u64 v = sh[threadIdx.x];
-        u64 o = threadIdx.x >= off ? sh[threadIdx.x - off] : 1;
+        T v = sh[threadIdx.x];
+        T o = threadIdx.x >= off ? sh[threadIdx.x - off] : F::one();
         __syncthreads();
-        sh[threadIdx.x] = gl::mul(v, o);
+        sh[threadIdx.x] = F::mul(v, o);
         __syncthreads();
     }
-    if (threadIdx.x < nblocks) t[threadIdx.x] = threadIdx.x ? sh[threadIdx.x - 1] : 1;
+    if (threadIdx.x < nblocks) t[threadIdx.x] = threadIdx.x ? sh[threadIdx.x - 1] : F::one();
 }
 
 // grid (ceil(n/256), c): Z(row) = carry * zloc; partial products p_m = Z * q_0..q_m (m < num_prods)
 // output columns: [Z_0..Z_{c-1}, pp_{0,*}, pp_{1,*}, ...] (prover.rs:311-317)
-__global__ __launch_bounds__(256) void k_zs_finalize(ZsParams p, const u64* __restrict__ q, const u64* __restrict__ zloc,
-                                                     const u64* __restrict__ totals, u32 nblocks, u64* __restrict__ out) {
+template <class F>
+__global__ __launch_bounds__(256) void k_zs_finalize(ZsParams<F> p, const typename F::T* __restrict__ q,
+                                                     const typename F::T* __restrict__ zloc, const typename F::T* __restrict__ totals,
+                                                     u32 nblocks, typename F::T* __restrict__ out) {
+    typedef typename F::T T;
     const size_t n = (size_t)1 << p.log_n;
     const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
     const u32 ch = blockIdx.y;
     if (row >= n) return;
-    u64 z = gl::mul(totals[(size_t)ch * nblocks + (row >> 10)], zloc[(size_t)ch * n + row]);
+    T z = F::mul(totals[(size_t)ch * nblocks + (row >> 10)], zloc[(size_t)ch * n + row]);
     out[(size_t)ch * n + row] = z;
     const u32 num_prods = p.nchunks - 1;
-    u64 acc = z;
+    T acc = z;
     for (u32 m = 0; m < num_prods; m++) {
-        acc = gl::mul(acc, q[((size_t)ch * p.nchunks + m) * n + row]);
+        acc = F::mul(acc, q[((size_t)ch * p.nchunks + m) * n + row]);
         out[((size_t)p.num_challenges + (size_t)ch * num_prods + m) * n + row] = acc;
     }
 }
@@ -153,10 +165,11 @@ __global__ __launch_bounds__(256) void k_zs_finalize(ZsParams p, const u64* __re
 // qv[(k * R + coset) * n + il], il = natural index of the point inside its coset block.
 // C = num_challenges and CH = chunk size (quotient_degree_factor) are compile-time so that the per-challenge
 // accumulators stay in registers and a chunk's 2*CH loads are issued together.
-template <u32 C, u32 CH>
-__global__ __launch_bounds__(256) void k_quotient(QuotientParams p, const u64* __restrict__ cs, const u64* __restrict__ wires,
-                                                  const u64* __restrict__ zs, const u64* __restrict__ uni,
-                                                  u64* __restrict__ qv) {
+template <class F, u32 C, u32 CH>
+__global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typename F::T* __restrict__ cs,
+                                                  const typename F::T* __restrict__ wires, const typename F::T* __restrict__ zs,
+                                                  const typename F::T* __restrict__ uni, typename F::T* __restrict__ qv) {
+    typedef typename F::T T;
     const u32 lgn = p.log_n, r = p.rate_bits;
     const size_t n = (size_t)1 << lgn, N = n << r;
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -165,41 +178,41 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams p, const u64* _
     const u32 il = brev32(jl, lgn);
     const u32 imod = brev32(cidx, r);
     const u64 i = ((u64)il << r) | imod;
-    const u64 x = gl::mul(gl::GENERATOR, pow_split(p.w_N, i));  // shifted_x = 7 * w_N^i
+    const T x = F::mul(F::generator(), pow_split(p.w_N, i));  // shifted_x = g * w_N^i
     const size_t jn = ((size_t)cidx << lgn) | brev32((il + 1) & (u32)(n - 1), lgn);  // leaf of i + 2^r
 
-    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash 4]
+    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash H]
     const u32 nr = p.num_routed, nterms = p.nterms, R = 1u << r;
-    const u64* betas = uni;
-    const u64* gammas = uni + C;
-    const u64* bk = gammas + C;
-    const u64* apow = bk + (size_t)C * nr;
-    const u64* zh = apow + (size_t)C * nterms;
-    const u64* zh_inv = zh + R;
-    const u64* pi_hash = zh_inv + R;
+    const T* betas = uni;
+    const T* gammas = uni + C;
+    const T* bk = gammas + C;
+    const T* apow = bk + (size_t)C * nr;
+    const T* zh = apow + (size_t)C * nterms;
+    const T* zh_inv = zh + R;
+    const T* pi_hash = zh_inv + R;
 
-    u64 acc[C];
+    T acc[C];
 #pragma unroll
-    for (u32 k = 0; k < C; k++) acc[k] = 0;
+    for (u32 k = 0; k < C; k++) acc[k] = F::zero();
     u32 t = 0;
     // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61)
-    const u64 l0 = gl::mul(zh[imod], gl::inv(gl::mul((u64)(n % gl::P), gl::sub(x, 1))));
-    u64 zk[C];
+    const T l0 = F::mul(zh[imod], F::inv(F::mul(F::enc((u64)n), F::sub(x, F::one()))));
+    T zk[C];
 #pragma unroll
     for (u32 k = 0; k < C; k++) zk[k] = zs[(size_t)k * N + j];
 #pragma unroll
     for (u32 k = 0; k < C; k++, t++) {
-        u64 term = gl::mul(l0, gl::sub(zk[k], 1));
+        T term = F::mul(l0, F::sub(zk[k], F::one()));
 #pragma unroll
-        for (u32 k2 = 0; k2 < C; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + t]));
+        for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mul(term, apow[k2 * nterms + t]));
     }
     // partial-product checks (util/partial_products.rs:53-77); term index = C + k * nchunks + m
     const u32 num_prods = p.nchunks - 1;
-    u64 prev[C];
+    T prev[C];
 #pragma unroll
     for (u32 k = 0; k < C; k++) prev[k] = zk[k];
     for (u32 m = 0; m < p.nchunks; m++) {
-        u64 wv[CH], sg[CH];
+        T wv[CH], sg[CH];
         const u32 w0 = m * CH;
 #pragma unroll
         for (u32 q = 0; q < CH; q++) {
@@ -207,85 +220,89 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams p, const u64* _
             wv[q] = wires[(size_t)w * N + j];
             sg[q] = cs[(size_t)(p.num_constants + w) * N + j];
         }
-        u64 next[C];
+        T next[C];
 #pragma unroll
         for (u32 k = 0; k < C; k++)
             next[k] = m == num_prods ? zs[(size_t)k * N + jn] : zs[((size_t)C + (size_t)k * num_prods + m) * N + j];
-        u64 np[C], dp[C];
+        T np[C], dp[C];
 #pragma unroll
-        for (u32 k = 0; k < C; k++) np[k] = dp[k] = 1;
+        for (u32 k = 0; k < C; k++) np[k] = dp[k] = F::one();
 #pragma unroll
         for (u32 q = 0; q < CH; q++) {
             if (w0 + q < nr) {
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
-                    u64 num = gl::add(gl::add(wv[q], gl::mul(bk[k * nr + w0 + q], x)), gammas[k]);
-                    u64 den = gl::add(gl::add(wv[q], gl::mul(betas[k], sg[q])), gammas[k]);
-                    np[k] = gl::mul(np[k], num);
-                    dp[k] = gl::mul(dp[k], den);
+                    T num = F::add(F::add(wv[q], F::mul(bk[k * nr + w0 + q], x)), gammas[k]);
+                    T den = F::add(F::add(wv[q], F::mul(betas[k], sg[q])), gammas[k]);
+                    np[k] = F::mul(np[k], num);
+                    dp[k] = F::mul(dp[k], den);
                 }
             }
         }
 #pragma unroll
         for (u32 k = 0; k < C; k++) {
-            const u64 term = gl::sub(gl::mul(prev[k], np[k]), gl::mul(next[k], dp[k]));
+            const T term = F::sub(F::mul(prev[k], np[k]), F::mul(next[k], dp[k]));
             const u32 tt = C + k * p.nchunks + m;
 #pragma unroll
-            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + tt]));
+            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mul(term, apow[k2 * nterms + tt]));
             prev[k] = next[k];
         }
     }
     t = C + C * p.nchunks;
     // gate constraints: filter * unfiltered, summed per constraint index (vanishing_poly.rs:741-774,
     // gates/gate.rs:188-215,391-404).  One selector group {0,1,2}; no UNUSED factor (single selector).
+    // PublicInputGate<H> has H constraints, ConstantGate num_gate_consts <= H.
     {
-        const u64 s = cs[j];  // constants[0] = selector
-        u64 f[3];
+        const T s = cs[j];  // constants[0] = selector
+        T f[3];
 #pragma unroll
         for (u32 g = 0; g < 3; g++) {
-            u64 v = 1;
+            T v = F::one();
 #pragma unroll
             for (u32 ii = 0; ii < 3; ii++)
-                if (ii != g) v = gl::mul(v, gl::sub((u64)ii, s));
+                if (ii != g) v = F::mul(v, F::sub(F::enc(ii), s));
             f[g] = v;
         }
-        const u64 f_pi = p.gate_pi == 0 ? f[0] : (p.gate_pi == 1 ? f[1] : f[2]);
-        const u64 f_c = p.gate_constant == 0 ? f[0] : (p.gate_constant == 1 ? f[1] : f[2]);
+        const T f_pi = p.gate_pi == 0 ? f[0] : (p.gate_pi == 1 ? f[1] : f[2]);
+        const T f_c = p.gate_constant == 0 ? f[0] : (p.gate_constant == 1 ? f[1] : f[2]);
 #pragma unroll
-        for (u32 cj = 0; cj < 4; cj++, t++) {
-            const u64 wv = wires[(size_t)cj * N + j];
-            u64 term = gl::mul(f_pi, gl::sub(wv, pi_hash[cj]));
+        for (u32 cj = 0; cj < F::H; cj++, t++) {
+            const T wv = wires[(size_t)cj * N + j];
+            T term = F::mul(f_pi, F::sub(wv, pi_hash[cj]));
             if (cj < p.num_gate_consts) {
-                const u64 kc = cs[(size_t)(p.num_selectors + cj) * N + j];
-                term = gl::add(term, gl::mul(f_c, gl::sub(kc, wv)));
+                const T kc = cs[(size_t)(p.num_selectors + cj) * N + j];
+                term = F::add(term, F::mul(f_c, F::sub(kc, wv)));
             }
 #pragma unroll
-            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = gl::add(acc[k2], gl::mul(term, apow[k2 * nterms + t]));
+            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mul(term, apow[k2 * nterms + t]));
         }
     }
 #pragma unroll
-    for (u32 k = 0; k < C; k++) qv[(((size_t)k << r) + cidx) * n + il] = gl::mul(acc[k], zh_inv[imod]);
+    for (u32 k = 0; k < C; k++) qv[(((size_t)k << r) + cidx) * n + il] = F::mul(acc[k], zh_inv[imod]);
 }
 
 // After the per-block natural->natural inverse NTTs: a_c[t] are the coefficients of R_c(s_c X).
-// chunk_m[t] = 7^(-n m) / R * sum_c zeta_c^(-m) * s_c^(-t) * a_c[t]     (mat[m][c] holds the constant part)
-__global__ __launch_bounds__(256) void k_quotient_combine(u32 log_n, u32 rate_bits, const u64* __restrict__ a,
-                                                          const u64* __restrict__ mat, CosetPow inv_shift, u64* __restrict__ out) {
+// chunk_m[t] = g^(-n m) / R * sum_c zeta_c^(-m) * s_c^(-t) * a_c[t]     (mat[m][c] holds the constant part)
+template <class F>
+__global__ __launch_bounds__(256) void k_quotient_combine(u32 log_n, u32 rate_bits, const typename F::T* __restrict__ a,
+                                                          const typename F::T* __restrict__ mat, CosetPow<F> inv_shift,
+                                                          typename F::T* __restrict__ out) {
+    typedef typename F::T T;
     const size_t n = (size_t)1 << log_n;
     const u32 R = 1u << rate_bits;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const u32 k = blockIdx.y;
     if (t >= n) return;
-    u64 v[MAX_RATE];
+    T v[MAX_RATE];
     for (u32 c = 0; c < R; c++) {
-        u64 s = inv_shift.lo[(size_t)c * inv_shift.nlo + (t & (inv_shift.nlo - 1))];
+        T s = inv_shift.lo[(size_t)c * inv_shift.nlo + (t & (inv_shift.nlo - 1))];
         size_t h = t / inv_shift.nlo;
-        if (h) s = gl::mul(s, inv_shift.hi[(size_t)c * inv_shift.nhi + h]);
-        v[c] = gl::mul(a[((size_t)k * R + c) * n + t], s);
+        if (h) s = F::mul(s, inv_shift.hi[(size_t)c * inv_shift.nhi + h]);
+        v[c] = F::mul(a[((size_t)k * R + c) * n + t], s);
     }
     for (u32 m = 0; m < R; m++) {
-        u64 acc = 0;
-        for (u32 c = 0; c < R; c++) acc = gl::add(acc, gl::mul(v[c], mat[m * R + c]));
+        T acc = F::zero();
+        for (u32 c = 0; c < R; c++) acc = F::add(acc, F::mul(v[c], mat[m * R + c]));
         out[((size_t)k * R + m) * n + t] = acc;
     }
 }
@@ -293,329 +310,433 @@ __global__ __launch_bounds__(256) void k_quotient_combine(u32 log_n, u32 rate_bi
 // ------------------------------------------------------------------ openings: sum_t c_t z^t
 
 // table[t] = z^t, t < n
-__global__ __launch_bounds__(256) void k_ext_pow_table(ExtPowTab z, size_t n, ext2* __restrict__ table) {
+template <class F>
+__global__ __launch_bounds__(256) void k_ext_pow_table(ExtPowTab<F> z, size_t n, typename F::E* __restrict__ table) {
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t < n) table[t] = pow_split(z, t);
 }
 
-__device__ __forceinline__ ext2 block_reduce_add(ext2 v, ext2* sh) {
+template <class F>
+__device__ __forceinline__ typename F::E block_reduce_add(typename F::E v, typename F::E* sh) {
     sh[threadIdx.x] = v;
     __syncthreads();
     for (u32 off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) sh[threadIdx.x] = gl::add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        if (threadIdx.x < off) sh[threadIdx.x] = F::eadd(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
     }
-    ext2 r = sh[0];
+    typename F::E r = sh[0];
     __syncthreads();
     return r;
 }
 
 // grid (nchunks = ceil(n / 4096), ncols): partial[col][chunk] = sum over the chunk of c_t * z^t
-__global__ __launch_bounds__(256) void k_eval_partial(const u64* __restrict__ coeffs, size_t n, const ext2* __restrict__ ztab,
-                                                      ext2* __restrict__ partial) {
-    __shared__ ext2 sh[256];
-    const u64* c = coeffs + (size_t)blockIdx.y * n;
+template <class F>
+__global__ __launch_bounds__(256) void k_eval_partial(const typename F::T* __restrict__ coeffs, size_t n,
+                                                      const typename F::E* __restrict__ ztab, typename F::E* __restrict__ partial) {
+    typedef typename F::E E;
+    __shared__ E sh[256];
+    const typename F::T* c = coeffs + (size_t)blockIdx.y * n;
     const size_t base = (size_t)blockIdx.x * 4096;
-    ext2 acc = gl::e2(0);
+    E acc = F::ezero();
     for (u32 k = 0; k < 16; k++) {
         size_t t = base + k * 256 + threadIdx.x;
-        if (t < n) acc = gl::add(acc, gl::scale(ztab[t], c[t]));
+        if (t < n) acc = F::eadd(acc, F::escale(ztab[t], c[t]));
     }
-    ext2 r = block_reduce_add(acc, sh);
+    E r = block_reduce_add<F>(acc, sh);
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 // grid (ncols): out[col] = sum of partial[col][*]
-__global__ __launch_bounds__(256) void k_eval_final(const ext2* __restrict__ partial, u32 nchunks, ext2* __restrict__ out) {
-    __shared__ ext2 sh[256];
-    ext2 acc = gl::e2(0);
-    for (u32 k = threadIdx.x; k < nchunks; k += 256) acc = gl::add(acc, partial[(size_t)blockIdx.x * nchunks + k]);
-    ext2 r = block_reduce_add(acc, sh);
+template <class F>
+__global__ __launch_bounds__(256) void k_eval_final(const typename F::E* __restrict__ partial, u32 nchunks,
+                                                    typename F::E* __restrict__ out) {
+    typedef typename F::E E;
+    __shared__ E sh[256];
+    E acc = F::ezero();
+    for (u32 k = threadIdx.x; k < nchunks; k += 256) acc = F::eadd(acc, partial[(size_t)blockIdx.x * nchunks + k]);
+    E r = block_reduce_add<F>(acc, sh);
     if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
 // ------------------------------------------------------------------ prove_openings
 
 // comp[t] = sum_j alpha^j * poly_j[t]  (reduce_polys_base, util/reducing.rs:89-103) over up to 4 column groups
-__global__ __launch_bounds__(256) void k_reduce_polys(PolyGroups g, size_t n, const ext2* __restrict__ apow, ext2* __restrict__ comp) {
+template <class F>
+__global__ __launch_bounds__(256) void k_reduce_polys(PolyGroups<F> g, size_t n, const typename F::E* __restrict__ apow,
+                                                      typename F::E* __restrict__ comp) {
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    ext2 acc = gl::e2(0);
+    typename F::E acc = F::ezero();
     u32 jj = 0;
     for (u32 o = 0; o < g.ngroups; o++) {
-        const u64* base = g.ptr[o];
-        for (u32 j = 0; j < g.ncols[o]; j++, jj++) acc = gl::add(acc, gl::scale(apow[jj], base[(size_t)j * n + t]));
+        const typename F::T* base = g.ptr[o];
+        for (u32 j = 0; j < g.ncols[o]; j++, jj++) acc = F::eadd(acc, F::escale(apow[jj], base[(size_t)j * n + t]));
     }
     comp[t] = acc;
 }
 
 // divide_by_linear (polynomial/division.rs:75-88): q[t] = sum_{u > t} c_u z^(u-t-1) = z^-(t+1) * S_{t+1},
 // S_t = sum_{u >= t} c_u z^u.  Step 1: w_u = c_u z^u and block-local suffix sums (blocks of 1024).
-__global__ __launch_bounds__(256) void k_divide_local(const ext2* __restrict__ comp, size_t n, ExtPowTab z, ext2* __restrict__ sloc,
-                                                      ext2* __restrict__ totals) {
-    __shared__ ext2 sh[256];
+template <class F>
+__global__ __launch_bounds__(256) void k_divide_local(const typename F::E* __restrict__ comp, size_t n, ExtPowTab<F> z,
+                                                      typename F::E* __restrict__ sloc, typename F::E* __restrict__ totals) {
+    typedef typename F::E E;
+    __shared__ E sh[256];
     const size_t u0 = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    ext2 w[4];
+    E w[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) w[k] = u0 + k < n ? gl::mul(comp[u0 + k], pow_split(z, u0 + k)) : gl::e2(0);
-    ext2 mine = gl::add(gl::add(w[0], w[1]), gl::add(w[2], w[3]));
+    for (int k = 0; k < 4; k++) w[k] = u0 + k < n ? F::emul(comp[u0 + k], pow_split(z, u0 + k)) : F::ezero();
+    E mine = F::eadd(F::eadd(w[0], w[1]), F::eadd(w[2], w[3]));
     sh[threadIdx.x] = mine;
     __syncthreads();
     for (u32 off = 1; off < 256; off <<= 1) {  // inclusive SUFFIX scan
-        ext2 v = sh[threadIdx.x];
-        ext2 o = threadIdx.x + off < 256 ? sh[threadIdx.x + off] : gl::e2(0);
+        E v = sh[threadIdx.x];
+        E o = threadIdx.x + off < 256 ? sh[threadIdx.x + off] : F::ezero();
         __syncthreads();
-        sh[threadIdx.x] = gl::add(v, o);
+        sh[threadIdx.x] = F::eadd(v, o);
         __syncthreads();
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = sh[0];
-    ext2 run = threadIdx.x + 1 < 256 ? sh[threadIdx.x + 1] : gl::e2(0);  // sum of later threads in this block
+    E run = threadIdx.x + 1 < 256 ? sh[threadIdx.x + 1] : F::ezero();  // sum of later threads in this block
 #pragma unroll
     for (int k = 3; k >= 0; k--) {
-        run = gl::add(run, w[k]);
+        run = F::eadd(run, w[k]);
         if (u0 + k < n) sloc[u0 + k] = run;  // local S_t (this block only)
     }
 }
 // single block, 1024 threads: totals[b] <- sum of totals of LATER blocks (exclusive suffix)
-__global__ __launch_bounds__(1024) void k_divide_totals(ext2* __restrict__ totals, u32 nblocks) {
-    __shared__ ext2 sh[1024];
-    sh[threadIdx.x] = threadIdx.x < nblocks ? totals[threadIdx.x] : gl::e2(0);
+template <class F>
+__global__ __launch_bounds__(1024) void k_divide_totals(typename F::E* __restrict__ totals, u32 nblocks) {
+    typedef typename F::E E;
+    __shared__ E sh[1024];
+    sh[threadIdx.x] = threadIdx.x < nblocks ? totals[threadIdx.x] : F::ezero();
     __syncthreads();
     for (u32 off = 1; off < 1024; off <<= 1) {
-        ext2 v = sh[threadIdx.x];
-        ext2 o = threadIdx.x + off < 1024 ? sh[threadIdx.x + off] : gl::e2(0);
+        E v = sh[threadIdx.x];
+        E o = threadIdx.x + off < 1024 ? sh[threadIdx.x + off] : F::ezero();
         __syncthreads();
-        sh[threadIdx.x] = gl::add(v, o);
+        sh[threadIdx.x] = F::eadd(v, o);
         __syncthreads();
     }
-    if (threadIdx.x < nblocks) totals[threadIdx.x] = threadIdx.x + 1 < 1024 ? sh[threadIdx.x + 1] : gl::e2(0);
+    if (threadIdx.x < nblocks) totals[threadIdx.x] = threadIdx.x + 1 < 1024 ? sh[threadIdx.x + 1] : F::ezero();
 }
 // final[t] = final[t] * shift + q[t], q[t] = zinv^(t+1) * S_{t+1}, q[n-1] = 0   (fri/oracle.rs:218-223)
-__global__ __launch_bounds__(256) void k_divide_apply(const ext2* __restrict__ sloc, const ext2* __restrict__ totals, size_t n,
-                                                      ExtPowTab zinv, ext2 shift, int first, ext2* __restrict__ final_poly) {
+template <class F>
+__global__ __launch_bounds__(256) void k_divide_apply(const typename F::E* __restrict__ sloc, const typename F::E* __restrict__ totals,
+                                                      size_t n, ExtPowTab<F> zinv, typename F::E shift, int first,
+                                                      typename F::E* __restrict__ final_poly) {
+    typedef typename F::E E;
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    ext2 q = gl::e2(0);
+    E q = F::ezero();
     if (t + 1 < n) {
         size_t u = t + 1;
-        ext2 S = gl::add(sloc[u], totals[u >> 10]);
-        q = gl::mul(S, pow_split(zinv, u));
+        E S = F::eadd(sloc[u], totals[u >> 10]);
+        q = F::emul(S, pow_split(zinv, u));
     }
-    final_poly[t] = first ? q : gl::add(gl::mul(final_poly[t], shift), q);
+    final_poly[t] = first ? q : F::eadd(F::emul(final_poly[t], shift), q);
 }
-// split an ext2 array into two base columns [2][n] (for the coordinate-wise NTT)
-__global__ __launch_bounds__(256) void k_ext_split(const ext2* __restrict__ src, size_t n, u64* __restrict__ dst) {
+// split an extension array into D base columns [D][n] (for the coordinate-wise NTT)
+template <class F>
+__global__ __launch_bounds__(256) void k_ext_split(const typename F::E* __restrict__ src, size_t n, typename F::T* __restrict__ dst) {
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    ext2 v = src[t];
-    dst[t] = v.c0;
-    dst[n + t] = v.c1;
+    typename F::E v = src[t];
+#pragma unroll
+    for (u32 k = 0; k < F::D; k++) dst[(size_t)k * n + t] = F::coord(v, k);
 }
 
 // ------------------------------------------------------------------ FRI
 
-// leaf m = flatten(values[arity*m .. arity*(m+1))) in bit-reversed (= leaf) order (fri/prover.rs:101-107)
-__global__ __launch_bounds__(256) void k_fri_leaves(const u64* __restrict__ v0, const u64* __restrict__ v1, u32 arity_bits,
-                                                    u64 num_leaves, u64* __restrict__ out) {
+// Sponge over the field's permutation, rate 8, fed with DEVICE-form elements; out() gives canonical words.
+template <class F>
+struct Sponge;
+template <>
+struct Sponge<GlF> {
+    u64 s[12];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = 0;
+    }
+    __device__ __forceinline__ void permute() { poseidon_gl::permute_lazy(s); }
+    __device__ __forceinline__ u64 out(int i) { return poseidon_gl::to_canonical(s[i]); }
+    __device__ __forceinline__ void set_canonical(int i, u64 v) { s[i] = v; }
+};
+template <>
+struct Sponge<BbF> {
+    u32 s[16];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = 0;
+    }
+    __device__ __forceinline__ void permute() { poseidon2_bb::permute(s); }
+    __device__ __forceinline__ u32 out(int i) { return bb::from_mont(s[i]); }
+    __device__ __forceinline__ void set_canonical(int i, u32 v) { s[i] = bb::to_mont(v); }
+};
+
+// leaf m = flatten(values[arity*m .. arity*(m+1))) in bit-reversed (= leaf) order (fri/prover.rs:101-107);
+// vals = [D][len] coordinate columns, out = H canonical words per leaf.
+template <class F>
+__global__ __launch_bounds__(256) void k_fri_leaves(const typename F::T* __restrict__ vals, size_t len, u32 arity_bits,
+                                                    u64 num_leaves, typename F::T* __restrict__ out) {
+    typedef typename F::T T;
+    constexpr u32 D = F::D, H = F::H, PER = 8 / D;  // extension elements per absorption of 8 base elements
     u64 m = (u64)blockIdx.x * 256 + threadIdx.x;
     if (m >= num_leaves) return;
     const u32 arity = 1u << arity_bits;
-    const u64* a = v0 + (m << arity_bits);
-    const u64* b = v1 + (m << arity_bits);
-    u64 s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = 0;
-    if (2 * arity <= 4) {  // hash_or_noop
-        for (u32 k = 0; k < arity; k++) {
-            s[2 * k] = a[k];
-            s[2 * k + 1] = b[k];
-        }
-    } else {
-        for (u32 k0 = 0; k0 < arity; k0 += 4) {  // 8 base elements per absorption
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (k0 + k < arity) {
-                    s[2 * k] = a[k0 + k];
-                    s[2 * k + 1] = b[k0 + k];
-                }
-            poseidon_gl::permute_lazy(s);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) s[i] = poseidon_gl::to_canonical(s[i]);
+    const T* a = vals + (m << arity_bits);
+    T* o = out + (size_t)H * m;
+    if (D * arity <= H) {  // hash_or_noop (plonk/config.rs:70-84)
+        for (u32 i = 0; i < H; i++) o[i] = 0;
+        for (u32 k = 0; k < arity; k++)
+            for (u32 d = 0; d < D; d++) o[D * k + d] = (T)F::dec(a[(size_t)d * len + k]);
+        return;
     }
-    u64* o = out + 4 * m;
-    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+    Sponge<F> sp;
+    sp.init();
+    for (u32 k0 = 0; k0 < arity; k0 += PER) {
+#pragma unroll
+        for (u32 k = 0; k < PER; k++)
+            if (k0 + k < arity) {
+#pragma unroll
+                for (u32 d = 0; d < D; d++) sp.s[D * k + d] = a[(size_t)d * len + k0 + k];
+            }
+        sp.permute();
+    }
+#pragma unroll
+    for (u32 i = 0; i < H; i++) o[i] = sp.out(i);
 }
 
-// coeffs' [m] = sum_t coeffs[arity*m + t] beta^t  (reduce_with_powers, fri/prover.rs:112-121); in/out as [2][len] columns
-__global__ __launch_bounds__(256) void k_fri_fold(const u64* __restrict__ in, size_t in_len, u32 arity_bits, ext2 beta,
-                                                  u64* __restrict__ out) {
+// coeffs' [m] = sum_t coeffs[arity*m + t] beta^t  (reduce_with_powers, fri/prover.rs:112-121); in/out as [D][len] columns
+template <class F>
+__global__ __launch_bounds__(256) void k_fri_fold(const typename F::T* __restrict__ in, size_t in_len, u32 arity_bits,
+                                                  typename F::E beta, typename F::T* __restrict__ out) {
+    typedef typename F::E E;
     const size_t out_len = in_len >> arity_bits;
     size_t m = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= out_len) return;
     const u32 arity = 1u << arity_bits;
-    ext2 acc = gl::e2(0);
+    E acc = F::ezero();
     for (u32 t = arity; t-- > 0;) {
         size_t idx = (m << arity_bits) + t;
-        acc = gl::add(gl::mul(acc, beta), gl::e2(in[idx], in[in_len + idx]));
+        E v = F::ezero();
+#pragma unroll
+        for (u32 k = 0; k < F::D; k++) F::set_coord(v, k, in[(size_t)k * in_len + idx]);
+        acc = F::eadd(F::emul(acc, beta), v);
     }
-    out[m] = acc.c0;
-    out[out_len + m] = acc.c1;
+#pragma unroll
+    for (u32 k = 0; k < F::D; k++) out[(size_t)k * out_len + m] = F::coord(acc, k);
 }
 
 // proof of work: candidates start .. start+count; result = min satisfying candidate (fri/prover.rs:169-180)
-__global__ __launch_bounds__(256) void k_pow_grind(PowState st, u64 start, u64 count, u32 min_leading_zeros, u64* __restrict__ result) {
+template <class F>
+__global__ __launch_bounds__(256) void k_pow_grind(PowState<F> st, u64 start, u64 count, u32 min_leading_zeros,
+                                                   u64* __restrict__ result) {
     u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
     if (g >= count) return;
     u64 cand = start + g;
-    u64 s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = st.s[i];
+    Sponge<F> sp;
     // runtime position, static register indexing
 #pragma unroll
-    for (int i = 0; i < 12; i++)
-        if ((u32)i == st.pos) s[i] = cand;
-    poseidon_gl::permute_lazy(s);
-    u64 resp = poseidon_gl::to_canonical(s[7]);
+    for (int i = 0; i < (int)F::SPONGE_W; i++) sp.set_canonical(i, (u32)i == st.pos ? (typename F::T)cand : st.s[i]);
+    sp.permute();
+    u64 resp = sp.out(7);
     u32 lz = resp ? (u32)__clzll((long long)resp) : 64;
     if (lz >= min_leading_zeros) atomicMin(result, cand);
 }
 
-// ------------------------------------------------------------------ query gathers
+// ------------------------------------------------------------------ query gathers (outputs canonical)
 
 // rows[q][w] = cols[w * stride + idx[q]]
-__global__ void k_gather_rows(const u64* __restrict__ cols, size_t stride, u32 width, const u64* __restrict__ idx, u32 nidx,
-                              u64* __restrict__ rows) {
+template <class F>
+__global__ void k_gather_rows(const typename F::T* __restrict__ cols, size_t stride, u32 width, const u64* __restrict__ idx,
+                              u32 nidx, typename F::T* __restrict__ rows) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nidx * width) return;
     u32 q = g / width, w = g % width;
-    rows[g] = cols[(size_t)w * stride + idx[q]];
+    rows[g] = (typename F::T)F::dec(cols[(size_t)w * stride + idx[q]]);
 }
-// FRI layer leaf: out[q][2k + comp] = v_comp[arity * idx[q] + k]
-__global__ void k_gather_fri_leaves(const u64* __restrict__ v0, const u64* __restrict__ v1, u32 arity_bits,
-                                    const u64* __restrict__ idx, u32 nidx, u64* __restrict__ out) {
+// FRI layer leaf: out[q][D k + comp] = v_comp[arity * idx[q] + k]
+template <class F>
+__global__ void k_gather_fri_leaves(const typename F::T* __restrict__ vals, size_t len, u32 arity_bits,
+                                    const u64* __restrict__ idx, u32 nidx, typename F::T* __restrict__ out) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 width = 2u << arity_bits;
+    const u32 width = F::D << arity_bits;
     if (g >= nidx * width) return;
     u32 q = g / width, e = g % width;
-    const u64* v = (e & 1) ? v1 : v0;
-    out[g] = v[(idx[q] << arity_bits) + (e >> 1)];
+    out[g] = (typename F::T)F::dec(vals[(size_t)(e % F::D) * len + (idx[q] << arity_bits) + e / F::D]);
 }
-// sib[q][i][0..4) = level_i[(idx[q] >> i) ^ 1]
-__global__ void k_gather_siblings_multi(const u64* __restrict__ levels, u32 log_leaves, u32 cap_height,
-                                        const u64* __restrict__ idx, u32 nidx, u64* __restrict__ out) {
+// sib[q][i][0..H) = level_i[(idx[q] >> i) ^ 1]
+template <class F>
+__global__ void k_gather_siblings_multi(const typename F::T* __restrict__ levels, u32 log_leaves, u32 cap_height,
+                                        const u64* __restrict__ idx, u32 nidx, typename F::T* __restrict__ out) {
+    constexpr u32 H = F::H;
     const u32 layers = log_leaves - cap_height;
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nidx * layers * 4) return;
-    u32 e = g & 3, i = (g >> 2) % layers, q = (g >> 2) / layers;
+    if (g >= nidx * layers * H) return;
+    u32 e = g % H, i = (g / H) % layers, q = (g / H) / layers;
     const u64 N = (u64)1 << log_leaves;
     const u64 off = 2 * N - ((2 * N) >> i);
-    out[g] = levels[4 * (off + ((idx[q] >> i) ^ 1)) + e];
+    out[g] = levels[H * (off + ((idx[q] >> i) ^ 1)) + e];
 }
 
 // ------------------------------------------------------------------ launchers
 
 static inline u32 nblk(size_t n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 
-void gl_zs_partial_products(const ZsParams& p, const u64* witness, const u64* sigma, const u64* k_is, const u64* betas,
-                            const u64* gammas, u64* q_tmp, u64* zloc_tmp, u64* totals_tmp, u32* err, u64* out, hipStream_t st) {
+template <class F>
+void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, const typename F::T* sigma, const typename F::T* k_is,
+                         const typename F::T* betas, const typename F::T* gammas, typename F::T* q_tmp, typename F::T* zloc_tmp,
+                         typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st) {
     const size_t n = (size_t)1 << p.log_n;
     const u32 nb1024 = nblk(n, 1024);
-    hipLaunchKernelGGL(k_zs_quotients, dim3(nblk(n, 256), p.num_challenges), dim3(256), 0, st, p, witness, sigma, k_is, betas,
+    hipLaunchKernelGGL(k_zs_quotients<F>, dim3(nblk(n, 256), p.num_challenges), dim3(256), 0, st, p, witness, sigma, k_is, betas,
                        gammas, q_tmp, err);
-    hipLaunchKernelGGL(k_zs_scan_local, dim3(nb1024, p.num_challenges), dim3(256), 0, st, p, q_tmp, zloc_tmp, totals_tmp);
-    hipLaunchKernelGGL(k_zs_scan_totals, dim3(p.num_challenges), dim3(1024), 0, st, totals_tmp, nb1024);
-    hipLaunchKernelGGL(k_zs_finalize, dim3(nblk(n, 256), p.num_challenges), dim3(256), 0, st, p, q_tmp, zloc_tmp, totals_tmp,
+    hipLaunchKernelGGL(k_zs_scan_local<F>, dim3(nb1024, p.num_challenges), dim3(256), 0, st, p, q_tmp, zloc_tmp, totals_tmp);
+    hipLaunchKernelGGL(k_zs_scan_totals<F>, dim3(p.num_challenges), dim3(1024), 0, st, totals_tmp, nb1024);
+    hipLaunchKernelGGL(k_zs_finalize<F>, dim3(nblk(n, 256), p.num_challenges), dim3(256), 0, st, p, q_tmp, zloc_tmp, totals_tmp,
                        nb1024, out);
 }
 
-void gl_quotient_values(const QuotientParams& p, const u64* cs, const u64* wires, const u64* zs, const u64* uniforms, u64* qv,
-                        hipStream_t st) {
+#define GB_Q(FF, CC, HH) hipLaunchKernelGGL((k_quotient<FF, CC, HH>), grid, block, 0, st, p, cs, wires, zs, uniforms, qv)
+template <>
+bool quotient_values<GlF>(const QuotientParams<GlF>& p, const u64* cs, const u64* wires, const u64* zs, const u64* uniforms, u64* qv,
+                          hipStream_t st) {
     const size_t N = (size_t)1 << (p.log_n + p.rate_bits);
     const dim3 grid(nblk(N, 256)), block(256);
-#define GB_Q(CC, HH) hipLaunchKernelGGL((k_quotient<CC, HH>), grid, block, 0, st, p, cs, wires, zs, uniforms, qv)
     if (p.chunk == 8) {
         switch (p.num_challenges) {
-            case 1: GB_Q(1, 8); return;
-            case 2: GB_Q(2, 8); return;
-            case 3: GB_Q(3, 8); return;
-            case 4: GB_Q(4, 8); return;
+            case 1: GB_Q(GlF, 1, 8); return true;
+            case 2: GB_Q(GlF, 2, 8); return true;
+            case 3: GB_Q(GlF, 3, 8); return true;
+            case 4: GB_Q(GlF, 4, 8); return true;
             default: break;
         }
     }
     if (p.chunk == 16 && p.num_challenges <= 2) {
-        if (p.num_challenges == 1) GB_Q(1, 16); else GB_Q(2, 16);
-        return;
+        if (p.num_challenges == 1) GB_Q(GlF, 1, 16); else GB_Q(GlF, 2, 16);
+        return true;
     }
-    // (gb_circuit_create rejects other shapes)
+    return false;
+}
+// BabyBear: (31 - degree_bits) * c >= 100 (circuit_builder.rs:1190-1192) needs c = 6 .. 10 for degree_bits <= 20
+template <>
+bool quotient_values<BbF>(const QuotientParams<BbF>& p, const u32* cs, const u32* wires, const u32* zs, const u32* uniforms, u32* qv,
+                          hipStream_t st) {
+    const size_t N = (size_t)1 << (p.log_n + p.rate_bits);
+    const dim3 grid(nblk(N, 256)), block(256);
+    if (p.chunk != 8) return false;
+    switch (p.num_challenges) {
+        case 6: GB_Q(BbF, 6, 8); return true;
+        case 7: GB_Q(BbF, 7, 8); return true;
+        case 8: GB_Q(BbF, 8, 8); return true;
+        case 9: GB_Q(BbF, 9, 8); return true;
+        case 10: GB_Q(BbF, 10, 8); return true;
+        default: return false;
+    }
+}
 #undef GB_Q
+bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges) {
+    if (field == GlF::TAG)
+        return (chunk == 8 && num_challenges >= 1 && num_challenges <= 4) || (chunk == 16 && num_challenges >= 1 && num_challenges <= 2);
+    return chunk == 8 && num_challenges >= 6 && num_challenges <= 10;
 }
 
-void gl_quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const u64* a, const u64* mat, const CosetPow& inv_shift,
-                         u64* out, hipStream_t st) {
+template <class F>
+void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typename F::T* a, const typename F::T* mat,
+                      const CosetPow<F>& inv_shift, typename F::T* out, hipStream_t st) {
     const size_t n = (size_t)1 << log_n;
-    hipLaunchKernelGGL(k_quotient_combine, dim3(nblk(n, 256), num_challenges), dim3(256), 0, st, log_n, rate_bits, a, mat,
+    hipLaunchKernelGGL(k_quotient_combine<F>, dim3(nblk(n, 256), num_challenges), dim3(256), 0, st, log_n, rate_bits, a, mat,
                        inv_shift, out);
 }
 
-void gl_ext_pow_table(const ExtPowTab& z, size_t n, u64* table, hipStream_t st) {
-    hipLaunchKernelGGL(k_ext_pow_table, dim3(nblk(n, 256)), dim3(256), 0, st, z, n, reinterpret_cast<ext2*>(table));
+template <class F>
+void ext_pow_table(const ExtPowTab<F>& z, size_t n, typename F::E* table, hipStream_t st) {
+    hipLaunchKernelGGL(k_ext_pow_table<F>, dim3(nblk(n, 256)), dim3(256), 0, st, z, n, table);
 }
 
-void gl_eval_columns(const u64* coeffs, size_t ncols, size_t n, const u64* ztab, u64* partial_tmp, u64* out, hipStream_t st) {
+template <class F>
+void eval_columns(const typename F::T* coeffs, size_t ncols, size_t n, const typename F::E* ztab, typename F::E* partial_tmp,
+                  typename F::E* out, hipStream_t st) {
     if (!ncols) return;
     const u32 nch = nblk(n, 4096);
-    hipLaunchKernelGGL(k_eval_partial, dim3(nch, (u32)ncols), dim3(256), 0, st, coeffs, n, reinterpret_cast<const ext2*>(ztab),
-                       reinterpret_cast<ext2*>(partial_tmp));
-    hipLaunchKernelGGL(k_eval_final, dim3((u32)ncols), dim3(256), 0, st, reinterpret_cast<const ext2*>(partial_tmp), nch,
-                       reinterpret_cast<ext2*>(out));
+    hipLaunchKernelGGL(k_eval_partial<F>, dim3(nch, (u32)ncols), dim3(256), 0, st, coeffs, n, ztab, partial_tmp);
+    hipLaunchKernelGGL(k_eval_final<F>, dim3((u32)ncols), dim3(256), 0, st, partial_tmp, nch, out);
 }
 
-void gl_reduce_polys(const PolyGroups& g, size_t n, const u64* apow, u64* comp, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_polys, dim3(nblk(n, 256)), dim3(256), 0, st, g, n, reinterpret_cast<const ext2*>(apow),
-                       reinterpret_cast<ext2*>(comp));
+template <class F>
+void reduce_polys(const PolyGroups<F>& g, size_t n, const typename F::E* apow, typename F::E* comp, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_polys<F>, dim3(nblk(n, 256)), dim3(256), 0, st, g, n, apow, comp);
 }
 
-void gl_divide_by_linear_accumulate(const u64* comp, size_t n, const ExtPowTab& z, const ExtPowTab& zinv, const u64 shift[2],
-                                    int first, u64* sloc_tmp, u64* totals_tmp, u64* final_poly, hipStream_t st) {
+template <class F>
+void divide_by_linear_accumulate(const typename F::E* comp, size_t n, const ExtPowTab<F>& z, const ExtPowTab<F>& zinv,
+                                 typename F::E shift, int first, typename F::E* sloc_tmp, typename F::E* totals_tmp,
+                                 typename F::E* final_poly, hipStream_t st) {
     const u32 nb = nblk(n, 1024);
-    hipLaunchKernelGGL(k_divide_local, dim3(nb), dim3(256), 0, st, reinterpret_cast<const ext2*>(comp), n, z,
-                       reinterpret_cast<ext2*>(sloc_tmp), reinterpret_cast<ext2*>(totals_tmp));
-    hipLaunchKernelGGL(k_divide_totals, dim3(1), dim3(1024), 0, st, reinterpret_cast<ext2*>(totals_tmp), nb);
-    hipLaunchKernelGGL(k_divide_apply, dim3(nblk(n, 256)), dim3(256), 0, st, reinterpret_cast<const ext2*>(sloc_tmp),
-                       reinterpret_cast<const ext2*>(totals_tmp), n, zinv, gl::e2(shift[0], shift[1]), first,
-                       reinterpret_cast<ext2*>(final_poly));
+    hipLaunchKernelGGL(k_divide_local<F>, dim3(nb), dim3(256), 0, st, comp, n, z, sloc_tmp, totals_tmp);
+    hipLaunchKernelGGL(k_divide_totals<F>, dim3(1), dim3(1024), 0, st, totals_tmp, nb);
+    hipLaunchKernelGGL(k_divide_apply<F>, dim3(nblk(n, 256)), dim3(256), 0, st, sloc_tmp, totals_tmp, n, zinv, shift, first,
+                       final_poly);
 }
 
-void gl_ext_split(const u64* src, size_t n, u64* dst, hipStream_t st) {
-    hipLaunchKernelGGL(k_ext_split, dim3(nblk(n, 256)), dim3(256), 0, st, reinterpret_cast<const ext2*>(src), n, dst);
+template <class F>
+void ext_split(const typename F::E* src, size_t n, typename F::T* dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_ext_split<F>, dim3(nblk(n, 256)), dim3(256), 0, st, src, n, dst);
 }
 
-void gl_fri_leaves(const u64* v0, const u64* v1, u32 arity_bits, u64 num_leaves, u64* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_fri_leaves, dim3(nblk(num_leaves, 256)), dim3(256), 0, st, v0, v1, arity_bits, num_leaves, out);
+template <class F>
+void fri_leaves(const typename F::T* vals, size_t len, u32 arity_bits, u64 num_leaves, typename F::T* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_fri_leaves<F>, dim3(nblk(num_leaves, 256)), dim3(256), 0, st, vals, len, arity_bits, num_leaves, out);
 }
 
-void gl_fri_fold(const u64* in, size_t in_len, u32 arity_bits, const u64 beta[2], u64* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_fri_fold, dim3(nblk(in_len >> arity_bits, 256)), dim3(256), 0, st, in, in_len, arity_bits,
-                       gl::e2(beta[0], beta[1]), out);
+template <class F>
+void fri_fold(const typename F::T* in, size_t in_len, u32 arity_bits, typename F::E beta, typename F::T* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_fri_fold<F>, dim3(nblk(in_len >> arity_bits, 256)), dim3(256), 0, st, in, in_len, arity_bits, beta, out);
 }
 
-void gl_pow_grind(const PowState& s, u64 start, u64 count, u32 min_lz, u64* result, hipStream_t st) {
-    hipLaunchKernelGGL(k_pow_grind, dim3(nblk(count, 256)), dim3(256), 0, st, s, start, count, min_lz, result);
+template <class F>
+void pow_grind(const PowState<F>& s, u64 start, u64 count, u32 min_lz, u64* result, hipStream_t st) {
+    hipLaunchKernelGGL(k_pow_grind<F>, dim3(nblk(count, 256)), dim3(256), 0, st, s, start, count, min_lz, result);
 }
 
-void gl_gather_rows_multi(const u64* cols, size_t stride, u32 width, const u64* idx, u32 nidx, u64* rows, hipStream_t st) {
-    hipLaunchKernelGGL(k_gather_rows, dim3(nblk((size_t)nidx * width, 256)), dim3(256), 0, st, cols, stride, width, idx, nidx, rows);
+template <class F>
+void gather_rows_multi(const typename F::T* cols, size_t stride, u32 width, const u64* idx, u32 nidx, typename F::T* rows,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_rows<F>, dim3(nblk((size_t)nidx * width, 256)), dim3(256), 0, st, cols, stride, width, idx, nidx, rows);
 }
-void gl_gather_fri_leaves(const u64* v0, const u64* v1, u32 arity_bits, const u64* idx, u32 nidx, u64* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_gather_fri_leaves, dim3(nblk((size_t)nidx * (2u << arity_bits), 256)), dim3(256), 0, st, v0, v1,
+template <class F>
+void gather_fri_leaves(const typename F::T* vals, size_t len, u32 arity_bits, const u64* idx, u32 nidx, typename F::T* out,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_fri_leaves<F>, dim3(nblk((size_t)nidx * (F::D << arity_bits), 256)), dim3(256), 0, st, vals, len,
                        arity_bits, idx, nidx, out);
 }
-void gl_gather_siblings_multi(const u64* levels, u32 log_leaves, u32 cap_height, const u64* idx, u32 nidx, u64* out,
-                              hipStream_t st) {
+template <class F>
+void gather_siblings_multi(const typename F::T* levels, u32 log_leaves, u32 cap_height, const u64* idx, u32 nidx, typename F::T* out,
+                           hipStream_t st) {
     const u32 layers = log_leaves - cap_height;
     if (!layers) return;
-    hipLaunchKernelGGL(k_gather_siblings_multi, dim3(nblk((size_t)nidx * layers * 4, 256)), dim3(256), 0, st, levels, log_leaves,
-                       cap_height, idx, nidx, out);
+    hipLaunchKernelGGL(k_gather_siblings_multi<F>, dim3(nblk((size_t)nidx * layers * F::H, 256)), dim3(256), 0, st, levels,
+                       log_leaves, cap_height, idx, nidx, out);
 }
+
+#define GB_INSTANTIATE(F)                                                                                                           \
+    template void zs_partial_products<F>(const ZsParams<F>&, const F::T*, const F::T*, const F::T*, const F::T*, const F::T*, F::T*, \
+                                         F::T*, F::T*, u32*, F::T*, hipStream_t);                                                   \
+    template void quotient_combine<F>(u32, u32, u32, const F::T*, const F::T*, const CosetPow<F>&, F::T*, hipStream_t);             \
+    template void ext_pow_table<F>(const ExtPowTab<F>&, size_t, F::E*, hipStream_t);                                                \
+    template void eval_columns<F>(const F::T*, size_t, size_t, const F::E*, F::E*, F::E*, hipStream_t);                             \
+    template void reduce_polys<F>(const PolyGroups<F>&, size_t, const F::E*, F::E*, hipStream_t);                                   \
+    template void divide_by_linear_accumulate<F>(const F::E*, size_t, const ExtPowTab<F>&, const ExtPowTab<F>&, F::E, int, F::E*,   \
+                                                 F::E*, F::E*, hipStream_t);                                                        \
+    template void ext_split<F>(const F::E*, size_t, F::T*, hipStream_t);                                                            \
+    template void fri_leaves<F>(const F::T*, size_t, u32, u64, F::T*, hipStream_t);                                                 \
+    template void fri_fold<F>(const F::T*, size_t, u32, F::E, F::T*, hipStream_t);                                                  \
+    template void pow_grind<F>(const PowState<F>&, u64, u64, u32, u64*, hipStream_t);                                               \
+    template void gather_rows_multi<F>(const F::T*, size_t, u32, const u64*, u32, F::T*, hipStream_t);                              \
+    template void gather_fri_leaves<F>(const F::T*, size_t, u32, const u64*, u32, F::T*, hipStream_t);                              \
+    template void gather_siblings_multi<F>(const F::T*, u32, u32, const u64*, u32, F::T*, hipStream_t);
+GB_INSTANTIATE(GlF)
+GB_INSTANTIATE(BbF)
+#undef GB_INSTANTIATE
 
 }  // namespace gbk

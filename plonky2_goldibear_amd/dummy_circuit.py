@@ -59,6 +59,58 @@ def splitmix64(seed, count):
     return z % _P
 
 
+BB_P = 2013265921  # 2^31 - 2^27 + 1
+
+
+def bb_mul(a, b):
+    return (np.asarray(a, dtype=np.uint64) * np.asarray(b, dtype=np.uint64) % np.uint64(BB_P)).astype(np.uint32)
+
+
+def bb_powers(base, n):
+    out = np.ones(n, dtype=np.uint32)
+    m, bm = 1, int(base) % BB_P
+    while m < n:
+        out[m:2 * m] = bb_mul(out[:m], bm)
+        bm = bm * bm % BB_P
+        m *= 2
+    return out
+
+
+def build_dummy_circuit_bb(degree_bits, num_routed_wires=41, num_constants=2):
+    """BabyBear form of build_dummy_circuit (recursion_config_bb_narrow): PublicInputGate<8>, k_is = 31^i,
+    subgroup generator 0x1a427a41^(2^(27 - degree_bits)) (field constants recalled from upstream Plonky3, unpinned)."""
+    assert degree_bits >= 3
+    n = 1 << degree_bits
+    pi_row = (1 << (degree_bits - 1)) + 1
+    const_row = pi_row + 1
+    cs = np.zeros((1 + num_constants + num_routed_wires, n), dtype=np.uint32)
+    cs[0, pi_row] = GATE_PI
+    cs[0, const_row] = GATE_CONSTANT
+    k_is = np.array([pow(31, i, BB_P) for i in range(num_routed_wires)], dtype=np.uint32)
+    sub = bb_powers(pow(0x1a427a41, 1 << (27 - degree_bits), BB_P), n)
+    sig = cs[1 + num_constants:]
+    for j in range(num_routed_wires):
+        sig[j] = bb_mul(sub, k_is[j])
+    cls = [(pi_row, j) for j in range(8)] + [(const_row, 0)]
+    for t, (row, col) in enumerate(cls):
+        nrow, ncol = cls[(t + 1) % len(cls)]
+        sig[col, row] = int(k_is[ncol]) * int(sub[nrow]) % BB_P
+    return cs, k_is, pi_row, const_row
+
+
+def dummy_witness_bb(degree_bits, pi_row, num_wires=167, seed=0):
+    """wires 8.. of the PublicInputGate<8> row from SplitMix64 reduced mod p."""
+    w = np.zeros((num_wires, 1 << degree_bits), dtype=np.uint32)
+    idx = np.arange(1, num_wires - 8 + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(0x9E3779B97F4A7C15 + seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    w[8:, pi_row] = (z % np.uint64(BB_P)).astype(np.uint32)
+    return w
+
+
 def build_dummy_circuit(degree_bits, num_routed_wires=80, num_constants=2):
     """-> (constants_sigmas [1 + num_constants + routed][n] uint64, k_is [routed], pi_row, const_row)"""
     assert degree_bits >= 3

@@ -13,7 +13,7 @@ import weakref
 import numpy as np
 
 from . import native as N
-from .polynomial_batch import _as_input, _live_contexts  # noqa: F401
+from .polynomial_batch import _as_input, _dtype, _live_contexts  # noqa: F401
 
 _live_circuits = weakref.WeakSet()
 
@@ -26,24 +26,35 @@ class gb_circuit_config(C.Structure):
 
 
 class CircuitData:
+    """Defaults are standard_recursion_config_gl (plonk/circuit_data.rs:102-116); `CircuitData.babybear(...)`
+    fills in recursion_config_bb_narrow (:131-139)."""
+
+    @classmethod
+    def babybear(cls, ctx, degree_bits, constants_sigmas, k_is, *, num_challenges=6, **kw):
+        d = dict(num_wires=167, num_routed_wires=41, arity_bits=3, num_challenges=num_challenges, field=N.GB_BABYBEAR)
+        d.update(kw)
+        return cls(ctx, degree_bits, constants_sigmas, k_is, **d)
+
     def __init__(self, ctx, degree_bits, constants_sigmas, k_is, *, num_wires=135, num_routed_wires=80, num_constants=2,
                  num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16,
                  num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1, gate_constant=1, gate_pi=2,
                  field=N.GB_GOLDILOCKS):
         self.ctx, self._lib = ctx, ctx._lib
+        self.field, self._dt = field, _dtype(field)
+        hout = 4 if field == N.GB_GOLDILOCKS else 8
         self.cfg = gb_circuit_config(field, degree_bits, num_wires, num_routed_wires, num_constants, num_challenges,
                                      max_quotient_degree_factor, rate_bits, cap_height, proof_of_work_bits,
                                      num_query_rounds, arity_bits, final_poly_bits, num_selectors, gate_constant, gate_pi)
-        ptr, shape, flags, keep = _as_input(constants_sigmas)
+        ptr, shape, flags, keep = _as_input(constants_sigmas, field)
         want = (num_selectors + num_constants + num_routed_wires, 1 << degree_bits)
         if tuple(shape) != want:
             raise N.ShapeError(N.GB_ERR_INVALID, "constants_sigmas must be %r, got %r" % (want, tuple(shape)))
-        k = np.ascontiguousarray(k_is, dtype=np.uint64)
+        k = np.ascontiguousarray(k_is, dtype=self._dt)
         if k.shape != (num_routed_wires,):
             raise N.ShapeError(N.GB_ERR_INVALID, "k_is must have num_routed_wires entries")
         if flags == N.GB_INPUT_DEVICE:
             import torch
-            kd = torch.from_numpy(k.view(np.int64)).to("cuda:%d" % ctx.device)
+            kd = torch.from_numpy(k.view(np.int64 if k.itemsize == 8 else np.int32)).to("cuda:%d" % ctx.device)
             kptr, keep2 = kd.data_ptr(), kd
         else:
             kptr, keep2 = k.ctypes.data, k
@@ -51,15 +62,15 @@ class CircuitData:
         N.check(self._lib.gb_circuit_create(ctx.handle, C.byref(self.cfg), ptr, kptr, flags, C.byref(h)), ctx.handle)
         del keep, keep2
         self.handle = h
-        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
-        dig = np.empty(4, dtype=np.uint64)
+        cap = np.empty((1 << cap_height, hout), dtype=self._dt)
+        dig = np.empty(hout, dtype=self._dt)
         N.check(self._lib.gb_circuit_verifier_data(h, cap.ctypes.data, dig.ctypes.data), ctx.handle)
         self.constants_sigmas_cap, self.circuit_digest = cap, dig
         self._proof_buf = None
         _live_circuits.add(self)
 
     def prove(self, witness, public_inputs=()):
-        ptr, shape, flags, keep = _as_input(witness)
+        ptr, shape, flags, keep = _as_input(witness, self.field)
         want = (self.cfg.num_wires, 1 << self.cfg.degree_bits)
         if tuple(shape) != want:
             raise N.ShapeError(N.GB_ERR_INVALID, "witness must be %r, got %r" % (want, tuple(shape)))

@@ -1,0 +1,94 @@
+"""GPU prove() over BabyBear (BASELINE config 4) through the C ABI: proof BYTES identical to the CPU oracle
+prover's and accepted by the restated verifier.  BabyBear field constants are UNPINNED, so
+"identical" means identical to the restated algorithm, not to reference bytes.  -m gpu only."""
+import numpy as np
+import pytest
+
+from oracle import plonk_dummy as D
+from oracle.fields import BB
+from plonky2_goldibear_amd import CircuitData, GpuContext, ShapeError
+from plonky2_goldibear_amd import dummy_circuit as DC
+from plonky2_goldibear_amd import native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _gpu_circuit(ctx, circ):
+    cfg = circ.cfg
+    return CircuitData(ctx, circ.degree_bits, circ.constants_sigmas, circ.k_is, num_wires=cfg.num_wires,
+                       num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
+                       num_challenges=cfg.num_challenges, max_quotient_degree_factor=cfg.max_quotient_degree_factor,
+                       rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, proof_of_work_bits=cfg.proof_of_work_bits,
+                       num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits,
+                       gate_constant=circ.GATE_CONSTANT, gate_pi=circ.GATE_PI, field=N.GB_BABYBEAR)
+
+
+@pytest.mark.parametrize("degree_bits,num_challenges", [(3, 6), (4, 7), (6, 6), (9, 8), (12, 6), (13, 10)])
+def test_bb_proof_bytes_match_oracle(ctx, degree_bits, num_challenges):
+    circ = D.DummyCircuit(degree_bits, D.CircuitConfig.babybear(num_challenges), F=BB)
+    gpu = _gpu_circuit(ctx, circ)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    assert (gpu.constants_sigmas_cap == circ.constants_sigmas_cap).all()
+    w = circ.witness(seed=degree_bits)
+    want, _ = D.prove_cpu(circ, w)
+    got = gpu.prove(w)
+    assert len(got) == len(want)
+    assert got == want
+    assert D.verify(circ, got)
+
+
+def test_bb_product_side_circuit_builder_matches_oracle():
+    circ = D.DummyCircuit(7, F=BB)
+    cs, k_is, pi_row, const_row = DC.build_dummy_circuit_bb(7)
+    assert (cs == circ.constants_sigmas).all() and (k_is == circ.k_is).all()
+    assert (pi_row, const_row) == (circ.pi_row, circ.const_row)
+
+
+@pytest.mark.parametrize("degree_bits,num_challenges", [(14, 6), (16, 7)])
+def test_bb_larger_proofs_verify(ctx, degree_bits, num_challenges):
+    circ = D.DummyCircuit(degree_bits, D.CircuitConfig.babybear(num_challenges), F=BB)
+    gpu = _gpu_circuit(ctx, circ)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    proof = gpu.prove(circ.witness(seed=1))
+    stats = {}
+    assert D.verify(circ, proof, stats)
+    assert stats["merkle_paths"] == 28 * (4 + len(circ.reduction_arity_bits))
+    import torch
+    w2 = circ.witness(seed=2)
+    t = torch.from_numpy(w2.view(np.int32)).to("cuda:0")
+    proof2 = gpu.prove(t)
+    assert proof2 != proof and D.verify(circ, proof2)
+    assert proof2 == gpu.prove(w2)
+
+
+def test_bb_config4_2p20_rows(ctx):
+    """BASELINE config 4: 2^20-row dummy circuit, BabyBear + Poseidon2, num_challenges = 10 (31-bit field)."""
+    k = 20
+    cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(k)
+    gpu = CircuitData.babybear(ctx, k, cs, k_is, num_challenges=10)
+    circ = D.DummyCircuit.__new__(D.DummyCircuit)  # verifier-side view without the CPU commit of 44 x 2^20 columns
+    cfg = D.CircuitConfig.babybear(10)
+    circ.cfg, circ.degree_bits, circ.F, circ.n = cfg, k, BB, 1 << k
+    circ.k_is, circ.num_constants = k_is, 1 + cfg.num_constants
+    circ.num_partial_products = -(-cfg.num_routed_wires // cfg.max_quotient_degree_factor) - 1
+    circ.reduction_arity_bits = D.reduction_arity_bits(cfg, k)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    proof = gpu.prove(DC.dummy_witness_bb(k, pi_row, seed=3))
+    stats = {}
+    assert D.verify(circ, proof, stats)
+    assert stats["merkle_paths"] == 28 * (4 + 5)
+
+
+def test_bb_error_behaviour(ctx):
+    circ = D.DummyCircuit(5, F=BB)
+    with pytest.raises(ShapeError):  # circuit_builder.rs:1191-1192 with F::bits() = 31: 2^20 rows need 10 challenges
+        CircuitData.babybear(ctx, 20, np.zeros((44, 1 << 20), np.uint32), circ.k_is, num_challenges=6)
