@@ -62,13 +62,17 @@ def cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample_log_n):
     }
 
 
-def cpu_baseline_prove(log_n, num_challenges, sample_log_n):
+def cpu_baseline_prove(log_n, num_challenges, sample_log_n, field="goldilocks"):
     """The CPU oracle prover (restatement of the reference's prove(), OpenMP where the reference uses
     Rayon) on a smaller dummy circuit of the same shape, scaled linearly in rows."""
     from oracle import oracle as O
     from oracle import plonk_dummy as D
     cores = int(O.lib().gbo_num_threads())
-    circ = D.DummyCircuit(sample_log_n, D.CircuitConfig(num_challenges=num_challenges), check_security=False)
+    if field == "babybear":
+        from oracle.fields import BB
+        circ = D.DummyCircuit(sample_log_n, D.CircuitConfig.babybear(num_challenges), check_security=False, F=BB)
+    else:
+        circ = D.DummyCircuit(sample_log_n, D.CircuitConfig(num_challenges=num_challenges), check_security=False)
     _ = circ.circuit_digest  # build(): not part of prove()
     w = circ.witness(seed=1)
     t0 = time.perf_counter()
@@ -90,7 +94,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="prove", choices=["prove", "commit"])
-    ap.add_argument("--challenges", type=int, default=3)
+    ap.add_argument("--challenges", type=int, default=None,
+                    help="num_challenges; default = the minimum the reference's security assert allows at --log-n "
+                         "(Goldilocks 2^20: 3, BabyBear 2^20: 10; circuit_builder.rs:1190-1192)")
     ap.add_argument("--field", default="goldilocks", choices=["goldilocks", "babybear"])
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent proofs in flight per GPU (one host thread + one HIP stream each); a step is then one "
@@ -118,35 +124,52 @@ def main():
 
     ncols, log_n, rate_bits, cap_height = args.cols, args.log_n, 3, 4
     n = 1 << log_n
+    bb = args.field == "babybear"
+    if args.challenges is None:
+        bits = 31 if bb else 64
+        args.challenges = max(6 if bb else 2, -(-100 // (bits - log_n)))
+    # per-field circuit shape: standard_recursion_config_gl / recursion_config_bb_narrow (circuit_data.rs:102-139)
+    nwires, nrouted, arity_bits, ext_d, esz = (167, 41, 3, 4, 4) if bb else (135, 80, 4, 2, 8)
     ctx = GpuContext(local_rank)
     proof_len = 0
     inflight = max(1, args.inflight) if args.workload == "prove" else 1
     extra_ctx = []
     if args.workload == "prove":
         import threading
-        ncols = 135
-        cs, k_is, pi_row, _ = DC.build_dummy_circuit(log_n)
-        cs_dev = torch.from_numpy(cs.view(np.int64)).to("cuda:%d" % local_rank)
+        ncols = nwires
+        idt = np.int32 if bb else np.int64
+        cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(log_n) if bb else DC.build_dummy_circuit(log_n)
+        cs_dev = torch.from_numpy(cs.view(idt)).to("cuda:%d" % local_rank)
         lanes = []  # one (context, circuit, witness) per proof in flight: independent circuits, as across GPUs
         for li in range(inflight):
             lctx = ctx if li == 0 else GpuContext(local_rank)
             if li:
                 extra_ctx.append(lctx)
-            circuit = CircuitData(lctx, log_n, cs_dev, k_is, num_challenges=args.challenges)  # build(): once per circuit
-            wit = DC.dummy_witness(log_n, pi_row, seed=rank * inflight + li)
-            lanes.append((lctx, circuit, torch.from_numpy(wit.view(np.int64)).to("cuda:%d" % local_rank)))
+            if bb:  # build(): once per circuit
+                circuit = CircuitData.babybear(lctx, log_n, cs_dev, k_is, num_challenges=args.challenges)
+                wit = DC.dummy_witness_bb(log_n, pi_row, seed=rank * inflight + li)
+            else:
+                circuit = CircuitData(lctx, log_n, cs_dev, k_is, num_challenges=args.challenges)
+                wit = DC.dummy_witness(log_n, pi_row, seed=rank * inflight + li)
+            lanes.append((lctx, circuit, torch.from_numpy(wit.view(idt)).to("cuda:%d" % local_rank)))
+        # prove_with_partition_witness's retry loop (plonk/prover.rs:183-226): on InvZeroPermArg the random wire - last
+        # wire of the PublicInputGate row - is re-drawn and the proof redone; failed attempts stay inside the timed region
+        random_wire = (nwires - 1, pi_row)
+        rng = np.random.default_rng(1234 + rank)
+        retries = [0]
         del cs, cs_dev, wit
         torch.cuda.synchronize()
 
         def step():
             nonlocal proof_len
             if inflight == 1:
-                proof_len = len(lanes[0][1].prove(lanes[0][2]))
+                proof_len = len(lanes[0][1].prove(lanes[0][2], random_wire=random_wire, rng=rng))
+                retries[0] += lanes[0][1].perm_arg_retries
                 return
             out = [0] * inflight
 
             def run(i):
-                out[i] = len(lanes[i][1].prove(lanes[i][2]))
+                out[i] = len(lanes[i][1].prove(lanes[i][2], random_wire=random_wire, rng=np.random.default_rng(99 + i)))
             ts = [threading.Thread(target=run, args=(i,)) for i in range(inflight)]
             for t in ts:
                 t.start()
@@ -178,6 +201,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.workload == "prove":
+        retries[0] = 0
     if inflight == 1:
         ctx.set_profiling(True)  # per-scope HIP events; with several proofs in flight scopes overlap, so only wall time
     ctx.scope_reset()
@@ -202,18 +227,24 @@ def main():
         N = n << rate_bits
         if args.workload == "prove":
             c = args.challenges
-            nzs, nq = c * 10, c * 8
+            nzs, nq = c * (-(-nrouted // 8)), c * 8  # Z + partial products, quotient chunks
             # from_values (2 + 2^r) n s per column (wires, zs/pp), from_coeffs (1 + 2^r) n s (quotient
-            # chunks), + the final polynomial's 2 coordinate columns; the quotient's per-coset inverse NTTs and the
+            # chunks), + the final polynomial's D coordinate columns; the quotient's per-coset inverse NTTs and the
             # small FRI layers are not counted (conservative)
-            alg_bytes = ((2 + 8) * (135 + nzs) + (1 + 8) * (nq + 2)) * n * 8
-            perms = sum(N * (-(-w // 8)) + (N - 16) for w in (135, nzs, nq)) + sum(
-                (N >> (4 * (l + 1))) * 4 + ((N >> (4 * (l + 1))) - 16) for l in range((log_n - 5 + 3) // 4))
+            alg_bytes = ((2 + 8) * (nwires + nzs) + (1 + 8) * (nq + ext_d)) * n * esz
+            nlayers, db = 0, log_n
+            while db > 5 and db + rate_bits - arity_bits >= cap_height:  # fri/reduction_strategies.rs:44-56
+                nlayers, db = nlayers + 1, db - arity_bits
+            perms = sum(N * (-(-w // 8)) + (N - 16) for w in (nwires, nzs, nq)) + sum(
+                (N >> (arity_bits * (l + 1))) * ((ext_d << arity_bits) // 8) + ((N >> (arity_bits * (l + 1))) - 16)
+                for l in range(nlayers))
             metric = "proofs/s"
-            workload = ("prove(): 2^%d-row Goldilocks dummy circuit (2^%d+1 NoopGates), standard_recursion_config_gl with "
-                        "num_challenges=%d, Poseidon-12, witness resident in HBM -> proof bytes (%d B)" % (log_n, log_n - 1, c, proof_len))
+            workload = ("prove(): 2^%d-row %s dummy circuit (2^%d+1 NoopGates), %s with num_challenges=%d, %s, witness "
+                        "resident in HBM -> proof bytes (%d B)" % (
+                            log_n, "BabyBear" if bb else "Goldilocks", log_n - 1,
+                            "recursion_config_bb_narrow" if bb else "standard_recursion_config_gl", c,
+                            "Poseidon2-16" if bb else "Poseidon-12", proof_len))
         else:
-            esz = 4 if args.field == "babybear" else 8
             alg_bytes = (2 + (1 << rate_bits)) * n * esz * ncols  # (2 + 2^r) n s per column
             perms = N * (-(-ncols // 8)) + (N - (1 << cap_height))  # leaf sponge + internal nodes
             metric = "commits/s (PolynomialBatch::from_values, wires oracle of the 2^%d-row circuit)" % log_n
@@ -226,7 +257,7 @@ def main():
         if args.field == "goldilocks" and log_n == 20 and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if args.workload == "prove":
-                traffic = tj["ifft_bytes_per_column"] * (135 + nzs) + tj["lde_bytes_per_column"] * (135 + nzs + nq + 2)
+                traffic = tj["ifft_bytes_per_column"] * (nwires + nzs) + tj["lde_bytes_per_column"] * (nwires + nzs + nq + ext_d)
             else:
                 traffic = (tj["ifft_bytes_per_column"] + tj["lde_bytes_per_column"]) * ncols
         out = {
@@ -236,19 +267,22 @@ def main():
             "config": {"workload": workload, "field": args.field, "log_n": log_n, "rate_bits": rate_bits,
                        "cap_height": cap_height, "proofs_in_flight_per_gpu": inflight,
                        "sharding": "one independent circuit per GPU, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "NTT pass = k_gl_intt_p1+p2+p3 (IFFT) + k_gl_lde_pa+pb (FFT + blinding), all commitments of the step",
+            "roofline": {"bound": "hbm", "kernel": "NTT pass = %s (IFFT) + %s (FFT + blinding), all commitments of the step" % (
+                             ("k_bb_intt_p1+p2+p3", "k_bb_lde_pa+pb") if bb else ("k_gl_intt16_p1+p2+p3", "k_gl_lde_pa16+pb16")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "ms": ntt_ms},
             "scopes_ms_per_step": {k: v[0] / steps for k, v in scopes.items() if v[1]},
             "merkle": {"permutations": perms, "Gperm_per_s": perms / (merkle_ms * 1e-3) / 1e9},
         }
+        if args.workload == "prove":
+            out["perm_arg_retries"] = retries[0]  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
         if not args.no_cpu_baseline:
             sample = args.cpu_sample_log_n
             cores = os.cpu_count() or 1
             if args.workload == "prove":
                 if sample is None:
                     sample = max(8, min(log_n, 16, 10 + (cores.bit_length() - 1)))  # sized for ~10-30 s of CPU work
-                out["cpu_baseline"] = cpu_baseline_prove(log_n, args.challenges, sample)
+                out["cpu_baseline"] = cpu_baseline_prove(log_n, args.challenges, sample, args.field)
             else:
                 if sample is None:
                     sample = max(10, min(log_n, 19, 13 + (cores.bit_length() - 1)))

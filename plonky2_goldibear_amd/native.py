@@ -84,6 +84,11 @@ class PermArgZeroError(GoldibearError):
     """GB_ERR_PERM_ARG_ZERO: ProverError::InvZeroPermArg (plonk/prover.rs:512-514) - re-randomise and retry."""
 
 
+class TooManyPermArgFailuresError(GoldibearError):
+    """ProverError::TooManyPermArgFailures (plonk/prover.rs:188-192, 226): MAX_PERM_ARG_RETRIES attempts failed, or
+    the circuit has no random wire to re-randomise."""
+
+
 class ShapeError(GoldibearError, ValueError):
     """GB_ERR_INVALID: where the reference would assert!/panic! on a shape violation."""
 

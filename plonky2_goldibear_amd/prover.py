@@ -69,7 +69,37 @@ class CircuitData:
         self._proof_buf = None
         _live_circuits.add(self)
 
-    def prove(self, witness, public_inputs=()):
+    MAX_PERM_ARG_RETRIES = 3  # plonk/prover.rs:183
+
+    def prove(self, witness, public_inputs=(), random_wire=None, rng=None):
+        """prove_with_partition_witness (plonk/prover.rs:160-226): the retry loop around the proof proper.  When the
+        permutation argument hits a zero denominator (ProverError::InvZeroPermArg - with a 31-bit field and 2^20 rows
+        about one proof in five) the reference overwrites `random_wire` (circuit_builder.rs:1073-1075: the last wire of the
+        PublicInputGate row, given here as (column, row)) with a fresh F::rand() and tries again, at most 3 attempts.
+        `witness` is modified in place in that case, like the reference's `witness.wire_values`."""
+        self.perm_arg_retries = 0
+        for attempt in range(self.MAX_PERM_ARG_RETRIES):
+            if attempt > 0:
+                if random_wire is None:
+                    raise N.TooManyPermArgFailuresError(N.GB_ERR_PERM_ARG_ZERO, "Permutation argument division by zero but no "
+                                                        "random wire was given to randomize the witness")
+                rng = rng or np.random.default_rng()
+                col, row = random_wire
+                p = 0xFFFFFFFF00000001 if self.field == N.GB_GOLDILOCKS else 2013265921
+                val = int(rng.integers(0, p, dtype=np.uint64))
+                if isinstance(witness, np.ndarray):
+                    witness[col, row] = val
+                else:  # torch device tensor holding the same-width integer bit pattern
+                    witness[col, row] = val - (1 << (8 * witness.element_size())) if val >> (8 * witness.element_size() - 1) else val
+                self.perm_arg_retries = attempt
+            try:
+                return self.prove_once(witness, public_inputs)
+            except N.PermArgZeroError:
+                continue
+        raise N.TooManyPermArgFailuresError(N.GB_ERR_PERM_ARG_ZERO, "ProverError::TooManyPermArgFailures")
+
+    def prove_once(self, witness, public_inputs=()):
+        """internal_prove_with_partition_witness (plonk/prover.rs:228-447); raises PermArgZeroError."""
         ptr, shape, flags, keep = _as_input(witness, self.field)
         want = (self.cfg.num_wires, 1 << self.cfg.degree_bits)
         if tuple(shape) != want:

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import plonk_dummy as D
 from oracle.fields import BB
-from plonky2_goldibear_amd import CircuitData, GpuContext, ShapeError
+from plonky2_goldibear_amd import CircuitData, GpuContext, PermArgZeroError, ShapeError, TooManyPermArgFailuresError
 from plonky2_goldibear_amd import dummy_circuit as DC
 from plonky2_goldibear_amd import native as N
 
@@ -92,3 +92,33 @@ def test_bb_error_behaviour(ctx):
     circ = D.DummyCircuit(5, F=BB)
     with pytest.raises(ShapeError):  # circuit_builder.rs:1191-1192 with F::bits() = 31: 2^20 rows need 10 challenges
         CircuitData.babybear(ctx, 20, np.zeros((44, 1 << 20), np.uint32), circ.k_is, num_challenges=6)
+
+
+def test_bb_inv_zero_perm_arg_and_retry(ctx):
+    """ProverError::InvZeroPermArg (plonk/prover.rs:512-514) is reachable in a 31-bit field: at 2^16 rows, 7 challenges,
+    41 routed wires about 1 witness in 115 has a zero denominator.  Find one, check the CPU oracle prover reports the
+    same condition for it, and that the retry loop of prove_with_partition_witness (:183-226) re-randomises the random
+    wire and produces a verifying proof."""
+    k = 16
+    circ = D.DummyCircuit(k, D.CircuitConfig.babybear(7), F=BB)
+    gpu = _gpu_circuit(ctx, circ)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    bad = None
+    for seed in range(100, 1400):
+        w = circ.witness(seed=seed)
+        try:
+            gpu.prove_once(w)
+        except PermArgZeroError:
+            bad = w
+            break
+    if bad is None:
+        pytest.skip("no zero denominator in 1300 witnesses (probability ~1e-5)")
+    with pytest.raises(RuntimeError, match="rc=1"):  # oracle status 1 = InvZeroPermArg
+        D.prove_cpu(circ, bad)
+    with pytest.raises(TooManyPermArgFailuresError):  # no random wire given: the reference bails the same way
+        gpu.prove(bad.copy())
+    w = bad.copy()
+    proof = gpu.prove(w, random_wire=(circ.cfg.num_wires - 1, circ.pi_row), rng=np.random.default_rng(5))
+    assert gpu.perm_arg_retries >= 1
+    assert (w != bad).sum() == 1 and w[circ.cfg.num_wires - 1, circ.pi_row] != bad[circ.cfg.num_wires - 1, circ.pi_row]
+    assert D.verify(circ, proof)
