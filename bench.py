@@ -276,7 +276,7 @@ def main():
         }
         if args.workload == "prove":
             out["perm_arg_retries"] = retries[0]  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the driver's contract)
             sample = args.cpu_sample_log_n
             cores = os.cpu_count() or 1
             if args.workload == "prove":
