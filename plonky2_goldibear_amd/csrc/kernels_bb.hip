@@ -272,6 +272,11 @@ __global__ void k_bb_transpose_to_rows(const u32* __restrict__ cols, size_t col_
 // ------------------------------------------------------------------ launchers
 static inline u32 nblk(size_t n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 
+// radix-16 register kernels (kernels_bb16.hip); return false when the shape is not covered
+bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
+bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream);
+void bb_lde_pb_r16(u32* lde, size_t ntiles, const BbNttTables& t, hipStream_t stream);
+
 void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
     const u32 L = t.log_n;
     if (!ncols) return;
@@ -279,6 +284,7 @@ void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, co
         hipLaunchKernelGGL(k_bb_ntt_small, dim3((u32)ncols), dim3(THREADS), 0, stream, src, coeffs, L, t.tw4096_inv, t.n_inv);
         return;
     }
+    if (bb_intt_columns_r16(src, coeffs, scratch, ncols, t, stream)) return;
     BbInvGeom g{L, L <= 16 ? L - 8 : 8, L <= 16 ? 0 : L - 16, 8};
     const u32 LL = g.LB + g.LC;
     u32* p1_dst = g.LB ? coeffs : scratch;
@@ -298,10 +304,10 @@ void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables
                            ct.pow_lo);
         return;
     }
-    hipLaunchKernelGGL(k_bb_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
-                       t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-    hipLaunchKernelGGL(k_bb_lde_pb<false>, dim3((u32)(ncols << (r + L - 12))), dim3(THREADS), 0, stream, coeffs, lde, L, r,
-                       t.tw4096_fwd, ct.pow_lo);
+    if (!bb_lde_pa_r16(coeffs, lde, ncols, t, ct, stream))
+        hipLaunchKernelGGL(k_bb_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
+                           t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+    bb_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
 }
 void bb_merkle_leaves(const u32* cols, size_t col_stride, u32 width, u64 num_leaves, u32* out, hipStream_t stream) {
     hipLaunchKernelGGL(k_bb_merkle_leaves, dim3(nblk(num_leaves, 256)), dim3(256), 0, stream, cols, col_stride, width, num_leaves, out);

@@ -1,0 +1,344 @@
+// BabyBear NTT passes, v2: radix-16 butterflies held in registers (gfx950).
+//
+// Same passes, tiles, index math and memory layouts as kernels_ntt16.hip (Goldilocks); what differs is the
+// arithmetic: BabyBear has no power-of-two roots of unity, so the 17 non-trivial twiddles inside a 16-point
+// DFT are Montgomery multiplications by compile-time constants w_16^k.  The multiplication count per element
+// and layer is therefore the same as radix-2 (1/2); what the register form buys is one LDS round trip per four
+// layers instead of one per layer (v1, kernels_bb.hip: 34.8 ms of LDE per 2^20 proof, ~5x the VALU bound).
+// kernels_bb.hip's v1 passes remain the fallback for sizes other than 2^16 and 2^20.
+#include "bb_field.hpp"
+#include "kernels.hpp"
+
+namespace gbk {
+
+static constexpr int THREADS = 256;
+
+__device__ __forceinline__ constexpr u32 brev4(u32 x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); }
+
+namespace bbc {  // compile-time twiddles (canonical arithmetic, stored in Montgomery form)
+constexpr u32 cmul(u32 a, u32 b) { return (u32)((u64)a * b % bb::P); }
+constexpr u32 cpow(u32 b, u64 e) {
+    u32 r = 1;
+    while (e) {
+        if (e & 1) r = cmul(r, b);
+        b = cmul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+constexpr u32 W16 = cpow(bb::TWO_ADIC_GEN_27, 1u << 23);  // primitive 16th root of unity (two_adic_generator(4))
+constexpr u32 W16_INV = cpow(W16, 15);
+constexpr u32 mont(u32 x) { return (u32)(((u64)x << 32) % bb::P); }
+template <bool INV, int M>
+constexpr u32 tw() { return mont(cpow(INV ? W16_INV : W16, M)); }
+static_assert(cpow(W16, 16) == 1 && cpow(W16, 8) == bb::P - 1, "W16 must be a primitive 16th root of unity");
+}  // namespace bbc
+
+// (a - b) * w_16^(+-M)
+template <bool INV, int M>
+__device__ __forceinline__ u32 sub_twiddle(u32 a, u32 b) {
+    if constexpr (M == 0) return bb::sub(a, b);
+    else return bb::mul(bb::sub(a, b), bbc::tw<INV, M>());
+}
+
+template <bool INV, int H, int J>
+__device__ __forceinline__ void bfly(u32& a, u32& b) {  // DIF butterfly of half-size H at offset J: twiddle w_{2H}^J = w_16^(J * 8 / H)
+    u32 s = bb::add(a, b);
+    b = sub_twiddle<INV, J*(8 / H)>(a, b);
+    a = s;
+}
+
+// 16-point DFT in registers, natural input order, output X[k] in slot brev4(k) (in-place DIF)
+template <bool INV>
+__device__ __forceinline__ void dft16(u32 (&x)[16]) {
+#define B8(J) bfly<INV, 8, J>(x[J], x[J + 8]);
+    B8(0) B8(1) B8(2) B8(3) B8(4) B8(5) B8(6) B8(7)
+#undef B8
+#define B4(O, J) bfly<INV, 4, J>(x[O + J], x[O + J + 4]);
+    B4(0, 0) B4(0, 1) B4(0, 2) B4(0, 3) B4(8, 0) B4(8, 1) B4(8, 2) B4(8, 3)
+#undef B4
+#define B2(O, J) bfly<INV, 2, J>(x[O + J], x[O + J + 2]);
+    B2(0, 0) B2(0, 1) B2(4, 0) B2(4, 1) B2(8, 0) B2(8, 1) B2(12, 0) B2(12, 1)
+#undef B2
+#define B1(O) bfly<INV, 1, 0>(x[O], x[O + 1]);
+    B1(0) B1(2) B1(4) B1(6) B1(8) B1(10) B1(12) B1(14)
+#undef B1
+}
+
+__device__ __forceinline__ u32 bb_tw_split16(const u32* __restrict__ hi, const u32* __restrict__ lo, u32 e) {
+    u32 eh = e >> 10, el = e & 1023;
+    u32 w = lo[el];
+    return eh ? bb::mul(w, hi[eh]) : w;
+}
+
+// ------------------------------------------------------------------ LDE pass B: 4096 contiguous points, 3 radix-16 stages
+// grid = number of 4096-tiles of `lde` (in place).  natural -> bit-reversed.
+__global__ __launch_bounds__(THREADS) void k_bb_lde_pb16(u32* __restrict__ lde, const u32* __restrict__ tw4096) {
+    __shared__ u32 sh[16 * 272];
+    u32* p = lde + ((size_t)blockIdx.x << 12);
+    const u32 tid = threadIdx.x;
+    u32 x[16];
+    // stage 1: digit d2 (stride 256); this thread is (d1, d0) = tid
+#pragma unroll
+    for (u32 d = 0; d < 16; d++) x[d] = p[d * 256 + tid];
+    dft16<false>(x);
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) {
+        const u32 e = brev4(s) * tid;  // k2 * (16 d1 + d0) < 4096
+        u32 v = x[s];
+        if (e) v = bb::mul(v, tw4096[e]);
+        sh[s * 272 + tid] = v;
+    }
+    __syncthreads();
+    // stage 2: digit d1; this thread is (k2 slot, d0)
+    const u32 hi4 = tid >> 4, lo4 = tid & 15;
+#pragma unroll
+    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 16 + lo4];
+    dft16<false>(x);
+    __syncthreads();
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) {
+        const u32 e = brev4(s) * lo4 * 16;  // w_256^(k1 d0)
+        u32 v = x[s];
+        if (e) v = bb::mul(v, tw4096[e]);
+        sh[hi4 * 272 + lo4 * 17 + s] = v;  // [k2 slot][d0][k1 slot], rows padded to 17
+    }
+    __syncthreads();
+    // stage 3: digit d0; this thread is (k2 slot, k1 slot)
+#pragma unroll
+    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 17 + lo4];
+    dft16<false>(x);
+    __syncthreads();
+    // x[s] belongs at tile position tid * 16 + s: transpose through LDS for a coalesced store
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) sh[tid * 17 + s] = x[s];
+    __syncthreads();
+#pragma unroll
+    for (u32 it = 0; it < 16; it++) {
+        const u32 q = it * 256 + tid;
+        p[q] = sh[(q >> 4) * 17 + (q & 15)];
+    }
+}
+
+// ------------------------------------------------------------------ LDE pass A
+// LA = 8: grid = ncols * 256, tile 256 rows (a = 16 a1 + a0) x 16 columns.  Per coset: scale by s^(4096 a),
+// two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
+__global__ __launch_bounds__(THREADS) void k_bb_lde_pa16x2(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 L, u32 rate_bits,
+                                                           const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                           const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
+                                                           const u32* __restrict__ pow_hi) {
+    __shared__ u32 sh[16 * 272];
+    const size_t col = blockIdx.x >> 8;
+    const u32 tg = blockIdx.x & 255;
+    const u32 tid = threadIdx.x, hi4 = tid >> 4, j = tid & 15;
+    const u32 l = (tg << 4) + j;
+    const size_t n = (size_t)1 << L;
+    const u32* cin = coeffs + col * n + l;
+    u32 orig[16];
+#pragma unroll
+    for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
+    const u32 ncosets = 1u << rate_bits;
+    for (u32 c = 0; c < ncosets; c++) {
+        const u32* ph = pow_hi + (size_t)c * 256;
+        u32 x[16];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) {
+            const u32 a = a1 * 16 + hi4;
+            x[a1] = a ? bb::mul(orig[a1], ph[a]) : orig[a1];
+        }
+        dft16<false>(x);
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) {
+            const u32 e = brev4(s) * hi4 * 16;  // w_256^(k_a1 a0)
+            u32 v = x[s];
+            if (e) v = bb::mul(v, tw4096[e]);
+            sh[s * 272 + tid] = v;  // [k_a1 slot][a0][j]
+        }
+        __syncthreads();
+        // stage 2 thread = (k_a1 slot = hi4, j): digit a0
+#pragma unroll
+        for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * 272 + a0 * 16 + j];
+        dft16<false>(x);
+        const u32 sl = pow_lo[(size_t)c * 4096 + l];
+        u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+        const u32 ka1 = brev4(hi4);
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) {
+            const u32 ka = ka1 + 16 * brev4(s);
+            const u32 e = ka * l;
+            const u32 f = e ? bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, e)) : sl;
+            out[(size_t)(hi4 * 16 + s) << 12] = bb::mul(x[s], f);  // row position = brev8(k_a)
+        }
+        __syncthreads();
+    }
+}
+
+// LA = 4 (L = 16): grid = ncols * 16, block = 16 rows x 256 contiguous columns, one radix-16 stage, no LDS.
+__global__ __launch_bounds__(THREADS) void k_bb_lde_pa16x1(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 rate_bits,
+                                                           const u32* __restrict__ tw_hi, const u32* __restrict__ tw_lo,
+                                                           const u32* __restrict__ pow_lo, const u32* __restrict__ pow_hi) {
+    constexpr u32 L = 16;
+    const size_t col = blockIdx.x >> 4;
+    const u32 l = ((blockIdx.x & 15) << 8) + threadIdx.x;
+    const size_t n = (size_t)1 << L;
+    const u32* cin = coeffs + col * n + l;
+    u32 orig[16];
+#pragma unroll
+    for (u32 a = 0; a < 16; a++) orig[a] = cin[(size_t)a << 12];
+    const u32 ncosets = 1u << rate_bits;
+    for (u32 c = 0; c < ncosets; c++) {
+        const u32* ph = pow_hi + (size_t)c * 16;
+        u32 x[16];
+#pragma unroll
+        for (u32 a = 0; a < 16; a++) x[a] = a ? bb::mul(orig[a], ph[a]) : orig[a];
+        dft16<false>(x);
+        const u32 sl = pow_lo[(size_t)c * 4096 + l];
+        u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) {
+            const u32 e = brev4(s) * l;
+            const u32 f = e ? bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, e)) : sl;
+            out[(size_t)s << 12] = bb::mul(x[s], f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ inverse NTT passes (LA = 8, LB in {0, 4}, LC = 8)
+struct BbInv16Geom {
+    u32 L, LB;  // LA = LC = 8, LL = LB + 8
+};
+
+// P1: grid = ncols * 2^(LL-4); tile 256 rows (a) x 16 contiguous; rows written in natural k_a order
+__global__ __launch_bounds__(THREADS) void k_bb_intt16_p1(const u32* __restrict__ src, u32* __restrict__ dst, BbInv16Geom g,
+                                                          const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                          const u32* __restrict__ tw_lo) {
+    __shared__ u32 sh[16 * 272];
+    const u32 LL = g.LB + 8;
+    const u32 tiles_per_col = 1u << (LL - 4);
+    const size_t col = blockIdx.x / tiles_per_col;
+    const u32 tg = blockIdx.x % tiles_per_col;
+    const size_t base = (col << g.L) + ((size_t)tg << 4);
+    const u32 tid = threadIdx.x, hi4 = tid >> 4, j = tid & 15;
+    u32 x[16];
+#pragma unroll
+    for (u32 a1 = 0; a1 < 16; a1++) x[a1] = src[base + ((size_t)(a1 * 16 + hi4) << LL) + j];
+    dft16<true>(x);
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) {
+        const u32 e = brev4(s) * hi4 * 16;
+        u32 v = x[s];
+        if (e) v = bb::mul(v, tw4096[e]);
+        sh[s * 272 + tid] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * 272 + a0 * 16 + j];
+    dft16<true>(x);
+    const u32 l = (tg << 4) + j;
+    const u32 ka1 = brev4(hi4);
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) {
+        const u32 ka = ka1 + 16 * brev4(s);
+        const u32 e = ka * l;
+        u32 v = x[s];
+        if (e) v = bb::mul(v, bb_tw_split16(tw_hi, tw_lo, e));
+        dst[base + ((size_t)ka << LL) + j] = v;
+    }
+}
+
+// P2 (LB = 4): grid = ncols * 16 * 16; tile 16 k_a x 16 b x 16 c; src [k_a][b][c] -> dst [k_b][k_a][c]
+__global__ __launch_bounds__(THREADS) void k_bb_intt16_p2(const u32* __restrict__ src, u32* __restrict__ dst, u32 L,
+                                                          const u32* __restrict__ tw4096) {
+    const size_t col = blockIdx.x >> 8;
+    const u32 ga = (blockIdx.x >> 4) & 15, gc = blockIdx.x & 15;
+    const size_t cbase = col << L;
+    const u32 ia = threadIdx.x >> 4, jc = threadIdx.x & 15;
+    const u32 ka = 16 * ga + ia, c = 16 * gc + jc;
+    u32 x[16];
+#pragma unroll
+    for (u32 b = 0; b < 16; b++) x[b] = src[cbase + ((size_t)ka << 12) + ((size_t)b << 8) + c];
+    dft16<true>(x);
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) {
+        const u32 kb = brev4(s);
+        const u32 e = c * kb;  // w_4096^-(c k_b)
+        u32 v = x[s];
+        if (e) v = bb::mul(v, tw4096[e]);
+        dst[cbase + ((size_t)kb << 16) + ((size_t)ka << 8) + c] = v;
+    }
+}
+
+// P3: grid = ncols * 2^LB * 16; tile 16 k_a x 256 c (c = 16 c1 + c0); src [k_b][k_a][c];
+// dst natural k = k_a + 256 k_b + 2^(8+LB) k_c, scaled by n^-1
+__global__ __launch_bounds__(THREADS) void k_bb_intt16_p3(const u32* __restrict__ src, u32* __restrict__ dst, BbInv16Geom g,
+                                                          const u32* __restrict__ tw4096, u32 n_inv) {
+    __shared__ u32 sh[16 * 272];
+    const u32 nb = 1u << g.LB;
+    const size_t col = blockIdx.x / (nb * 16);
+    const u32 rem = blockIdx.x % (nb * 16);
+    const u32 kb = rem >> 4, ga = rem & 15;
+    const size_t cbase = col << g.L;
+    const size_t sbase = cbase + ((size_t)kb << 16) + ((size_t)(16 * ga) << 8);
+    const u32 tid = threadIdx.x, hi4 = tid >> 4, lo4 = tid & 15;
+    u32 x[16];
+    // stage 1 thread = (ia = hi4, c0 = lo4): digit c1
+#pragma unroll
+    for (u32 c1 = 0; c1 < 16; c1++) x[c1] = src[sbase + hi4 * 256 + c1 * 16 + lo4];
+    dft16<true>(x);
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) {
+        const u32 e = brev4(s) * lo4 * 16;  // w_256^-(k_c1 c0)
+        u32 v = x[s];
+        if (e) v = bb::mul(v, tw4096[e]);
+        sh[s * 272 + lo4 * 17 + hi4] = v;  // [k_c1 slot][c0][ia], rows padded to 17
+    }
+    __syncthreads();
+    // stage 2 thread = (k_c1 slot = hi4, ia = lo4): digit c0
+#pragma unroll
+    for (u32 c0 = 0; c0 < 16; c0++) x[c0] = sh[hi4 * 272 + c0 * 17 + lo4];
+    dft16<true>(x);
+    const u32 kc1 = brev4(hi4);
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) {
+        const u32 kc = kc1 + 16 * brev4(s);
+        dst[cbase + ((size_t)kc << (8 + g.LB)) + ((size_t)kb << 8) + 16 * ga + lo4] = bb::mul(x[s], n_inv);
+    }
+}
+
+// ------------------------------------------------------------------ launchers (called from kernels_ntt.hip's dispatchers)
+
+bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
+    const u32 L = t.log_n;
+    if (L != 16 && L != 20) return false;
+    BbInv16Geom g{L, L - 16};
+    const u32 LL = g.LB + 8;
+    u32* p1_dst = g.LB ? coeffs : scratch;
+    hipLaunchKernelGGL(k_bb_intt16_p1, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv,
+                       t.tw_hi_inv, t.tw_lo_inv);
+    if (g.LB)
+        hipLaunchKernelGGL(k_bb_intt16_p2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv);
+    hipLaunchKernelGGL(k_bb_intt16_p3, dim3((u32)(ncols << (g.LB + 4))), dim3(THREADS), 0, stream, scratch, coeffs, g,
+                       t.tw4096_inv, t.n_inv);
+    return true;
+}
+
+bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream) {
+    const u32 L = t.log_n;
+    if (L == 20) {
+        hipLaunchKernelGGL(k_bb_lde_pa16x2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, ct.rate_bits,
+                           t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        return true;
+    }
+    if (L == 16) {
+        hipLaunchKernelGGL(k_bb_lde_pa16x1, dim3((u32)(ncols << 4)), dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits,
+                           t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        return true;
+    }
+    return false;
+}
+
+void bb_lde_pb_r16(u32* lde, size_t ntiles, const BbNttTables& t, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bb_lde_pb16, dim3((u32)ntiles), dim3(THREADS), 0, stream, lde, t.tw4096_fwd);
+}
+
+}  // namespace gbk
