@@ -26,10 +26,12 @@ __host__ __device__ __forceinline__ u32 add(u32 a, u32 b) {  // a, b < P
     u32 t = s - P;
     return t < s ? t : s;  // min(s, s - P) as unsigned: s - P wraps high when s < P
 }
+// a, b < P.  a >= b: d in [0, P) and d + P is larger; a < b: d wraps to >= 2^32 - P and d + P wraps to the
+// canonical value, which is then the smaller one - so min() selects without a compare (v_sub, v_add, v_min).
 __host__ __device__ __forceinline__ u32 sub(u32 a, u32 b) {
     u32 d = a - b;
     u32 t = d + P;
-    return a >= b ? d : t;
+    return t < d ? t : d;
 }
 __host__ __device__ __forceinline__ u32 neg(u32 a) { return a ? P - a : 0; }
 
@@ -38,8 +40,9 @@ __host__ __device__ __forceinline__ u32 reduce(u64 t) {
     u32 m = (u32)t * PINV;
     u32 u = (u32)(((u64)m * P) >> 32);
     u32 hi = (u32)(t >> 32);
-    u32 d = hi - u;
-    return hi >= u ? d : d + P;
+    u32 d = hi - u;  // hi, u < P: same selection as sub() (a 64-bit compare + s_nop + cndmask otherwise)
+    u32 e = d + P;
+    return e < d ? e : d;
 }
 // Montgomery product: (a R)(b R) -> (ab R)
 __host__ __device__ __forceinline__ u32 mul(u32 a, u32 b) { return reduce((u64)a * b); }

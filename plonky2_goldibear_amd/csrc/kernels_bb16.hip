@@ -121,23 +121,28 @@ __global__ __launch_bounds__(THREADS) void k_bb_lde_pb16(u32* __restrict__ lde, 
 }
 
 // ------------------------------------------------------------------ LDE pass A
-// LA = 8: grid = ncols * 256, tile 256 rows (a = 16 a1 + a0) x 16 columns.  Per coset: scale by s^(4096 a),
-// two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
-__global__ __launch_bounds__(THREADS) void k_bb_lde_pa16x2(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 L, u32 rate_bits,
-                                                           const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
-                                                           const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
-                                                           const u32* __restrict__ pow_hi) {
-    __shared__ u32 sh[16 * 272];
-    const size_t col = blockIdx.x >> 8;
-    const u32 tg = blockIdx.x & 255;
-    const u32 tid = threadIdx.x, hi4 = tid >> 4, j = tid & 15;
-    const u32 l = (tg << 4) + j;
+// LA = 8: tile 256 rows (a = 16 a1 + a0) x JW columns, JW = 32 so that a row segment is a full 128-byte line
+// (16 x 4 B = 64 B segments left the stores of v2's first cut at 0.8 TB/s).  grid = ncols * 4096 / JW, 16 * JW threads.
+// Per coset: scale by s^(4096 a), two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
+template <u32 JW>
+__global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 L, u32 rate_bits,
+                                                            const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                            const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
+                                                            const u32* __restrict__ pow_hi) {
+    constexpr u32 ROW = 16 * JW;  // one k_a1 slot: [a0][j]; 4-byte words, consecutive j -> consecutive banks
+    __shared__ u32 sh[16 * ROW];
+    constexpr u32 TPC = 4096 / JW;  // tiles per column
+    const size_t col = blockIdx.x / TPC;
+    const u32 tg = blockIdx.x % TPC;
+    const u32 tid = threadIdx.x, hi4 = tid / JW, j = tid % JW;
+    const u32 l = tg * JW + j;
     const size_t n = (size_t)1 << L;
     const u32* cin = coeffs + col * n + l;
     u32 orig[16];
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
     const u32 ncosets = 1u << rate_bits;
+    const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 16 * l);
     for (u32 c = 0; c < ncosets; c++) {
         const u32* ph = pow_hi + (size_t)c * 256;
         u32 x[16];
@@ -152,22 +157,21 @@ __global__ __launch_bounds__(THREADS) void k_bb_lde_pa16x2(const u32* __restrict
             const u32 e = brev4(s) * hi4 * 16;  // w_256^(k_a1 a0)
             u32 v = x[s];
             if (e) v = bb::mul(v, tw4096[e]);
-            sh[s * 272 + tid] = v;  // [k_a1 slot][a0][j]
+            sh[s * ROW + tid] = v;  // [k_a1 slot][a0][j]
         }
         __syncthreads();
         // stage 2 thread = (k_a1 slot = hi4, j): digit a0
 #pragma unroll
-        for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * 272 + a0 * 16 + j];
+        for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * ROW + a0 * JW + j];
         dft16<false>(x);
         const u32 sl = pow_lo[(size_t)c * 4096 + l];
         u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
-        const u32 ka1 = brev4(hi4);
+        // output twiddle s^l w_n^(k_a l), k_a = k_a1 + 16 k': a geometric progression in k' with ratio w_n^(16 l)
+        u32 f = bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, brev4(hi4) * l));
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) {
-            const u32 ka = ka1 + 16 * brev4(s);
-            const u32 e = ka * l;
-            const u32 f = e ? bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, e)) : sl;
-            out[(size_t)(hi4 * 16 + s) << 12] = bb::mul(x[s], f);  // row position = brev8(k_a)
+        for (u32 k = 0; k < 16; k++) {  // k' = k: slot brev4(k), row position = brev8(k_a)
+            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = bb::mul(x[brev4(k)], f);
+            if (k < 15) f = bb::mul(f, ratio);
         }
         __syncthreads();
     }
@@ -186,19 +190,19 @@ __global__ __launch_bounds__(THREADS) void k_bb_lde_pa16x1(const u32* __restrict
 #pragma unroll
     for (u32 a = 0; a < 16; a++) orig[a] = cin[(size_t)a << 12];
     const u32 ncosets = 1u << rate_bits;
+    const u32 ratio = bb_tw_split16(tw_hi, tw_lo, l);
     for (u32 c = 0; c < ncosets; c++) {
         const u32* ph = pow_hi + (size_t)c * 16;
         u32 x[16];
 #pragma unroll
         for (u32 a = 0; a < 16; a++) x[a] = a ? bb::mul(orig[a], ph[a]) : orig[a];
         dft16<false>(x);
-        const u32 sl = pow_lo[(size_t)c * 4096 + l];
         u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+        u32 f = pow_lo[(size_t)c * 4096 + l];  // s^l w_n^(k l), k = 0..15
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) {
-            const u32 e = brev4(s) * l;
-            const u32 f = e ? bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, e)) : sl;
-            out[(size_t)s << 12] = bb::mul(x[s], f);
+        for (u32 k = 0; k < 16; k++) {
+            out[(size_t)brev4(k) << 12] = bb::mul(x[brev4(k)], f);
+            if (k < 15) f = bb::mul(f, ratio);
         }
     }
 }
@@ -325,7 +329,7 @@ bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols
 bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream) {
     const u32 L = t.log_n;
     if (L == 20) {
-        hipLaunchKernelGGL(k_bb_lde_pa16x2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, ct.rate_bits,
+        hipLaunchKernelGGL(k_bb_lde_pa16x2<32>, dim3((u32)(ncols << 7)), dim3(512), 0, stream, coeffs, lde, L, ct.rate_bits,
                            t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
         return true;
     }

@@ -137,17 +137,19 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pa16x2(const u64* __restrict
     const u32 l = (tg << 4) + j;
     const size_t n = (size_t)1 << L;
     const u64* cin = coeffs + col * n + l;
-    u64 orig[16];
-#pragma unroll
-    for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
     const u32 ncosets = 1u << rate_bits;
+    const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
     for (u32 c = 0; c < ncosets; c++) {
         const u64* ph = pow_hi + (size_t)c * 256;
         u64 x[16];
+        // the tile's coefficients are re-read per coset (L2 hits after the first) instead of being held in 32 VGPRs:
+        // with them resident the kernel needs 182 VGPRs (2 waves/SIMD); the barrier keeps the loads inside the loop
+        asm volatile("" ::: "memory");
 #pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) {
+        for (u32 a1 = 0; a1 < 16; a1++) {  // stage-1 thread = (a0 = hi4, j)
             const u32 a = a1 * 16 + hi4;
-            x[a1] = a ? gl::mul(orig[a1], ph[a]) : orig[a1];
+            const u64 v = cin[(size_t)a << 12];
+            x[a1] = a ? gl::mul(v, ph[a]) : v;
         }
         dft16<false>(x);
 #pragma unroll
@@ -164,13 +166,12 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pa16x2(const u64* __restrict
         dft16<false>(x);
         const u64 sl = pow_lo[(size_t)c * 4096 + l];
         u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
-        const u32 ka1 = brev4(hi4);
+        // output twiddle s^l w_n^(k_a l), k_a = k_a1 + 16 k': a geometric progression in k' with ratio w_n^(16 l)
+        u64 f = gl::mul(sl, tw_split16(tw_hi, tw_lo, brev4(hi4) * l));
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) {
-            const u32 ka = ka1 + 16 * brev4(s);
-            const u32 e = ka * l;
-            const u64 f = e ? gl::mul(sl, tw_split16(tw_hi, tw_lo, e)) : sl;
-            out[(size_t)(hi4 * 16 + s) << 12] = gl::mul(x[s], f);  // row position = brev8(k_a)
+        for (u32 k = 0; k < 16; k++) {  // k' = k: slot brev4(k), row position = brev8(k_a)
+            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul(x[brev4(k)], f);
+            if (k < 15) f = gl::mul(f, ratio);
         }
         __syncthreads();
     }
@@ -189,19 +190,19 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pa16x1(const u64* __restrict
 #pragma unroll
     for (u32 a = 0; a < 16; a++) orig[a] = cin[(size_t)a << 12];
     const u32 ncosets = 1u << rate_bits;
+    const u64 ratio = tw_split16(tw_hi, tw_lo, l);
     for (u32 c = 0; c < ncosets; c++) {
         const u64* ph = pow_hi + (size_t)c * 16;
         u64 x[16];
 #pragma unroll
         for (u32 a = 0; a < 16; a++) x[a] = a ? gl::mul(orig[a], ph[a]) : orig[a];
         dft16<false>(x);
-        const u64 sl = pow_lo[(size_t)c * 4096 + l];
         u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+        u64 f = pow_lo[(size_t)c * 4096 + l];  // s^l w_n^(k l), k = 0..15
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) {
-            const u32 e = brev4(s) * l;
-            const u64 f = e ? gl::mul(sl, tw_split16(tw_hi, tw_lo, e)) : sl;
-            out[(size_t)s << 12] = gl::mul(x[s], f);
+        for (u32 k = 0; k < 16; k++) {
+            out[(size_t)brev4(k) << 12] = gl::mul(x[brev4(k)], f);
+            if (k < 15) f = gl::mul(f, ratio);
         }
     }
 }

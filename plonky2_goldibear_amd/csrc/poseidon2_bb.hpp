@@ -62,19 +62,15 @@ __device__ __forceinline__ void external_layer(u32 (&s)[16]) {
 
 __device__ __forceinline__ void internal_layer(u32 (&s)[16]) {
     constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};  // gates/poseidon2_babybear.rs:41-42
-    u32 y[16];
+    // part = sum_{i>=1} s_i 2^-32: the reduction is linear, so reduce the 35-bit sum once instead of 15 words
+    const u64 sum = (u64)(s[1] + s[2]) + (u64)(s[3] + s[4]) + (u64)(s[5] + s[6]) + (u64)(s[7] + s[8]) + (u64)(s[9] + s[10]) +
+                    (u64)(s[11] + s[12]) + (u64)(s[13] + s[14]) + (u64)s[15];  // words < 2^31: the pair sums fit 32 bits
+    const u32 part = bb::reduce(sum);
+    const u32 y0 = bb::reduce((u64)s[0]);
+    const u32 full = bb::add(part, y0);
+    s[0] = bb::sub(part, y0);
 #pragma unroll
-    for (int i = 0; i < 16; i++) y[i] = bb::reduce((u64)s[i]);  // s_i * 2^-32
-    u32 part = y[1];
-#pragma unroll
-    for (int i = 2; i < 16; i++) part = bb::add(part, y[i]);
-    const u32 full = bb::add(part, y[0]);
-    s[0] = bb::sub(part, y[0]);
-#pragma unroll
-    for (int i = 0; i < 15; i++) {
-        u32 v = SH[i] == 0 ? y[i + 1] : bb::reduce((u64)s[i + 1] << SH[i]);  // (s_{i+1} 2^-32) 2^k
-        s[i + 1] = bb::add(full, v);
-    }
+    for (int i = 0; i < 15; i++) s[i + 1] = bb::add(full, bb::reduce((u64)s[i + 1] << SH[i]));  // (s_{i+1} 2^-32) 2^k
 }
 
 // state: Montgomery form in, Montgomery form out
