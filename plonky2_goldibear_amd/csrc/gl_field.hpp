@@ -54,23 +54,40 @@ __host__ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
     if (t2 < t0) t2 += EPS;              // carry: 2^64 = EPS
     return canon(t2);
 }
-// a * b mod p, canonical in/out.  Device path: four explicit 32x32 products (v_mad_u64_u32) and
-// the fold written with carry builtins - 70 vs 108 cycles per wave in tools/microbench_mulmod.hip.
-__host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+// (r0 + 2^32 r1 + 2^64 hl + 2^96 hh) mod p as SOME u64 congruent to it (not canonical; < 2^64 < 2p).
+// 2^64 = 2^32 - 1 and 2^96 = -1:  x = lo + hl 2^32 - (hl + hh), then every carry out of bit 64 is worth +EPS and every
+// borrow -EPS.  Written on 32-bit limbs with the carry builtins so that the compiler emits plain v_add_co / v_subb chains
+// (11 32-bit VALU ops) instead of 64-bit adds and compares: 64.4 vs 70.5 cycles per wave-multiply
+// (tools/microbench_mulmod.hip, M4 vs M2).  No second overflow is possible: after a carry the sum is < 2^64 - 2^32,
+// after a borrow it is > 2^64 - 2^33.
+__device__ __forceinline__ u64 fold128(u32 r0, u32 r1, u32 hl, u32 hh) {
+    u32 cs, c1, bw, B, k1, k2;
+    u32 s0 = __builtin_addc(hl, hh, 0u, &cs);   // hl + hh (33 bits: s0, cs)
+    u32 a1 = __builtin_addc(r1, hl, 0u, &c1);   // high word of lo + hl 2^32; c1 = one 2^64
+    u32 d0 = __builtin_subc(r0, s0, 0u, &bw);
+    u32 d1 = __builtin_subc(a1, cs, bw, &B);    // B = minus one 2^64
+    u32 mC = 0u - c1, mB = 0u - B;              // (c1 - B) EPS as a 64-bit two's-complement value (cl, ch)
+    u32 cl = __builtin_subc(mC, mB, 0u, &k1);
+    u32 ch = 0u - k1;
+    u32 f0 = __builtin_addc(d0, cl, 0u, &k2);
+    u32 f1 = d1 + ch + k2;
+    return (u64)f0 | ((u64)f1 << 32);
+}
+// a * b as four 32-bit limbs (four v_mad_u64_u32)
+__device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& hl, u32& hh) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 p01 = (u64)a0 * b1 + (p00 >> 32);
     u64 p10 = (u64)a1 * b0 + (u32)p01;
     u64 p11 = (u64)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
-    u64 lo = (p10 << 32) | (u32)p00;
-    u32 hl = (u32)p11, hh = (u32)(p11 >> 32);
-    u64 t0, t2;
-    bool br = __builtin_usubll_overflow(lo, (u64)hh, &t0);
-    t0 -= br ? EPS : 0;
-    bool cy = __builtin_uaddll_overflow(t0, (u64)hl * EPS, &t2);
-    t2 += cy ? EPS : 0;
-    return canon(t2);
+    r0 = (u32)p00; r1 = (u32)p10; hl = (u32)p11; hh = (u32)(p11 >> 32);
+}
+// a * b mod p, any u64 in, canonical out.
+__host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 r0, r1, hl, hh;
+    mul_limbs(a, b, r0, r1, hl, hh);
+    return canon(fold128(r0, r1, hl, hh));
 #else
     return reduce128(a * b, mulhi(a, b));
 #endif

@@ -27,7 +27,8 @@ __device__ __forceinline__ u64 mul_pow2(u64 x) {
     if constexpr (K == 0) {
         return x;
     } else if constexpr (K < 64) {
-        return gl::reduce128(x << K, x >> (64 - K));
+        const u64 lo = x << K, hi = x >> (64 - K);
+        return gl::canon(gl::fold128((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)));
     } else {
         // 2^K = 2^(K-64) * (2^32 - 1): a 64-bit constant < p
         constexpr u64 c = ((u64)1 << (K - 32)) - ((u64)1 << (K - 64));

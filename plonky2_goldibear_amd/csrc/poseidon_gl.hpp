@@ -65,39 +65,26 @@ static constexpr u32 MDS_DIAG0 = 8;
 
 // ------------------------------------------------------------------ lazy arithmetic (any u64 in, any u64 out)
 
-// (lo + 2^64 hi) mod p, not canonical.  2^64 = 2^32 - 1, 2^96 = -1.
+// (lo + 2^64 hi) mod p, not canonical: gl::fold128 on the four limbs.
 __device__ __forceinline__ u64 reduce128_lazy(u64 lo, u64 hi) {
-    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u64 t0, t2;
-    bool br = __builtin_usubll_overflow(lo, (u64)hh, &t0);
-    t0 -= br ? EPS : 0;
-    bool cy = __builtin_uaddll_overflow(t0, (u64)hl * EPS, &t2);
-    t2 += cy ? EPS : 0;
-    return t2;
+    return gl::fold128((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
 }
 __device__ __forceinline__ u64 reduce128_lazy(u128 x) { return reduce128_lazy((u64)x, (u64)(x >> 64)); }
 
-__device__ __forceinline__ void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
-    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    u64 p00 = (u64)a0 * b0;
-    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-    u64 p10 = (u64)a1 * b0 + (u32)p01;
-    u64 p11 = (u64)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
-    lo = (p10 << 32) | (u32)p00;
-    hi = p11;
-}
 __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
-    u64 lo, hi;
-    mul_wide(a, b, lo, hi);
-    return reduce128_lazy(lo, hi);
+    u32 r0, r1, hl, hh;
+    gl::mul_limbs(a, b, r0, r1, hl, hh);
+    return gl::fold128(r0, r1, hl, hh);
 }
 // a * b + c
 __device__ __forceinline__ u64 mul_add_lazy(u64 a, u64 b, u64 c) {
-    u64 lo, hi;
-    mul_wide(a, b, lo, hi);
-    u64 l2 = lo + c;
-    hi += l2 < lo;  // hi <= 2^64 - 2: cannot overflow
-    return reduce128_lazy(l2, hi);
+    u32 r0, r1, hl, hh, k0, k1, k2;
+    gl::mul_limbs(a, b, r0, r1, hl, hh);
+    r0 = __builtin_addc(r0, (u32)c, 0u, &k0);
+    r1 = __builtin_addc(r1, (u32)(c >> 32), k0, &k1);
+    hl = __builtin_addc(hl, 0u, k1, &k2);
+    hh += k2;  // a b + c < 2^128: cannot overflow
+    return gl::fold128(r0, r1, hl, hh);
 }
 // x lazy, rc canonical (< p): one carry fix is enough
 __device__ __forceinline__ u64 add_rc(u64 x, u64 rc) {

@@ -66,8 +66,46 @@ __device__ __forceinline__ u64 mul3(u64 a, u64 b) {
     return r3 + corr;
 }
 
+// M4: lazy, 4 mads, fold written on 32-bit limbs with carry builtins (clean v_add_co / v_subb chains, no 64-bit compares):
+//   x = lo + hl 2^32 - (hl + hh) + (carry - borrow) EPS
+__device__ __forceinline__ u64 fold4(u32 r0, u32 r1, u32 hl, u32 hh) {
+    u32 cs, c1, bw, B, k1, k2;
+    u32 s0 = __builtin_addc(hl, hh, 0u, &cs);     // hl + hh (33 bits)
+    u32 a1w = __builtin_addc(r1, hl, 0u, &c1);    // high word of lo + hl 2^32, carry c1 = one 2^64
+    u32 d0 = __builtin_subc(r0, s0, 0u, &bw);
+    u32 d1 = __builtin_subc(a1w, cs, bw, &B);     // borrow B = minus one 2^64
+    u32 mC = 0u - c1, mB = 0u - B;                // (c1 - B) EPS as a 64-bit two's complement value
+    u32 cl = __builtin_subc(mC, mB, 0u, &k1);
+    u32 ch = 0u - k1;
+    u32 f0 = __builtin_addc(d0, cl, 0u, &k2);
+    u32 f1 = d1 + ch + k2;
+    return (u64)f0 | ((u64)f1 << 32);
+}
+__device__ __forceinline__ u64 mul4(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    u64 p11 = (u64)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
+    return fold4((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
+}
+// M5: as M4, the last partial product's second addend enters through the carry chain instead of a 64-bit add
+__device__ __forceinline__ u64 mul5(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    u64 p11 = (u64)a1 * b1 + (p01 >> 32);
+    u32 c;
+    u32 hl = __builtin_addc((u32)p11, (u32)(p10 >> 32), 0u, &c);
+    u32 hh = (u32)(p11 >> 32) + c;
+    return fold4((u32)p00, (u32)p10, hl, hh);
+}
+
 template <int V>
 __device__ __forceinline__ u64 mulv(u64 a, u64 b) {
+    if (V == 4) return mul4(a, b);
+    if (V == 5) return mul5(a, b);
     if (V == 0) return mul0(a, b);
     if (V == 1) return mul1(a, b);
     if (V == 2) return mul2(a, b);
@@ -139,5 +177,7 @@ int main() {
     run<1>("M1 lazy");
     run<2>("M2 lazy4m");
     run<3>("M3 phi");
+    run<4>("M4 limb32");
+    run<5>("M5 limb32b");
     return 0;
 }
