@@ -251,10 +251,10 @@ def main():
             workload = "from_values: %d cols x 2^%d rows %s, rate_bits 3, cap_height 4, %s" % (
                 ncols, log_n, args.field, "Poseidon2-16" if args.field == "babybear" else "Poseidon-12")
         achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
-        # physical HBM bytes per column, measured once with rocprofv3 PMC passes (profiles/r01_ntt_traffic_pmc.json)
+        # physical HBM bytes per column, measured with rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/*.json)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_ntt_traffic_pmc.json")
-        if args.field == "goldilocks" and log_n == 20 and os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01d_ntt_traffic_pmc_%s.json" % args.field)
+        if log_n == 20 and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if args.workload == "prove":
                 traffic = tj["ifft_bytes_per_column"] * (nwires + nzs) + tj["lde_bytes_per_column"] * (nwires + nzs + nq + ext_d)

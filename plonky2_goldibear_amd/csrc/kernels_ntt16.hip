@@ -127,7 +127,9 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
 // ------------------------------------------------------------------ LDE pass A
 // LA = 8: grid = ncols * 256, tile 256 rows (a = 16 a1 + a0) x 16 columns.  Per coset: scale by s^(4096 a),
 // two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
-__global__ __launch_bounds__(THREADS) void k_gl_lde_pa16x2(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 L, u32 rate_bits,
+// 3 waves/SIMD (<= 168 VGPRs): the tile's 16 coefficients per thread stay in registers across the coset loop, so the
+// coefficients cross HBM once (re-reading them per coset measured the same time but 7x the fetch bytes).
+__global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 L, u32 rate_bits,
                                                            const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
                                                            const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
                                                            const u64* __restrict__ pow_hi) {
@@ -138,19 +140,18 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pa16x2(const u64* __restrict
     const u32 l = (tg << 4) + j;
     const size_t n = (size_t)1 << L;
     const u64* cin = coeffs + col * n + l;
+    u64 orig[16];
+#pragma unroll
+    for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
     const u32 ncosets = 1u << rate_bits;
     const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
     for (u32 c = 0; c < ncosets; c++) {
         const u64* ph = pow_hi + (size_t)c * 256;
         u64 x[16];
-        // the tile's coefficients are re-read per coset (L2 hits after the first) instead of being held in 32 VGPRs:
-        // with them resident the kernel needs 182 VGPRs (2 waves/SIMD); the barrier keeps the loads inside the loop
-        asm volatile("" ::: "memory");
 #pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) {  // stage-1 thread = (a0 = hi4, j)
+        for (u32 a1 = 0; a1 < 16; a1++) {
             const u32 a = a1 * 16 + hi4;
-            const u64 v = cin[(size_t)a << 12];
-            x[a1] = a ? gl::mul(v, ph[a]) : v;
+            x[a1] = a ? gl::mul(orig[a1], ph[a]) : orig[a1];
         }
         dft16<false>(x);
 #pragma unroll
