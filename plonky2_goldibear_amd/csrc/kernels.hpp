@@ -114,6 +114,7 @@ struct QuotientParams {
     u32 chunk, nchunks, nterms;
     u32 gate_constant, gate_pi, num_gate_consts;
     PowTab<F> w_N;   // LDE domain generator powers
+    const typename F::T* l0;  // [N] L_0 on the LDE domain, leaf order (l0_table)
 };
 template <class F>
 struct PolyGroups {
@@ -136,6 +137,9 @@ template <class F>
 bool quotient_values(const QuotientParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* zs,
                      const typename F::T* uniforms, typename F::T* qv, hipStream_t st);
 bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges);
+// l0[j] = Z_H(x_j) / (n (x_j - 1)), zh = device copy of the 2^rate_bits values of Z_H on the cosets
+template <class F>
+void l0_table(u32 log_n, u32 rate_bits, const PowTab<F>& w_N, const typename F::T* zh, typename F::T* l0, hipStream_t st);
 template <class F>
 void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typename F::T* a, const typename F::T* mat,
                       const CosetPow<F>& inv_shift, typename F::T* out, hipStream_t st);

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
     const T x = F::mul(F::generator(), pow_split(p.w_N, i));  // shifted_x = g * w_N^i
     const size_t jn = ((size_t)cidx << lgn) | brev32((il + 1) & (u32)(n - 1), lgn);  // leaf of i + 2^r
 
-    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash H]
+    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash H]  (zh: see k_l0_table)
     const u32 nr = p.num_routed, nterms = p.nterms, R = 1u << r;
     const T* betas = uni;
     const T* gammas = uni + C;
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
 #pragma unroll
     for (u32 k = 0; k < C; k++) acc[k] = F::zero();
     u32 t = 0;
-    // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61)
-    const T l0 = F::mul(zh[imod], F::inv(F::mul(F::enc((u64)n), F::sub(x, F::one()))));
+    // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61); L_0 on the LDE domain is a per-circuit table (k_l0_table)
+    const T l0 = p.l0[j];
     T zk[C];
 #pragma unroll
     for (u32 k = 0; k < C; k++) zk[k] = zs[(size_t)k * N + j];
@@ -227,9 +227,22 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
         T np[C], dp[C];
 #pragma unroll
         for (u32 k = 0; k < C; k++) np[k] = dp[k] = F::one();
+        const u32 live = min(CH, nr - w0);  // wires in this chunk (uniform); only the tail chunk has fewer than CH
+        if (live == CH) {
 #pragma unroll
-        for (u32 q = 0; q < CH; q++) {
-            if (w0 + q < nr) {
+            for (u32 q = 0; q < CH; q++) {
+#pragma unroll
+                for (u32 k = 0; k < C; k++) {
+                    T num = F::add(F::add(wv[q], F::mul(bk[k * nr + w0 + q], x)), gammas[k]);
+                    T den = F::add(F::add(wv[q], F::mul(betas[k], sg[q])), gammas[k]);
+                    np[k] = F::mul(np[k], num);
+                    dp[k] = F::mul(dp[k], den);
+                }
+            }
+        } else {
+#pragma unroll
+            for (u32 q = 0; q < CH; q++) {
+                if (q >= live) continue;
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
                     T num = F::add(F::add(wv[q], F::mul(bk[k * nr + w0 + q], x)), gammas[k]);
@@ -279,6 +292,22 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
     }
 #pragma unroll
     for (u32 k = 0; k < C; k++) qv[(((size_t)k << r) + cidx) * n + il] = F::mul(acc[k], zh_inv[imod]);
+}
+
+// l0[j] = L_0(x_j) = Z_H(x_j) / (n (x_j - 1)) for every LDE point in leaf order (once per circuit: the quotient kernel
+// would otherwise spend a field inversion, ~127 multiplications, per point and proof)
+template <class F>
+__global__ __launch_bounds__(256) void k_l0_table(u32 log_n, u32 rate_bits, PowTab<F> w_N, const typename F::T* __restrict__ zh,
+                                                  typename F::T* __restrict__ l0) {
+    typedef typename F::T T;
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const u32 cidx = (u32)(j >> log_n), jl = (u32)(j & (n - 1));
+    const u32 imod = brev32(cidx, rate_bits);
+    const u64 i = ((u64)brev32(jl, log_n) << rate_bits) | imod;
+    const T x = F::mul(F::generator(), pow_split(w_N, i));
+    l0[j] = F::mul(zh[imod], F::inv(F::mul(F::enc((u64)n), F::sub(x, F::one()))));
 }
 
 // After the per-block natural->natural inverse NTTs: a_c[t] are the coefficients of R_c(s_c X).
@@ -642,6 +671,12 @@ bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges) {
 }
 
 template <class F>
+void l0_table(u32 log_n, u32 rate_bits, const PowTab<F>& w_N, const typename F::T* zh, typename F::T* l0, hipStream_t st) {
+    const size_t N = (size_t)1 << (log_n + rate_bits);
+    hipLaunchKernelGGL(k_l0_table<F>, dim3(nblk(N, 256)), dim3(256), 0, st, log_n, rate_bits, w_N, zh, l0);
+}
+
+template <class F>
 void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typename F::T* a, const typename F::T* mat,
                       const CosetPow<F>& inv_shift, typename F::T* out, hipStream_t st) {
     const size_t n = (size_t)1 << log_n;
@@ -723,6 +758,7 @@ void gather_siblings_multi(const typename F::T* levels, u32 log_leaves, u32 cap_
     template void zs_partial_products<F>(const ZsParams<F>&, const F::T*, const F::T*, const F::T*, const F::T*, const F::T*, F::T*, \
                                          F::T*, F::T*, u32*, F::T*, hipStream_t);                                                   \
     template void quotient_combine<F>(u32, u32, u32, const F::T*, const F::T*, const CosetPow<F>&, F::T*, hipStream_t);             \
+    template void l0_table<F>(u32, u32, const PowTab<F>&, const F::T*, F::T*, hipStream_t);                                         \
     template void ext_pow_table<F>(const ExtPowTab<F>&, size_t, F::E*, hipStream_t);                                                \
     template void eval_columns<F>(const F::T*, size_t, size_t, const F::E*, F::E*, F::E*, hipStream_t);                             \
     template void reduce_polys<F>(const PolyGroups<F>&, size_t, const F::E*, F::E*, hipStream_t);                                   \
