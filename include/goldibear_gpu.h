@@ -103,6 +103,10 @@ gb_status gb_batch_leaf(gb_batch* b, uint64_t leaf_index, void* row, void* sibli
 gb_status gb_batch_digests(gb_batch* b, void* out);
 /* .merkle_tree.leaves: out[N][ncols + salt] row-major (oracle.rs:108-109 order). Debug aid. */
 gb_status gb_batch_leaves(gb_batch* b, void* out);
+/* every polynomial of the batch evaluated at one extension-field point: what OpeningSet::new's eval_commitment
+ * (plonk/proof.rs:359-363) computes with `p.to_extension().eval(z)`.  z: [D] canonical elements (D = 2 Goldilocks,
+ * 4 BabyBear), out: [ncols][D] canonical. */
+gb_status gb_batch_eval_ext(gb_batch* b, const void* z, void* out);
 /* device pointers for zero-copy chaining: coeffs [ncols][n], lde [ncols+salt][N] in leaf order */
 gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** digest_levels);
 
@@ -111,11 +115,15 @@ gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** di
  * for the prover (plonk/circuit_builder.rs:1214-1312): the constants||sigmas commitment (committed
  * here, :1230-1239), the sigma values, k_is, and circuit_digest (:1300-1312, empty domain separator).
  * Only the gate set of the reference's dummy circuit is evaluated on the GPU:
- * gates sorted by (degree, id) = [NoopGate, ConstantGate{num_constants}, PublicInputGate], one selector
- * column (gates/selectors.rs:142-159); anything else is GB_ERR_UNSUPPORTED and stays on the CPU path. */
+ * gates sorted by (degree, id) = [NoopGate, ConstantGate{num_constants}, PublicInputGate<H>], one selector
+ * column (gates/selectors.rs:142-159); anything else is GB_ERR_UNSUPPORTED and stays on the CPU path.
+ * Both of the reference's configurations are served (plonk/config.rs:119-150): GB_GOLDILOCKS = D 2, H 4,
+ * Poseidon-12, 8-byte elements; GB_BABYBEAR = D 4 (x^4 - 11), H 8, Poseidon2-16, 4-byte elements.  The quotient
+ * kernel is compiled for max_quotient_degree_factor 8 with 1..4 challenges (Goldilocks; also 16 with 1..2) and
+ * 6..10 challenges (BabyBear, where circuit_builder.rs:1190-1192 demands (31 - degree_bits) * c >= 100). */
 typedef struct gb_circuit gb_circuit;
 typedef struct gb_circuit_config {
-    uint32_t field;                 /* GB_GOLDILOCKS */
+    uint32_t field;                 /* GB_GOLDILOCKS | GB_BABYBEAR */
     uint32_t degree_bits;
     uint32_t num_wires, num_routed_wires, num_constants; /* CircuitConfig (plonk/circuit_data.rs:63-93) */
     uint32_t num_challenges, max_quotient_degree_factor;
@@ -130,19 +138,29 @@ typedef struct gb_circuit_config {
 gb_status gb_circuit_create(gb_ctx* ctx, const gb_circuit_config* cfg, const void* constants_sigmas, const void* k_is,
                             uint32_t flags, gb_circuit** out);
 gb_status gb_circuit_free(gb_circuit* c);
-/* VerifierOnlyCircuitData: constants_sigmas_cap [2^cap_height][4] and circuit_digest [4] */
+/* VerifierOnlyCircuitData: constants_sigmas_cap [2^cap_height][H] and circuit_digest [H], field elements */
 gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_out);
 /* prove_with_partition_witness -> internal_prove_with_partition_witness (plonk/prover.rs:160-447):
  * witness = MatrixWitness.wire_values [num_wires][n] (iop/witness.rs:277-284), already generated.
  * Writes ProofWithPublicInputs bytes (util/serialization/mod.rs:2134-2151) to proof_out; *proof_len
  * is the size needed.  The PoW witness is the MINIMUM valid nonce (the reference's find_any with one
  * thread).  GB_ERR_PERM_ARG_ZERO mirrors ProverError::InvZeroPermArg (prover.rs:512-514): the caller
- * re-randomises the random wire and retries, as prover.rs:186-226 does. */
+ * re-randomises the random wire and retries, as prover.rs:186-226 does (in a 31-bit field about one
+ * 2^20-row proof in five needs it).  public_inputs are canonical values as u64 for either field; elements of
+ * `witness` and of the proof are 8 (Goldilocks) / 4 (BabyBear) bytes (hash/hash_types.rs:39-41, :73-75). */
 #define GB_ERR_PERM_ARG_ZERO 16
 #define GB_ERR_OPENING_IN_SUBGROUP 17
 #define GB_ERR_BUFFER_TOO_SMALL 18
 gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uint64_t* public_inputs,
                    size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);
+
+/* fri_proof_of_work (fri/prover.rs:136-188) on its own, for a host that keeps the Challenger: sponge_state is the
+ * duplex state with the pending input buffer already written over lanes 0..witness_pos-1 (`duplex_intermediate_state`,
+ * :165-167; [12] u64 / [16] u32 canonical), witness_pos = input_buffer.len().  Returns the MINIMUM candidate whose
+ * response `permute(state with candidate at witness_pos)[7]` has >= min_leading_zeros leading zeros as a u64
+ * (min_leading_zeros = proof_of_work_bits + 64 - F::order().bits(), :147). */
+gb_status gb_pow_grind(gb_ctx* ctx, uint32_t field, const void* sponge_state, uint32_t witness_pos, uint32_t min_leading_zeros,
+                       uint64_t* nonce);
 
 /* ---- bare kernels (parity tests and microbenchmarks) ---------------------------------------- */
 /* `count` Poseidon-12 (GL) / Poseidon2-16 (BB) permutations: in/out [count][width], host memory.

@@ -78,6 +78,15 @@ class GpuContext:
     def scope_reset(self):
         N.check(self._lib.gb_ctx_scope_reset(self.handle), self.handle)
 
+    def pow_grind(self, sponge_state, witness_pos, min_leading_zeros, field=N.GB_GOLDILOCKS):
+        """fri_proof_of_work (fri/prover.rs:136-188): minimum nonce for the given duplex state."""
+        st = np.ascontiguousarray(sponge_state, dtype=_dtype(field))
+        if st.shape != ((12,) if field == N.GB_GOLDILOCKS else (16,)):
+            raise N.ShapeError(N.GB_ERR_INVALID, "sponge state must have the permutation's width")
+        out = C.c_uint64()
+        N.check(self._lib.gb_pow_grind(self.handle, field, st.ctypes.data, witness_pos, min_leading_zeros, C.byref(out)), self.handle)
+        return out.value
+
     def permute(self, states, field=N.GB_GOLDILOCKS):
         """PoseidonGoldilocks::poseidon on each row of `states` [count][12]."""
         x = np.ascontiguousarray(states, dtype=_dtype(field))
@@ -206,6 +215,17 @@ class PolynomialBatch:
         """oracle.rs:153-158"""
         out = np.empty(self.num_polys, dtype=self._dt)
         N.check(self._lib.gb_batch_lde_values(self.handle, index, step, out.ctypes.data), self.ctx.handle)
+        return out
+
+    def eval_ext(self, z):
+        """plonk/proof.rs:359-363 eval_commitment: every polynomial at the extension point z (D canonical words)
+        -> [num_polys][D]"""
+        d = 2 if self.field == N.GB_GOLDILOCKS else 4
+        zz = np.ascontiguousarray(z, dtype=self._dt)
+        if zz.shape != (d,):
+            raise N.ShapeError(N.GB_ERR_INVALID, "z must have %d coordinates" % d)
+        out = np.empty((self.num_polys, d), dtype=self._dt)
+        N.check(self._lib.gb_batch_eval_ext(self.handle, zz.ctypes.data, out.ctypes.data), self.ctx.handle)
         return out
 
     def _leaf(self, i):

@@ -147,3 +147,51 @@ def test_circuit_digest_kat_gpu(ctx, kats):
     cs, degree_bits = D.test_form_constants_sigmas(16000)
     gpu = PolynomialBatch.from_values(ctx, cs, 3, 4)
     assert D.circuit_digest_from_cap(gpu.merkle_tree.cap, degree_bits).tolist() == want["digest"]
+
+
+@pytest.mark.parametrize("field_name,log_n,ncols", [("goldilocks", 0, 2), ("goldilocks", 5, 3), ("goldilocks", 13, 7),
+                                                     ("babybear", 4, 3), ("babybear", 13, 5)])
+def test_eval_ext_matches_horner(ctx, field_name, log_n, ncols):
+    """gb_batch_eval_ext = p.to_extension().eval(z) per polynomial (plonk/proof.rs:359-363), checked against a
+    Horner evaluation in the oracle's extension-field restatement (oracle/fields.py)."""
+    from oracle.fields import BB, GL
+    from plonky2_goldibear_amd import native as N
+    F, tag = (GL, N.GB_GOLDILOCKS) if field_name == "goldilocks" else (BB, N.GB_BABYBEAR)
+    n = 1 << log_n
+    coeffs = F.fill(0xABCDEF + log_n, ncols * n).reshape(ncols, n)
+    b = PolynomialBatch.from_coeffs(ctx, coeffs, 1, 0, field=tag)
+    z = tuple(int(x) for x in F.fill(77 + log_n, F.D))
+    got = b.eval_ext(np.array(z, dtype=F.dtype))
+    for c in range(ncols):
+        acc = F.zero
+        for t in range(n - 1, -1, -1):
+            acc = F.eadd(F.emul(acc, z), F.efrom(int(coeffs[c, t])))
+        assert tuple(int(x) for x in got[c]) == acc
+    with pytest.raises(ShapeError):
+        b.eval_ext(np.zeros(F.D + 1, dtype=F.dtype))
+    b.free()
+
+
+def test_pow_grind_minimum_nonce(ctx):
+    """gb_pow_grind = fri_proof_of_work (fri/prover.rs:136-188) with the minimum-nonce rule, both fields, checked by
+    brute force over the oracle's permutations."""
+    from oracle import oracle_bb as B
+    from plonky2_goldibear_amd import native as N
+    st = O.splitmix64_fill(4242, 12)
+    bits = 10
+    nonce = ctx.pow_grind(st, 3, bits)
+    for cand in range(nonce + 1):
+        s2 = st.copy()
+        s2[3] = cand
+        ok = int(O.poseidon(s2)[7]) >> (64 - bits) == 0
+        assert ok == (cand == nonce)
+    stb = B.fill(99, 16)
+    min_lz = 8 + 33  # proof_of_work_bits + (64 - 31)
+    nonce = ctx.pow_grind(stb, 5, min_lz, field=N.GB_BABYBEAR)
+    for cand in range(nonce + 1):
+        s2 = stb.copy()
+        s2[5] = cand
+        ok = int(B.poseidon2(s2)[7]) < (1 << (64 - min_lz))
+        assert ok == (cand == nonce)
+    with pytest.raises(ShapeError):
+        ctx.pow_grind(st, 8, bits)
