@@ -71,6 +71,14 @@ __device__ __forceinline__ u32 bb_tw_split16(const u32* __restrict__ hi, const u
     return eh ? bb::mul(w, hi[eh]) : w;
 }
 
+// The 15 inter-stage twiddles w_4096^(k m), k = brev4(slot), as ONE batch of independent loads issued before the
+// DFT that precedes their use.  (Loaded one by one behind `if (e)` each of them cost a full memory round trip:
+// rocprofv3 showed the waves of these kernels parked in s_waitcnt for 46-66 % of their lifetime.)
+__device__ __forceinline__ void load_tw16(u32 (&tw)[16], const u32* __restrict__ tw4096, u32 m) {
+#pragma unroll
+    for (u32 s = 1; s < 16; s++) tw[s] = tw4096[brev4(s) * m];
+}
+
 // ------------------------------------------------------------------ LDE pass B: 4096 contiguous points, 3 radix-16 stages
 // grid = number of 4096-tiles of `lde` (in place).  natural -> bit-reversed.
 __global__ __launch_bounds__(THREADS) void k_bb_lde_pb16(u32* __restrict__ lde, const u32* __restrict__ tw4096) {
@@ -81,28 +89,21 @@ __global__ __launch_bounds__(THREADS) void k_bb_lde_pb16(u32* __restrict__ lde, 
     // stage 1: digit d2 (stride 256); this thread is (d1, d0) = tid
 #pragma unroll
     for (u32 d = 0; d < 16; d++) x[d] = p[d * 256 + tid];
+    u32 tw[16];
+    load_tw16(tw, tw4096, tid);  // w_4096^(k2 (16 d1 + d0))
     dft16<false>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) {
-        const u32 e = brev4(s) * tid;  // k2 * (16 d1 + d0) < 4096
-        u32 v = x[s];
-        if (e) v = bb::mul(v, tw4096[e]);
-        sh[s * 272 + tid] = v;
-    }
+    for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? bb::mul(x[s], tw[s]) : x[s];
     __syncthreads();
     // stage 2: digit d1; this thread is (k2 slot, d0)
     const u32 hi4 = tid >> 4, lo4 = tid & 15;
 #pragma unroll
     for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 16 + lo4];
+    load_tw16(tw, tw4096, lo4 * 16);  // w_256^(k1 d0)
     dft16<false>(x);
     __syncthreads();
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) {
-        const u32 e = brev4(s) * lo4 * 16;  // w_256^(k1 d0)
-        u32 v = x[s];
-        if (e) v = bb::mul(v, tw4096[e]);
-        sh[hi4 * 272 + lo4 * 17 + s] = v;  // [k2 slot][d0][k1 slot], rows padded to 17
-    }
+    for (u32 s = 0; s < 16; s++) sh[hi4 * 272 + lo4 * 17 + s] = s ? bb::mul(x[s], tw[s]) : x[s];  // [k2 slot][d0][k1 slot], rows padded to 17
     __syncthreads();
     // stage 3: digit d0; this thread is (k2 slot, k1 slot)
 #pragma unroll
@@ -143,31 +144,28 @@ __global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict
     for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
     const u32 ncosets = 1u << rate_bits;
     const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 16 * l);
+    const u32 f0 = bb_tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // w_n^(k_a1 l)
+    u32 tw[16];
+    load_tw16(tw, tw4096, hi4 * 16);  // w_256^(k_a1 a0): the same for every coset
     for (u32 c = 0; c < ncosets; c++) {
-        const u32* ph = pow_hi + (size_t)c * 256;
+        const u32* ph = pow_hi + (size_t)c * 256 + hi4;
         u32 x[16];
 #pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) {
-            const u32 a = a1 * 16 + hi4;
-            x[a1] = a ? bb::mul(orig[a1], ph[a]) : orig[a1];
-        }
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = ph[a1 * 16];  // s_c^(4096 a): 16 independent loads (entry 0 is 1)
+        const u32 sl = pow_lo[(size_t)c * 4096 + l];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = bb::mul(orig[a1], x[a1]);
         dft16<false>(x);
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) {
-            const u32 e = brev4(s) * hi4 * 16;  // w_256^(k_a1 a0)
-            u32 v = x[s];
-            if (e) v = bb::mul(v, tw4096[e]);
-            sh[s * ROW + tid] = v;  // [k_a1 slot][a0][j]
-        }
+        for (u32 s = 0; s < 16; s++) sh[s * ROW + tid] = s ? bb::mul(x[s], tw[s]) : x[s];  // [k_a1 slot][a0][j]
         __syncthreads();
         // stage 2 thread = (k_a1 slot = hi4, j): digit a0
 #pragma unroll
         for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * ROW + a0 * JW + j];
         dft16<false>(x);
-        const u32 sl = pow_lo[(size_t)c * 4096 + l];
         u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
         // output twiddle s^l w_n^(k_a l), k_a = k_a1 + 16 k': a geometric progression in k' with ratio w_n^(16 l)
-        u32 f = bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, brev4(hi4) * l));
+        u32 f = bb::mul(sl, f0);
 #pragma unroll
         for (u32 k = 0; k < 16; k++) {  // k' = k: slot brev4(k), row position = brev8(k_a)
             out[(size_t)(hi4 * 16 + brev4(k)) << 12] = bb::mul(x[brev4(k)], f);
@@ -226,27 +224,24 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p1(const u32* __restrict_
     u32 x[16];
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) x[a1] = src[base + ((size_t)(a1 * 16 + hi4) << LL) + j];
+    u32 tw[16];
+    load_tw16(tw, tw4096, hi4 * 16);
+    const u32 l = (tg << 4) + j;
+    const u32 ka1 = brev4(hi4);
+    // output twiddle w_n^-(k_a l), k_a = k_a1 + 16 k: a geometric progression in k with ratio w_n^-(16 l)
+    u32 f = bb_tw_split16(tw_hi, tw_lo, ka1 * l);
+    const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 16 * l);
     dft16<true>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) {
-        const u32 e = brev4(s) * hi4 * 16;
-        u32 v = x[s];
-        if (e) v = bb::mul(v, tw4096[e]);
-        sh[s * 272 + tid] = v;
-    }
+    for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? bb::mul(x[s], tw[s]) : x[s];
     __syncthreads();
 #pragma unroll
     for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * 272 + a0 * 16 + j];
     dft16<true>(x);
-    const u32 l = (tg << 4) + j;
-    const u32 ka1 = brev4(hi4);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) {
-        const u32 ka = ka1 + 16 * brev4(s);
-        const u32 e = ka * l;
-        u32 v = x[s];
-        if (e) v = bb::mul(v, bb_tw_split16(tw_hi, tw_lo, e));
-        dst[base + ((size_t)ka << LL) + j] = v;
+    for (u32 k = 0; k < 16; k++) {
+        dst[base + ((size_t)(ka1 + 16 * k) << LL) + j] = bb::mul(x[brev4(k)], f);
+        if (k < 15) f = bb::mul(f, ratio);
     }
 }
 
@@ -261,15 +256,12 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p2(const u32* __restrict_
     u32 x[16];
 #pragma unroll
     for (u32 b = 0; b < 16; b++) x[b] = src[cbase + ((size_t)ka << 12) + ((size_t)b << 8) + c];
+    u32 tw[16];
+    load_tw16(tw, tw4096, c);  // w_4096^-(c k_b)
     dft16<true>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) {
-        const u32 kb = brev4(s);
-        const u32 e = c * kb;  // w_4096^-(c k_b)
-        u32 v = x[s];
-        if (e) v = bb::mul(v, tw4096[e]);
-        dst[cbase + ((size_t)kb << 16) + ((size_t)ka << 8) + c] = v;
-    }
+    for (u32 s = 0; s < 16; s++)
+        dst[cbase + ((size_t)brev4(s) << 16) + ((size_t)ka << 8) + c] = s ? bb::mul(x[s], tw[s]) : x[s];
 }
 
 // P3: grid = ncols * 2^LB * 16; tile 16 k_a x 256 c (c = 16 c1 + c0); src [k_b][k_a][c];
@@ -288,14 +280,11 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p3(const u32* __restrict_
     // stage 1 thread = (ia = hi4, c0 = lo4): digit c1
 #pragma unroll
     for (u32 c1 = 0; c1 < 16; c1++) x[c1] = src[sbase + hi4 * 256 + c1 * 16 + lo4];
+    u32 tw[16];
+    load_tw16(tw, tw4096, lo4 * 16);  // w_256^-(k_c1 c0)
     dft16<true>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) {
-        const u32 e = brev4(s) * lo4 * 16;  // w_256^-(k_c1 c0)
-        u32 v = x[s];
-        if (e) v = bb::mul(v, tw4096[e]);
-        sh[s * 272 + lo4 * 17 + hi4] = v;  // [k_c1 slot][c0][ia], rows padded to 17
-    }
+    for (u32 s = 0; s < 16; s++) sh[s * 272 + lo4 * 17 + hi4] = s ? bb::mul(x[s], tw[s]) : x[s];  // [k_c1 slot][c0][ia], rows padded to 17
     __syncthreads();
     // stage 2 thread = (k_c1 slot = hi4, ia = lo4): digit c0
 #pragma unroll
