@@ -128,22 +128,25 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
 // ------------------------------------------------------------------ LDE pass A
 // LA = 8: grid = ncols * 256, tile 256 rows (a = 16 a1 + a0) x 16 columns.  Per coset: scale by s^(4096 a),
 // two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
-// 3 waves/SIMD (<= 168 VGPRs): the tile's 16 coefficients per thread stay in registers across the coset loop, so the
-// coefficients cross HBM once (re-reading them per coset measured the same time but 7x the fetch bytes).
+// 3 waves/SIMD (<= 168 VGPRs, no spills): the tile's 16 coefficients per thread stay in registers across the coset
+// loop, so the coefficients cross HBM once (re-reading them per coset measured the same time but 7x the fetch bytes).
 __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 L, u32 rate_bits,
                                                            const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
                                                            const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
                                                            const u64* __restrict__ pow_hi) {
     __shared__ u64 sh[16 * 272];
+    __shared__ u64 tw256[256];  // w_256^m: the stage-1 twiddles, read from LDS at their use (keeps 30 VGPRs free)
     const size_t col = blockIdx.x >> 8;
     const u32 tg = blockIdx.x & 255;
     const u32 tid = threadIdx.x, hi4 = tid >> 4, j = tid & 15;
     const u32 l = (tg << 4) + j;
     const size_t n = (size_t)1 << L;
     const u64* cin = coeffs + col * n + l;
+    tw256[tid] = tw4096[tid * 16];
     u64 orig[16];
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
+    __syncthreads();  // tw256 visible
     const u32 ncosets = 1u << rate_bits;
     const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
     const u64 f0 = tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // w_n^(k_a1 l)
@@ -155,11 +158,9 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
         const u64 sl = pow_lo[(size_t)c * 4096 + l];
 #pragma unroll
         for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul(orig[a1], x[a1]);
-        u64 tw[16];
-        load_tw16(tw, tw4096, hi4 * 16);  // w_256^(k_a1 a0)
         dft16<false>(x);
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul(x[s], tw[s]) : x[s];  // [k_a1 slot][a0][j]
+        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul(x[s], tw256[(brev4(s) * hi4) & 255]) : x[s];  // w_256^(k_a1 a0); [k_a1 slot][a0][j]
         __syncthreads();
         // stage 2 thread = (k_a1 slot = hi4, j): digit a0
 #pragma unroll
