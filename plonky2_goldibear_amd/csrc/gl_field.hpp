@@ -20,18 +20,38 @@ static constexpr u64 TWO_ADIC_GEN_32 = 1753635133440165772ULL;  // order 2^32
 __host__ __device__ __forceinline__ u64 canon(u64 x) { return x >= P ? x - P : x; }
 
 // a, b canonical -> canonical.  s - p == s + EPS (mod 2^64), so both the wrapped case (a + b >= 2^64) and the
-// s >= p case select s + EPS; written with carry builtins: 50 vs 64 cycles per wave-butterfly
-// (tools/microbench_addsub.hip).
+// s >= p case select s + EPS.  Device form on 32-bit limbs: four v_add(c)_co + two v_cndmask, all 32-bit-rate ops
+// (the u64 form lowers to two v_lshl_add_u64 and two v_cmp_u64, ~40 % more issue cycles per butterfly).
 __host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 c0, c1, d0, d1;
+    u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0);
+    u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
+    u32 t0 = __builtin_addc(s0, 0xFFFFFFFFu, 0u, &d0);
+    u32 t1 = __builtin_addc(s1, 0u, d0, &d1);
+    const bool sel = (c1 | d1) != 0;
+    return sel ? ((u64)t0 | ((u64)t1 << 32)) : ((u64)s0 | ((u64)s1 << 32));
+#else
     u64 s, u;
     bool c = __builtin_uaddll_overflow(a, b, &s);
     bool c2 = __builtin_uaddll_overflow(s, EPS, &u);
     return (c | c2) ? u : s;
+#endif
 }
 __host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 b0, b1, k;
+    u32 d0 = __builtin_subc((u32)a, (u32)b, 0u, &b0);
+    u32 d1 = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b0, &b1);
+    u32 m = 0u - b1;  // EPS when the difference wrapped: d - EPS == d + p (mod 2^64)
+    u32 e0 = __builtin_subc(d0, m, 0u, &k);
+    u32 e1 = d1 - k;
+    return (u64)e0 | ((u64)e1 << 32);
+#else
     u64 d;
     bool br = __builtin_usubll_overflow(a, b, &d);
     return d - (br ? EPS : 0);  // + p
+#endif
 }
 __host__ __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }
 

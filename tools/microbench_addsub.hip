@@ -43,8 +43,27 @@ __device__ __forceinline__ u64 sub2(u64 a, u64 b) {
         : "vcc");
     return ((u64)d1 << 32) | d0;
 }
-template <int V> __device__ __forceinline__ u64 addv(u64 a, u64 b) { return V == 0 ? add0(a, b) : (V == 1 ? add1(a, b) : add2(a, b)); }
-template <int V> __device__ __forceinline__ u64 subv(u64 a, u64 b) { return V == 0 ? sub0(a, b) : (V == 1 ? sub1(a, b) : sub2(a, b)); }
+// 32-bit limb versions with the carry builtins (what gl_field.hpp uses on the device)
+__device__ __forceinline__ u64 add3(u64 a, u64 b) {
+    u32 c0, c1, d0, d1;
+    u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0);
+    u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
+    u32 t0 = __builtin_addc(s0, 0xFFFFFFFFu, 0u, &d0);
+    u32 t1 = __builtin_addc(s1, 0u, d0, &d1);
+    const bool sel = (c1 | d1) != 0;
+    return sel ? ((u64)t0 | ((u64)t1 << 32)) : ((u64)s0 | ((u64)s1 << 32));
+}
+__device__ __forceinline__ u64 sub3(u64 a, u64 b) {
+    u32 b0, b1, k;
+    u32 d0 = __builtin_subc((u32)a, (u32)b, 0u, &b0);
+    u32 d1 = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b0, &b1);
+    u32 m = 0u - b1;
+    u32 e0 = __builtin_subc(d0, m, 0u, &k);
+    u32 e1 = d1 - k;
+    return (u64)e0 | ((u64)e1 << 32);
+}
+template <int V> __device__ __forceinline__ u64 addv(u64 a, u64 b) { return V == 0 ? add0(a, b) : (V == 1 ? add1(a, b) : (V == 2 ? add2(a, b) : add3(a, b))); }
+template <int V> __device__ __forceinline__ u64 subv(u64 a, u64 b) { return V == 0 ? sub0(a, b) : (V == 1 ? sub1(a, b) : (V == 2 ? sub2(a, b) : sub3(a, b))); }
 
 #define ITER 4096
 template <int V>
@@ -98,4 +117,4 @@ void run(const char* name) {
     printf("%-12s bad=%d %8.3f ms  %6.1f cycles per wave-butterfly (add+sub) per SIMD @2.4GHz\n", name, bad, ms, ms * 1e-3 * 2.4e9 / (bf / 64 / 1024));
     hipFree(d); hipFree(da); hipFree(db); hipFree(dout);
 }
-int main() { run<0>("compare"); run<1>("builtins"); run<2>("carry-asm"); return 0; }
+int main() { run<0>("compare"); run<1>("builtins u64"); run<2>("carry-asm"); run<3>("builtins u32 limbs"); return 0; }
