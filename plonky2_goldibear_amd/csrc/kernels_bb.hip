@@ -199,16 +199,15 @@ __global__ __launch_bounds__(256) void k_bb_merkle_leaves(const u32* __restrict_
     if (width <= 8) {  // hash_or_noop (plonk/config.rs:70-84), NUM_HASH_OUT_ELTS = 8
         for (u32 c = 0; c < width; c++) s[c] = cols[(size_t)c * col_stride + j];
     } else {
-        u32 c0 = 0;
-        for (; c0 + 8 <= width; c0 += 8) {
+        for (u32 c0 = 0; c0 < width; c0 += 8) {  // one loop, one inlined copy of the permutation
+            if (c0 + 8 <= width) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
-            poseidon2_bb::permute(s);
-        }
-        if (c0 < width) {
+                for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+                for (int i = 0; i < 8; i++)
+                    if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            }
             poseidon2_bb::permute(s);
         }
     }

@@ -25,17 +25,17 @@ __global__ __launch_bounds__(256) void k_gl_merkle_leaves(const u64* __restrict_
     if (width <= 4) {
         for (u32 c = 0; c < width; c++) s[c] = cols[(size_t)c * col_stride + j];
     } else {
-        u32 c0 = 0;
-        for (; c0 + 8 <= width; c0 += 8) {
+        // one loop, one inlined copy of the permutation (two copies are 72 KB of code against a 64 KB instruction cache)
+        for (u32 c0 = 0; c0 < width; c0 += 8) {
+            if (c0 + 8 <= width) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+                for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            }
             permute_lazy(s);  // capacity lanes stay lazy residues between absorptions
-        }
-        if (c0 < width) {
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
-            permute_lazy(s);
         }
     }
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * j);
