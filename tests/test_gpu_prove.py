@@ -105,3 +105,19 @@ def test_full_size_2pow20_proof_verifies(ctx):
     assert gpu.prove(w) == proof
     gpu.free()
     ctx.trim()
+
+
+@pytest.mark.parametrize("degree_bits", [15, 17, 18, 19])
+def test_odd_sizes_verify(ctx, degree_bits):
+    """Sizes whose NTTs take the mixed paths (v1 strided pass + radix-16 contiguous pass, FRI layers of every residue
+    mod 4): the proof must verify."""
+    circ = D.DummyCircuit(degree_bits, D.CircuitConfig(num_challenges=3))
+    gpu = _gpu_circuit(ctx, circ)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    proof = gpu.prove(circ.witness(seed=degree_bits))
+    stats = {}
+    assert D.verify(circ, proof, stats)
+    assert stats["merkle_paths"] == 28 * (4 + len(circ.reduction_arity_bits))
+    gpu.free()
+    ctx.trim()

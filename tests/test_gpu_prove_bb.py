@@ -122,3 +122,18 @@ def test_bb_inv_zero_perm_arg_and_retry(ctx):
     assert gpu.perm_arg_retries >= 1
     assert (w != bad).sum() == 1 and w[circ.cfg.num_wires - 1, circ.pi_row] != bad[circ.cfg.num_wires - 1, circ.pi_row]
     assert D.verify(circ, proof)
+
+
+@pytest.mark.parametrize("degree_bits,num_challenges", [(15, 7), (17, 8), (18, 8), (19, 9)])
+def test_bb_odd_sizes_verify(ctx, degree_bits, num_challenges):
+    circ = D.DummyCircuit(degree_bits, D.CircuitConfig.babybear(num_challenges), F=BB)
+    gpu = _gpu_circuit(ctx, circ)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    proof = gpu.prove(circ.witness(seed=degree_bits), random_wire=(circ.cfg.num_wires - 1, circ.pi_row),
+                      rng=np.random.default_rng(degree_bits))
+    stats = {}
+    assert D.verify(circ, proof, stats)
+    assert stats["merkle_paths"] == 28 * (4 + len(circ.reduction_arity_bits))
+    gpu.free()
+    ctx.trim()
