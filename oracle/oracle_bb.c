@@ -1,9 +1,11 @@
 /* TEST ORACLE - CPU restatement of the reference's BabyBear hot path (Poseidon2 width 16, H = 8).
  *
- * Test infrastructure only.  PARITY UNPINNED for the field constants: the reference takes BabyBear from
- * the un-vendored Plonky3 fork (p3-baby-bear / p3-monty-31 / p3-poseidon2, branch goldilocks_improvements,
- * no pinned rev) and holds no numeric KAT or serialized proof for this field.  What IS in
- * the reference and followed here line by line:
+ * Test infrastructure only.  PARITY PARTLY PINNED: the reference takes BabyBear from the un-vendored Plonky3 fork
+ * (p3-baby-bear / p3-monty-31 / p3-poseidon2, branch goldilocks_improvements, no pinned rev) and holds no serialized
+ * BabyBear proof.  Its one numeric BabyBear KAT (hash/poseidon2_risc0_babybear.rs:321-342, a width-24 Poseidon2) is
+ * restated at the end of this file and matches: that pins the modulus, the canonical arithmetic, the x^7 s-box and the
+ * Poseidon2 round order.  The generator 31, two_adic_generator(27) and the extension non-residue 11 stay UNPINNED
+ * (recalled from upstream, self-consistency only).  What IS in the reference and followed here line by line:
  *   plonky2/src/hash/poseidon2_babybear.rs:18-67            round counts and constants
  *   plonky2/src/gates/poseidon2_babybear.rs:41-42,609-672   permutation order (asserted == p3 at :958-1004)
  *   plonky2/src/gates/poseidon2_babybear.rs:736-740,787-832,903-917  add_rc, M_I, M_E, apply_mat4
@@ -277,3 +279,52 @@ void gbo_bb_coset_ifft(bb_t *v, unsigned lg_n, bb_t shift) {
 }
 void gbo_bb_powers(bb_t base, size_t n, bb_t *out) { bb_t x = 1; for (size_t i = 0; i < n; i++) { out[i] = x; x = bb_mul(x, base); } }
 void gbo_bb_scale_vec(const bb_t *a, bb_t k, size_t n, bb_t *out) { for (size_t i = 0; i < n; i++) out[i] = bb_mul(a[i], k); }
+
+/* ------------------------------------------------------------------ Poseidon2-24 with the RISC0 parameters.
+ * NOT on the hot path.  Restated because it is the one BabyBear computation the reference pins with numbers
+ * (hash/poseidon2_risc0_babybear.rs:321-342): matching that KAT pins, from the reference's own data, the modulus
+ * p = 2^31 - 2^27 + 1, the x^7 s-box and the generic Poseidon2 round order the width-16 permutation above shares
+ * (p3_poseidon2::Poseidon2::permute_mut drives both; restated in gates/poseidon2_risc0_babybear.rs:552-600).
+ * Layers: gates/poseidon2_risc0_babybear.rs:678-682 (add_rc), :731-736 (internal: sum + diag_i x_i),
+ * :738-766 (external: apply_hl_mat4 per block + column-class sums), :841-857 (apply_hl_mat4). */
+static const uint32_t R0_EXT_RC[8][24] = {BB_R0_EXTERNAL_CONSTANTS_LIST};
+static const uint32_t R0_INT_RC[21] = {BB_R0_INTERNAL_CONSTANTS_LIST};
+static const uint32_t R0_DIAG[24] = {BB_R0_M_INT_DIAG_HZN_LIST};
+
+static void r0_apply_hl_mat4(bb_t x[4]) {
+    bb_t t0 = bb_add(x[0], x[1]), t1 = bb_add(x[2], x[3]);
+    bb_t t2 = bb_add(bb_add(x[1], x[1]), t1), t3 = bb_add(bb_add(x[3], x[3]), t0);
+    bb_t t1_4 = bb_add(bb_add(t1, t1), bb_add(t1, t1)), t0_4 = bb_add(bb_add(t0, t0), bb_add(t0, t0));
+    bb_t t4 = bb_add(t1_4, t3), t5 = bb_add(t0_4, t2);
+    bb_t t6 = bb_add(t3, t5), t7 = bb_add(t2, t4);
+    x[0] = t6; x[1] = t5; x[2] = t7; x[3] = t4;
+}
+static void r0_external(bb_t s[24]) {
+    for (int i = 0; i < 24; i += 4) r0_apply_hl_mat4(s + i);
+    bb_t sums[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; k++) for (int j = 0; j < 24; j += 4) sums[k] = bb_add(sums[k], s[j + k]);
+    for (int i = 0; i < 24; i++) s[i] = bb_add(s[i], sums[i % 4]);
+}
+static void r0_internal(bb_t s[24]) {
+    bb_t sum = 0;
+    for (int i = 0; i < 24; i++) sum = bb_add(sum, s[i]);
+    for (int i = 0; i < 24; i++) s[i] = bb_add(sum, bb_mul(R0_DIAG[i], s[i]));
+}
+void gbo_bb_poseidon2_r0(const bb_t in[24], bb_t out[24]) {
+    bb_t s[24];
+    memcpy(s, in, sizeof s);
+    r0_external(s);
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 24; i++) s[i] = sbox7(bb_add(s[i], R0_EXT_RC[r][i]));
+        r0_external(s);
+    }
+    for (int r = 0; r < 21; r++) {
+        s[0] = sbox7(bb_add(s[0], R0_INT_RC[r]));
+        r0_internal(s);
+    }
+    for (int r = 4; r < 8; r++) {
+        for (int i = 0; i < 24; i++) s[i] = sbox7(bb_add(s[i], R0_EXT_RC[r][i]));
+        r0_external(s);
+    }
+    memcpy(out, s, sizeof s);
+}

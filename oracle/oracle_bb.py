@@ -32,6 +32,7 @@ def lib():
         L.gbo_bb_commit.restype = C.c_int
         L.gbo_bb_two_adic_generator.argtypes = [C.c_uint]
         L.gbo_bb_two_adic_generator.restype = C.c_uint32
+        L.gbo_bb_poseidon2_r0.argtypes = [_u32p, _u32p]
         L.gbo_bb_powers.argtypes = [C.c_uint32, C.c_size_t, _u32p]
         L.gbo_bb_scale_vec.argtypes = [_u32p, C.c_uint32, C.c_size_t, _u32p]
         _done = True
@@ -51,6 +52,13 @@ def _lg(n):
 def poseidon2(state):
     out = np.empty(16, dtype=np.uint32)
     lib().gbo_bb_poseidon2(_a(state), out)
+    return out
+
+
+def poseidon2_r0(state):
+    """Poseidon2-24 with the RISC0 parameters (hash/poseidon2_risc0_babybear.rs) - KAT pin only, not on the hot path"""
+    out = np.empty(24, dtype=np.uint32)
+    lib().gbo_bb_poseidon2_r0(_a(state), out)
     return out
 
 

@@ -52,6 +52,15 @@ def poseidon_kats():
     return vecs
 
 
+def poseidon2_r0_babybear_kat():
+    """hash/poseidon2_risc0_babybear.rs:321-342 test_against_r0_values: the one BabyBear known-answer test in the reference"""
+    src = read("plonky2/src/hash/poseidon2_risc0_babybear.rs")
+    body = src[src.index("fn test_against_r0_values"):src.index("poseidon2_r0.permute_mut(input)")]
+    nums = [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]{8}", body)]
+    assert len(nums) == 48, len(nums)
+    return {"input": nums[:24], "output": nums[24:]}
+
+
 def digest_kats():
     src = read("plonky2/src/recursion/recursive_verifier.rs")
     start = src.index("fn test_recursive_recursive_verifier_gl")
@@ -86,6 +95,7 @@ def main():
     kats = {
         "poseidon12": poseidon_kats(),
         "circuit_digest_gl": digest_kats(),
+        "poseidon2_r0_babybear": poseidon2_r0_babybear_kat(),
         "reverse_index_bits_256": bitrev_table(),
     }
     with open(os.path.join(OUT, "reference_kats.json"), "w") as f:

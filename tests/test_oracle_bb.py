@@ -111,3 +111,15 @@ def test_batch_matches_definition():
         lde = _eval_naive(b.polynomials[c].tolist(), lg_n + r, 31)
         for i in range(1 << (lg_n + r)):
             assert b.get_lde_values(i, 1)[c] == lde[i]
+
+
+def test_reference_kat_poseidon2_r0_babybear(kats):
+    """The one BabyBear known-answer test the reference holds (hash/poseidon2_risc0_babybear.rs:321-342,
+    `test_against_r0_values`): a width-24 Poseidon2 with RISC0's parameters.  It is not the hot path's hash, but it
+    runs on the same field code and the same Poseidon2 round order as the width-16 permutation (one generic
+    p3_poseidon2::Poseidon2 drives both), so matching it pins - from the reference's own numbers - the BabyBear
+    modulus, canonical arithmetic, the x^7 s-box and the round structure.  Still unpinned afterwards: the multiplicative
+    generator 31, the two-adic generator and the extension non-residue 11."""
+    k = kats["poseidon2_r0_babybear"]
+    out = B.poseidon2_r0(np.array(k["input"], dtype=np.uint32))
+    assert [int(x) for x in out] == k["output"]
