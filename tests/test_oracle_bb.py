@@ -123,3 +123,9 @@ def test_reference_kat_poseidon2_r0_babybear(kats):
     k = kats["poseidon2_r0_babybear"]
     out = B.poseidon2_r0(np.array(k["input"], dtype=np.uint32))
     assert [int(x) for x in out] == k["output"]
+
+
+def test_in_repo_monty_inverse_constant_matches_the_modulus():
+    # gates/poseidon2_babybear.rs:776,790 multiply by 943718400 "= 2^-32 mod p" (the Montgomery R^-1): a second in-repo
+    # number that only makes sense for p = 2^31 - 2^27 + 1
+    assert 943718400 * (1 << 32) % B.BB_P == 1
