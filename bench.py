@@ -77,7 +77,7 @@ def cpu_baseline_prove(log_n, num_challenges, sample_log_n, field="goldilocks"):
     w = circ.witness(seed=1)
     t0 = time.perf_counter()
     proof, _dbg = D.prove_cpu(circ, w)
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 - D.prove_cpu.last_cs_commit_seconds  # the oracle redoes build()'s constants/sigmas commit
     assert D.verify(circ, proof)
     scale = float(1 << (log_n - sample_log_n))
     return {
@@ -281,7 +281,7 @@ def main():
             cores = os.cpu_count() or 1
             if args.workload == "prove":
                 if sample is None:
-                    sample = max(8, min(log_n, 16, 10 + (cores.bit_length() - 1)))  # sized for ~10-30 s of CPU work
+                    sample = max(8, min(log_n, 17 if bb else 16, (11 if bb else 10) + (cores.bit_length() - 1)))  # ~10-30 s of CPU work
                 out["cpu_baseline"] = cpu_baseline_prove(log_n, args.challenges, sample, args.field)
             else:
                 if sample is None:

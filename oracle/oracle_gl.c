@@ -18,6 +18,8 @@
 #define W 12
 #define RATE 8
 #define HOUT 4
+
+double gbo_last_cs_commit_seconds = 0.0; /* set by the dummy-circuit provers (prover_impl.h) */
 #define N_PARTIAL 22
 #define HALF_FULL 4
 
@@ -38,17 +40,23 @@ static inline gl_t sbox(gl_t x) {
     return gl_mul(x3, x4);
 }
 
-/* hash/poseidon_goldilocks.rs:547-557 (mds_row_shf_field) applied to all rows (:584-595).
- * Entries are < 2^6 so the 12-term sum of 64x6-bit products fits 128 bits. */
+/* hash/poseidon_goldilocks.rs:547-557 (mds_row_shf_field) applied to all rows (:584-595), computed the way the
+ * reference's mds_layer does (:497-528): on the 32-bit halves of the state, whose 12-term sums with the < 2^6
+ * entries fit 64 bits, recombined as lo + 2^32 hi and reduced once. */
 static void mds_layer(gl_t s[W]) {
-    gl_t out[W];
-    for (int r = 0; r < W; r++) {
-        unsigned __int128 acc = 0;
-        for (int i = 0; i < W; i++) acc += (unsigned __int128)s[(i + r) % W] * MDS_CIRC[i];
-        acc += (unsigned __int128)s[r] * MDS_DIAG[r];
-        out[r] = gl_reduce128(acc);
+    uint64_t lo[2 * W], hi[2 * W];
+    for (int i = 0; i < W; i++) {
+        lo[i] = lo[i + W] = (uint32_t)s[i];
+        hi[i] = hi[i + W] = s[i] >> 32;
     }
-    memcpy(s, out, sizeof out);
+    for (int r = 0; r < W; r++) {
+        uint64_t sl = lo[r] * MDS_DIAG[r], sh = hi[r] * MDS_DIAG[r];
+        for (int i = 0; i < W; i++) {
+            sl += lo[i + r] * MDS_CIRC[i];
+            sh += hi[i + r] * MDS_CIRC[i];
+        }
+        s[r] = gl_reduce128((unsigned __int128)sl + ((unsigned __int128)sh << 32));
+    }
 }
 
 /* hash/poseidon_goldilocks.rs:802-809 */

@@ -160,6 +160,7 @@ def prove_cpu(circ, witness, public_inputs=()):
             out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError("oracle prover failed: rc=%d" % rc)
+    prove_cpu.last_cs_commit_seconds = C.c_double.in_dll(L, "gbo_last_cs_commit_seconds").value  # build() share of the call
     return out[: out_len.value].tobytes(), dbg
 
 
