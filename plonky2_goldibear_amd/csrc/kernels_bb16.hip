@@ -6,6 +6,8 @@
 // and layer is therefore the same as radix-2 (1/2); what the register form buys is one LDS round trip per four
 // layers instead of one per layer (v1, kernels_bb.hip: 34.8 ms of LDE per 2^20 proof, ~5x the VALU bound).
 // kernels_bb.hip's v1 passes remain the fallback for sizes other than 2^16 and 2^20.
+#include <algorithm>
+
 #include "bb_field.hpp"
 #include "kernels.hpp"
 
@@ -81,43 +83,59 @@ __device__ __forceinline__ void load_tw16(u32 (&tw)[16], const u32* __restrict__
 
 // ------------------------------------------------------------------ LDE pass B: 4096 contiguous points, 3 radix-16 stages
 // grid = number of 4096-tiles of `lde` (in place).  natural -> bit-reversed.
-__global__ __launch_bounds__(THREADS) void k_bb_lde_pb16(u32* __restrict__ lde, const u32* __restrict__ tw4096) {
+__global__ __launch_bounds__(THREADS) void k_bb_lde_pb16(u32* __restrict__ lde, const u32* __restrict__ tw4096, u32 ntiles) {
     __shared__ u32 sh[16 * 272];
-    u32* p = lde + ((size_t)blockIdx.x << 12);
     const u32 tid = threadIdx.x;
-    u32 x[16];
-    // stage 1: digit d2 (stride 256); this thread is (d1, d0) = tid
-#pragma unroll
-    for (u32 d = 0; d < 16; d++) x[d] = p[d * 256 + tid];
-    u32 tw[16];
-    load_tw16(tw, tw4096, tid);  // w_4096^(k2 (16 d1 + d0))
-    dft16<false>(x);
-#pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? bb::mul(x[s], tw[s]) : x[s];
-    __syncthreads();
-    // stage 2: digit d1; this thread is (k2 slot, d0)
     const u32 hi4 = tid >> 4, lo4 = tid & 15;
+    u32 tw1[16], tw2[16];
+    load_tw16(tw1, tw4096, tid);       // w_4096^(k2 (16 d1 + d0))
+    load_tw16(tw2, tw4096, lo4 * 16);  // w_256^(k1 d0)
+    u32 x[16], nx[16];
+    u32 tile = blockIdx.x;
+    if (tile < ntiles) {
+        const u32* p = lde + ((size_t)tile << 12);
 #pragma unroll
-    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 16 + lo4];
-    load_tw16(tw, tw4096, lo4 * 16);  // w_256^(k1 d0)
-    dft16<false>(x);
-    __syncthreads();
+        for (u32 d = 0; d < 16; d++) nx[d] = p[d * 256 + tid];
+    }
+    // persistent workgroups: the next tile's 16 loads are in flight while this tile is transformed
+    for (; tile < ntiles; tile += gridDim.x) {
+        u32* p = lde + ((size_t)tile << 12);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[hi4 * 272 + lo4 * 17 + s] = s ? bb::mul(x[s], tw[s]) : x[s];  // [k2 slot][d0][k1 slot], rows padded to 17
-    __syncthreads();
-    // stage 3: digit d0; this thread is (k2 slot, k1 slot)
+        for (u32 d = 0; d < 16; d++) x[d] = nx[d];
+        const u32 next = tile + gridDim.x;
+        if (next < ntiles) {
+            const u32* q = lde + ((size_t)next << 12);
 #pragma unroll
-    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 17 + lo4];
-    dft16<false>(x);
-    __syncthreads();
-    // x[s] belongs at tile position tid * 16 + s: transpose through LDS for a coalesced store
+            for (u32 d = 0; d < 16; d++) nx[d] = q[d * 256 + tid];
+        }
+        // stage 1: digit d2 (stride 256); this thread is (d1, d0) = tid
+        dft16<false>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[tid * 17 + s] = x[s];
-    __syncthreads();
+        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? bb::mul(x[s], tw1[s]) : x[s];
+        __syncthreads();
+        // stage 2: digit d1; this thread is (k2 slot, d0)
 #pragma unroll
-    for (u32 it = 0; it < 16; it++) {
-        const u32 q = it * 256 + tid;
-        p[q] = sh[(q >> 4) * 17 + (q & 15)];
+        for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 16 + lo4];
+        dft16<false>(x);
+        __syncthreads();
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) sh[hi4 * 272 + lo4 * 17 + s] = s ? bb::mul(x[s], tw2[s]) : x[s];  // [k2 slot][d0][k1 slot], rows padded to 17
+        __syncthreads();
+        // stage 3: digit d0; this thread is (k2 slot, k1 slot)
+#pragma unroll
+        for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 17 + lo4];
+        dft16<false>(x);
+        __syncthreads();
+        // x[s] belongs at tile position tid * 16 + s: transpose through LDS for a coalesced store
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) sh[tid * 17 + s] = x[s];
+        __syncthreads();
+#pragma unroll
+        for (u32 it = 0; it < 16; it++) {
+            const u32 q = it * 256 + tid;
+            p[q] = sh[(q >> 4) * 17 + (q & 15)];
+        }
+        __syncthreads();
     }
 }
 
@@ -331,7 +349,8 @@ bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables&
 }
 
 void bb_lde_pb_r16(u32* lde, size_t ntiles, const BbNttTables& t, hipStream_t stream) {
-    hipLaunchKernelGGL(k_bb_lde_pb16, dim3((u32)ntiles), dim3(THREADS), 0, stream, lde, t.tw4096_fwd);
+    const u32 grid = (u32)std::min<size_t>(ntiles, 256 * 7);  // persistent: 7 workgroups per CU (65 VGPRs, 17 KB LDS each)
+    hipLaunchKernelGGL(k_bb_lde_pb16, dim3(grid), dim3(THREADS), 0, stream, lde, t.tw4096_fwd, (u32)ntiles);
 }
 
 }  // namespace gbk
