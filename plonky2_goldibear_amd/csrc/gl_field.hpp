@@ -93,6 +93,22 @@ __device__ __forceinline__ u64 fold128(u32 r0, u32 r1, u32 hl, u32 hh) {
     u32 f1 = d1 + ch + k2;
     return (u64)f0 | ((u64)f1 << 32);
 }
+// The same for a five-limb value r0 + 2^32 r1 + 2^64 hl + 2^96 hh + 2^128 r4 with a small r4 (a sum of a few 128-bit
+// products): 2^128 = -2^32, so r4 2^32 joins the subtrahend hl + hh, whose high word becomes cs + r4 (r4 <= 2^31).
+__device__ __forceinline__ u64 fold160(u32 r0, u32 r1, u32 hl, u32 hh, u32 r4) {
+    u32 cs, c1, bw, B, k1, k2;
+    u32 s0 = __builtin_addc(hl, hh, 0u, &cs);
+    u32 s1 = cs + r4;
+    u32 a1 = __builtin_addc(r1, hl, 0u, &c1);
+    u32 d0 = __builtin_subc(r0, s0, 0u, &bw);
+    u32 d1 = __builtin_subc(a1, s1, bw, &B);
+    u32 mC = 0u - c1, mB = 0u - B;
+    u32 cl = __builtin_subc(mC, mB, 0u, &k1);
+    u32 ch = 0u - k1;
+    u32 f0 = __builtin_addc(d0, cl, 0u, &k2);
+    u32 f1 = d1 + ch + k2;
+    return (u64)f0 | ((u64)f1 << 32);
+}
 // a * b as four 32-bit limbs (four v_mad_u64_u32)
 __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& hl, u32& hh) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);

@@ -53,7 +53,27 @@ __device__ static const u64 RC[GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN] = {GL_POSEID
 __device__ static const u64 FP_FIRST[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST};
 __device__ static const u64 FP_RC[22] = {GL_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS_LIST};
 __device__ static const u64 FP_VS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_VS_LIST};
+// Two partial rounds at a time (see partial_rounds): the second round's w_hat row meets the first round's pending update
+// u_k v_k of the state, sum_i v_{k,i} w_hat_{k+1,i} = PAIR_C[k/2], a per-pair constant (compile-time, mod p).
+namespace raw {
+constexpr u64 VS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_VS_LIST};
+constexpr u64 cmulmod(u64 a, u64 b) { return (u64)(((u128)(a % gl::P) * (b % gl::P)) % gl::P); }
+struct PairTable {
+    u64 v[11];
+};
+constexpr PairTable pair_constants() {
+    PairTable t{};
+    for (int kk = 0; kk < 11; kk++) {
+        u64 acc = 0;
+        for (int i = 0; i < 11; i++) acc = (u64)(((u128)acc + cmulmod(VS[(2 * kk) * 11 + i], WHATS[(2 * kk + 1) * 11 + i])) % gl::P);
+        t.v[kk] = acc;
+    }
+    return t;
+}
+constexpr PairTable PAIR = pair_constants();
+}  // namespace raw
 __device__ static const LimbTable<22 * 11> WHATS_L = split22(raw::WHATS);
+__device__ static const LimbTable<11> PAIR_L = split22(raw::PAIR.v);
 __device__ static const LimbTable<11 * 11> INIT_L = split22(raw::INIT);
 
 // MDS_MATRIX_CIRC / MDS_MATRIX_DIAG (hash/poseidon_goldilocks.rs:301-302) as immediates
@@ -180,18 +200,46 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
         for (int r = 1; r < 12; r++) d.acc(t[r], INIT_L.v[(r - 1) * 11 + (c - 1)]);
         s[c] = d.finish();
     }
-    for (int k = 0; k < N_PARTIAL; k++) {
-        const Limb3* wh = WHATS_L.v + 11 * k;
-        const u64* vs = FP_VS + 11 * k;
-        u64 s0 = add_rc(sbox(s[0]), FP_RC[k]);
+    // Two rounds per iteration.  Round k updates s_i += u_k v_{k,i}; instead of reducing that and multiplying it into
+    // round k+1's dot product, round k+1 takes the block-start s_i plus u_k PAIR_C (linearity), and the state is updated
+    // once per pair: s_i + u_k v_{k,i} + u_{k+1} v_{k+1,i} summed as five limbs and folded once (11 folds per pair saved).
+    for (int kk = 0; kk < N_PARTIAL / 2; kk++) {
+        const int k = 2 * kk;
+        const Limb3* wh0 = WHATS_L.v + 11 * k;
+        const Limb3* wh1 = wh0 + 11;
+        const u64* vs0 = FP_VS + 11 * k;
+        const u64* vs1 = vs0 + 11;
         // mds_partial_layer_fast (:718-744): d = s0*(CIRC[0]+DIAG[0]) + sum_i s[i]*w_hat[i-1]
-        Dot d;
-        d.acc_small(s0, mds_circ(0) + MDS_DIAG0);
+        const u64 u0 = add_rc(sbox(s[0]), FP_RC[k]);
+        Dot d0;
+        d0.acc_small(u0, mds_circ(0) + MDS_DIAG0);
 #pragma unroll
-        for (int i = 1; i < 12; i++) d.acc(s[i], wh[i - 1]);
+        for (int i = 1; i < 12; i++) d0.acc(s[i], wh0[i - 1]);
+        const u64 u1 = add_rc(sbox(d0.finish()), FP_RC[k + 1]);
+        Dot d1;
+        d1.acc_small(u1, mds_circ(0) + MDS_DIAG0);
 #pragma unroll
-        for (int i = 1; i < 12; i++) s[i] = mul_add_lazy(s0, vs[i - 1], s[i]);
-        s[0] = d.finish();
+        for (int i = 1; i < 12; i++) d1.acc(s[i], wh1[i - 1]);
+        d1.acc(u0, PAIR_L.v[kk]);
+#pragma unroll
+        for (int i = 1; i < 12; i++) {
+            u32 p0, p1, p2, p3, q0, q1, q2, q3, c0, c1, c2, c3;
+            gl::mul_limbs(u0, vs0[i - 1], p0, p1, p2, p3);
+            gl::mul_limbs(u1, vs1[i - 1], q0, q1, q2, q3);
+            // p + q + s_i as five limbs
+            u32 r0 = __builtin_addc(p0, q0, 0u, &c0);
+            u32 r1 = __builtin_addc(p1, q1, c0, &c1);
+            u32 r2 = __builtin_addc(p2, q2, c1, &c2);
+            u32 r3 = __builtin_addc(p3, q3, c2, &c3);
+            u32 r4 = c3;
+            r0 = __builtin_addc(r0, (u32)s[i], 0u, &c0);
+            r1 = __builtin_addc(r1, (u32)(s[i] >> 32), c0, &c1);
+            r2 = __builtin_addc(r2, 0u, c1, &c2);
+            r3 = __builtin_addc(r3, 0u, c2, &c3);
+            r4 += c3;
+            s[i] = gl::fold160(r0, r1, r2, r3, r4);
+        }
+        s[0] = d1.finish();
     }
 }
 
