@@ -136,12 +136,32 @@ struct Dot {
         t0[0] += (u64)(u32)a * c;
         t1[0] += (u64)(u32)(a >> 32) * c;
     }
+    // value = sum_k (t0[k] + 2^32 t1[k]) 2^(22 k), every t < 2^58: assembled as five 32-bit limbs (each term is three limbs,
+    // shifted by 0 / 22 / 44 bits) and folded once (gl::fold160) - 18 instructions fewer than two 128-bit folds
     __device__ __forceinline__ u64 finish() const {
-        u128 g0 = (u128)t0[0] + ((u128)t0[1] << 22) + ((u128)t0[2] << 44);
-        u128 g1 = (u128)t1[0] + ((u128)t1[1] << 22) + ((u128)t1[2] << 44);
-        u64 r1 = reduce128_lazy(g1);
-        u128 v = g0 + ((u128)r1 << 32);  // < 2^103 + 2^96
-        return reduce128_lazy(v);
+        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            u32 c, c2;
+            const u32 a0 = (u32)t0[k];
+            const u32 a1 = __builtin_addc((u32)(t0[k] >> 32), (u32)t1[k], 0u, &c);
+            const u32 a2 = (u32)(t1[k] >> 32) + c;  // < 2^27
+            u32 b0, b1, b2, b3;
+            if (k == 0) {
+                b0 = a0; b1 = a1; b2 = a2; b3 = 0;
+            } else if (k == 1) {
+                b0 = a0 << 22; b1 = (a1 << 22) | (a0 >> 10); b2 = (a2 << 22) | (a1 >> 10); b3 = a2 >> 10;
+            } else {  // 44 = 32 + 12
+                b0 = 0; b1 = a0 << 12; b2 = (a1 << 12) | (a0 >> 20); b3 = (a2 << 12) | (a1 >> 20);
+                r4 += a2 >> 20;
+            }
+            r0 = __builtin_addc(r0, b0, 0u, &c);
+            r1 = __builtin_addc(r1, b1, c, &c2);
+            r2 = __builtin_addc(r2, b2, c2, &c);
+            r3 = __builtin_addc(r3, b3, c, &c2);
+            r4 += c2;
+        }
+        return gl::fold160(r0, r1, r2, r3, r4);
     }
 };
 
