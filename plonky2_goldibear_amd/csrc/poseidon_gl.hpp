@@ -170,7 +170,9 @@ struct Dot {
 // res[r] = sum_i s[(i+r)%12] * CIRC[i] + s[r]*DIAG[r]; entries < 2^6, so the two 32-bit halves
 // accumulate in 64 bits (< 2^41) and fold once: value = sl + 2^32 sh  (the decomposition of the
 // reference's mds_layer :497-528, without its FFT form).
-__device__ __forceinline__ void mds_layer(u64 (&s)[12]) {
+// `rc`: the constants of the layer that FOLLOWS (next round's constant layer), added into the unreduced sums as two
+// 32-bit halves - two 64-bit adds per word instead of a separate add-with-carry-fix after the fold.
+__device__ __forceinline__ void mds_layer(u64 (&s)[12], const u64* __restrict__ rc) {
     u32 lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -179,7 +181,8 @@ __device__ __forceinline__ void mds_layer(u64 (&s)[12]) {
     }
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        u64 sl = 0, sh = 0;
+        const u64 c = rc[r];
+        u64 sl = (u32)c, sh = c >> 32;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             sl += (u64)lo[(i + r) % 12] * mds_circ(i);
@@ -190,7 +193,7 @@ __device__ __forceinline__ void mds_layer(u64 (&s)[12]) {
             sh += (u64)hi[0] * MDS_DIAG0;
         }
         // sl + 2^32 (sh_lo + 2^32 sh_hi) = sl + sh_hi * EPS + (sh_lo << 32), sh_hi < 2^10
-        u64 t = sl + (sh >> 32) * EPS;  // < 2^43
+        u64 t = sl + (sh >> 32) * EPS;  // < 2^44
         u64 r2;
         bool cy = __builtin_uaddll_overflow(t, sh << 32, &r2);
         r2 += cy ? EPS : 0;
@@ -198,21 +201,24 @@ __device__ __forceinline__ void mds_layer(u64 (&s)[12]) {
     }
 }
 
-__device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0) {
+__device__ static const u64 ZERO_RC[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// Four full rounds; the state comes in with round0's constants already added, and leaves with `tail_rc` added (the
+// constants of whatever layer follows: FAST_PARTIAL_FIRST_ROUND_CONSTANT after the first half, nothing after the second).
+__device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0, const u64* __restrict__ tail_rc) {
     for (int k = 0; k < HALF_FULL; k++) {
-        const u64* rc = RC + 12 * (round0 + k);
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(add_rc(s[i], rc[i]));
-        mds_layer(s);
+        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        mds_layer(s, k + 1 < HALF_FULL ? RC + 12 * (round0 + k + 1) : tail_rc);
     }
 }
 
 __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
     // partial_first_constant_layer (:632-638) + mds_partial_layer_init (:657-683)
+    // partial_first_constant_layer (:632-638) was added by the last full round's MDS (full_rounds' tail_rc)
     u64 t[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = add_rc(s[i], FP_FIRST[i]);
-    s[0] = t[0];
+    for (int i = 0; i < 12; i++) t[i] = s[i];
 #pragma unroll
     for (int c = 1; c < 12; c++) {
         Dot d;
@@ -265,9 +271,13 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
 
 // state in: any u64 residues; state out: any u64 residues (call to_canonical before storing)
 __device__ __forceinline__ void permute_lazy(u64 (&s)[12]) {
-    full_rounds(s, 0);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], RC[i]);
+    full_rounds(s, 0, FP_FIRST);
     partial_rounds(s);
-    full_rounds(s, HALF_FULL + N_PARTIAL);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], RC[12 * (HALF_FULL + N_PARTIAL) + i]);
+    full_rounds(s, HALF_FULL + N_PARTIAL, ZERO_RC);
 }
 
 __device__ __forceinline__ void permute(u64 (&s)[12]) {
