@@ -121,3 +121,19 @@ def test_odd_sizes_verify(ctx, degree_bits):
     assert stats["merkle_paths"] == 28 * (4 + len(circ.reduction_arity_bits))
     gpu.free()
     ctx.trim()
+
+
+def test_repeated_proving_does_not_leak(ctx):
+    """The per-context pool reuses every temporary of prove(): device memory must be flat across proofs."""
+    import torch
+    circ = D.DummyCircuit(14)
+    gpu = _gpu_circuit(ctx, circ)
+    w = circ.witness(seed=3)
+    free = []
+    for i in range(24):
+        w[134, circ.pi_row] = 1000 + i
+        assert len(gpu.prove(w)) > 0
+        if i in (3, 23):
+            free.append(torch.cuda.mem_get_info(0)[0])
+    assert free[0] == free[1]
+    gpu.free()
