@@ -72,6 +72,35 @@ constexpr PairTable pair_constants() {
 }
 constexpr PairTable PAIR = pair_constants();
 }  // namespace raw
+// The last full round of the first half, its MDS, the first partial constant layer and mds_partial_layer_init are one
+// linear map of the s-box outputs y: s_c = sum_j y_j MI[j][c-1] + MI_K[c-1] (c >= 1), MI = MDS rows 1..11 times M_init.
+namespace raw {
+constexpr u64 CIRC[12] = {GL_POSEIDON_MDS_CIRC_LIST};
+constexpr u64 FIRST[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST};
+struct MergedInit {
+    u64 m[12 * 11];  // [j][c]
+    u64 k[11];
+};
+constexpr MergedInit merged_init() {
+    MergedInit t{};
+    for (int c = 0; c < 11; c++) {
+        for (int j = 0; j < 12; j++) {
+            u64 acc = 0;
+            for (int r = 1; r < 12; r++)  // MDS[r][j] = CIRC[(j - r) mod 12] for r >= 1 (DIAG is non-zero at r = 0 only)
+                acc = (u64)(((u128)acc + cmulmod(CIRC[(j - r + 12) % 12], INIT[(r - 1) * 11 + c])) % gl::P);
+            t.m[j * 11 + c] = acc;
+        }
+        u64 acc = 0;
+        for (int r = 1; r < 12; r++) acc = (u64)(((u128)acc + cmulmod(FIRST[r], INIT[(r - 1) * 11 + c])) % gl::P);
+        t.k[c] = acc;
+    }
+    return t;
+}
+constexpr MergedInit MERGED = merged_init();
+}  // namespace raw
+__device__ static const LimbTable<12 * 11> MI_L = split22(raw::MERGED.m);
+__device__ static const u64 MI_K[11] = {raw::MERGED.k[0], raw::MERGED.k[1], raw::MERGED.k[2], raw::MERGED.k[3], raw::MERGED.k[4], raw::MERGED.k[5],
+                                        raw::MERGED.k[6], raw::MERGED.k[7], raw::MERGED.k[8], raw::MERGED.k[9], raw::MERGED.k[10]};
 __device__ static const LimbTable<22 * 11> WHATS_L = split22(raw::WHATS);
 __device__ static const LimbTable<11> PAIR_L = split22(raw::PAIR.v);
 __device__ static const LimbTable<11 * 11> INIT_L = split22(raw::INIT);
@@ -82,6 +111,12 @@ __device__ __forceinline__ constexpr u32 mds_circ(int i) {
     return c[i];
 }
 static constexpr u32 MDS_DIAG0 = 8;
+namespace raw {
+constexpr u64 DIAG[12] = {GL_POSEIDON_MDS_DIAG_LIST};
+static_assert(DIAG[0] == MDS_DIAG0 && DIAG[1] == 0 && DIAG[2] == 0 && DIAG[3] == 0 && DIAG[4] == 0 && DIAG[5] == 0 && DIAG[6] == 0 &&
+                  DIAG[7] == 0 && DIAG[8] == 0 && DIAG[9] == 0 && DIAG[10] == 0 && DIAG[11] == 0,
+              "MDS_MATRIX_DIAG must be [8, 0, ...]");
+}  // namespace raw
 
 // ------------------------------------------------------------------ lazy arithmetic (any u64 in, any u64 out)
 
@@ -213,19 +248,46 @@ __device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0, const u64*
     }
 }
 
-__device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
-    // partial_first_constant_layer (:632-638) + mds_partial_layer_init (:657-683)
-    // partial_first_constant_layer (:632-638) was added by the last full round's MDS (full_rounds' tail_rc)
-    u64 t[12];
+// Rounds 0..3 of the permutation (state comes in with round 0's constants added) and everything linear up to the first
+// partial round: the fourth round's MDS, partial_first_constant_layer (:632-638) and mds_partial_layer_init (:657-683)
+// are applied as ONE 12 x 11 dot-product layer (MI_L, MI_K) plus the MDS's row 0 for the word that stays outside M_init.
+__device__ __forceinline__ void first_half(u64 (&s)[12]) {
+    for (int k = 0; k < HALF_FULL - 1; k++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = s[i];
+        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        mds_layer(s, RC + 12 * (k + 1));
+    }
+    u64 y[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) y[i] = sbox(s[i]);
+    {  // row 0 of the MDS + FAST_PARTIAL_FIRST_ROUND_CONSTANT[0]
+        const u64 c = FP_FIRST[0];
+        u64 sl = (u32)c, sh = c >> 32;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            sl += (u64)(u32)y[i] * mds_circ(i);
+            sh += (u64)(u32)(y[i] >> 32) * mds_circ(i);
+        }
+        sl += (u64)(u32)y[0] * MDS_DIAG0;
+        sh += (u64)(u32)(y[0] >> 32) * MDS_DIAG0;
+        u64 t = sl + (sh >> 32) * EPS, r2;
+        bool cy = __builtin_uaddll_overflow(t, sh << 32, &r2);
+        r2 += cy ? EPS : 0;
+        s[0] = r2;
+    }
 #pragma unroll
     for (int c = 1; c < 12; c++) {
         Dot d;
+        const u64 kc = MI_K[c - 1];
+        d.t0[0] = (u32)kc;
+        d.t1[0] = kc >> 32;
 #pragma unroll
-        for (int r = 1; r < 12; r++) d.acc(t[r], INIT_L.v[(r - 1) * 11 + (c - 1)]);
+        for (int j = 0; j < 12; j++) d.acc(y[j], MI_L.v[j * 11 + (c - 1)]);
         s[c] = d.finish();
     }
+}
+
+__device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
     // Two rounds per iteration.  Round k updates s_i += u_k v_{k,i}; instead of reducing that and multiplying it into
     // round k+1's dot product, round k+1 takes the block-start s_i plus u_k PAIR_C (linearity), and the state is updated
     // once per pair: s_i + u_k v_{k,i} + u_{k+1} v_{k+1,i} summed as five limbs and folded once (11 folds per pair saved).
@@ -273,7 +335,7 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
 __device__ __forceinline__ void permute_lazy(u64 (&s)[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], RC[i]);
-    full_rounds(s, 0, FP_FIRST);
+    first_half(s);
     partial_rounds(s);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], RC[12 * (HALF_FULL + N_PARTIAL) + i]);
