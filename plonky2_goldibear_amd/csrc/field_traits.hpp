@@ -28,6 +28,17 @@ struct GlF {
     static GB_HD T add(T a, T b) { return gl::add(a, b); }
     static GB_HD T sub(T a, T b) { return gl::sub(a, b); }
     static GB_HD T mul(T a, T b) { return gl::mul(a, b); }
+    // a * b as ANY u64 residue: for product chains whose result is only multiplied again (mul() accepts any u64 and
+    // canonicalises its own output; add / sub need canonical operands)
+    static GB_HD T mul_lazy(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        u32 r0, r1, hl, hh;
+        gl::mul_limbs(a, b, r0, r1, hl, hh);
+        return gl::fold128(r0, r1, hl, hh);
+#else
+        return gl::mul(a, b);
+#endif
+    }
     static GB_HD T inv(T a) { return gl::inv(a); }
     static GB_HD T pow(T a, u64 e) { return gl::pow(a, e); }
     static GB_HD T generator() { return gl::GENERATOR; }
@@ -59,6 +70,7 @@ struct BbF {
     static GB_HD T add(T a, T b) { return bb::add(a, b); }
     static GB_HD T sub(T a, T b) { return bb::sub(a, b); }
     static GB_HD T mul(T a, T b) { return bb::mul(a, b); }
+    static GB_HD T mul_lazy(T a, T b) { return bb::mul(a, b); }
     static GB_HD T inv(T a) { return bb::inv(a); }
     static GB_HD T pow(T a, u64 e) { return bb::pow(a, e); }
     static GB_HD T generator() { return bb::to_mont(bb::GENERATOR); }

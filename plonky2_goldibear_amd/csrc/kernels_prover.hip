@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void k_zs_quotients(ZsParams<F> p, const typen
             T w = witness[(size_t)j * n + row];
             T num = F::add(F::add(w, F::mul(bx, k_is[j])), gamma);
             T den = F::add(F::add(w, F::mul(beta, sigma[(size_t)j * n + row])), gamma);
-            np = F::mul(np, num);
-            dp = F::mul(dp, den);
+            np = F::mul_lazy(np, num);
+            dp = F::mul_lazy(dp, den);
         }
         N[m] = np;
         Dn[m] = dp;
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
                 for (u32 k = 0; k < C; k++) {
                     T num = F::add(F::add(wv[q], F::mul(bk[k * nr + w0 + q], x)), gammas[k]);
                     T den = F::add(F::add(wv[q], F::mul(betas[k], sg[q])), gammas[k]);
-                    np[k] = F::mul(np[k], num);
-                    dp[k] = F::mul(dp[k], den);
+                    np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
+                    dp[k] = F::mul_lazy(dp[k], den);
                 }
             }
         } else {
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
                 for (u32 k = 0; k < C; k++) {
                     T num = F::add(F::add(wv[q], F::mul(bk[k * nr + w0 + q], x)), gammas[k]);
                     T den = F::add(F::add(wv[q], F::mul(betas[k], sg[q])), gammas[k]);
-                    np[k] = F::mul(np[k], num);
-                    dp[k] = F::mul(dp[k], den);
+                    np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
+                    dp[k] = F::mul_lazy(dp[k], den);
                 }
             }
         }
