@@ -157,13 +157,15 @@ def main():
         random_wire = (nwires - 1, pi_row)
         rng = np.random.default_rng(1234 + rank)
         retries = [0]
+        last_proof = [None]
         del cs, cs_dev, wit
         torch.cuda.synchronize()
 
         def step():
             nonlocal proof_len
             if inflight == 1:
-                proof_len = len(lanes[0][1].prove(lanes[0][2], random_wire=random_wire, rng=rng))
+                last_proof[0] = lanes[0][1].prove(lanes[0][2], random_wire=random_wire, rng=rng)
+                proof_len = len(last_proof[0])
                 retries[0] += lanes[0][1].perm_arg_retries
                 return
             out = [0] * inflight
@@ -275,6 +277,8 @@ def main():
             "merkle": {"permutations": perms, "Gperm_per_s": perms / (merkle_ms * 1e-3) / 1e9},
         }
         if args.workload == "prove":
+            if last_proof[0] is not None:  # outside the timed region: the library's own host-side verifier (gb_verify)
+                out["verified"] = bool(lanes[0][1].verify(last_proof[0]))
             out["perm_arg_retries"] = retries[0]  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the driver's contract)
             sample = args.cpu_sample_log_n

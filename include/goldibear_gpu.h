@@ -154,6 +154,14 @@ gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_ou
 gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uint64_t* public_inputs,
                    size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);
 
+/* verify() of a proof produced for this circuit (plonk/verifier.rs:17-128, fri/verifier.rs:67-250,
+ * plonk/get_challenges.rs:26-101), restated for the dummy gate set and run on the HOST like the reference's verifier: the
+ * Fiat-Shamir replay, vanishing(zeta) == Z_H(zeta) * quotient(zeta), the proof of work, every Merkle path and the FRI
+ * folding checks.  GB_OK = the proof verifies; GB_ERR_VERIFY names the failed check in gb_last_error; GB_ERR_INVALID =
+ * malformed bytes. */
+#define GB_ERR_VERIFY 19
+gb_status gb_verify(gb_circuit* c, const void* proof, size_t proof_len);
+
 /* fri_proof_of_work (fri/prover.rs:136-188) on its own, for a host that keeps the Challenger: sponge_state is the
  * duplex state with the pending input buffer already written over lanes 0..witness_pos-1 (`duplex_intermediate_state`,
  * :165-167; [12] u64 / [16] u32 canonical), witness_pos = input_buffer.len().  Returns the MINIMUM candidate whose

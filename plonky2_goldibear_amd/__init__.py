@@ -5,6 +5,6 @@ native     ctypes binding of that ABI (no fallback: raises if the library is mis
 polynomial_batch  host-side mirror of PolynomialBatch / MerkleTree (fri/oracle.rs, hash/merkle_tree.rs)
 """
 from .native import GB_BABYBEAR, GB_GOLDILOCKS, GoldibearError, ShapeError  # noqa: F401
-from .native import PermArgZeroError, TooManyPermArgFailuresError  # noqa: F401
+from .native import PermArgZeroError, TooManyPermArgFailuresError, VerifyError  # noqa: F401
 from .polynomial_batch import GpuContext, MerkleTree, PolynomialBatch  # noqa: F401
 from .prover import CircuitData  # noqa: F401

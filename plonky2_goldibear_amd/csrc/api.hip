@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <new>
 #include <algorithm>
@@ -735,3 +736,4 @@ gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uin
 }  // extern "C"
 
 #include "prover_host.inc"
+#include "verifier_host.inc"

@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 GB_OK, GB_ERR_INVALID, GB_ERR_HIP, GB_ERR_OOM, GB_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-GB_ERR_PERM_ARG_ZERO, GB_ERR_OPENING_IN_SUBGROUP, GB_ERR_BUFFER_TOO_SMALL = 16, 17, 18
+GB_ERR_PERM_ARG_ZERO, GB_ERR_OPENING_IN_SUBGROUP, GB_ERR_BUFFER_TOO_SMALL, GB_ERR_VERIFY = 16, 17, 18, 19
 GB_GOLDILOCKS, GB_BABYBEAR = 0, 1
 GB_INPUT_HOST, GB_INPUT_DEVICE = 0, 1
 GB_SALT_SIZE = 4
@@ -40,6 +40,7 @@ SIGNATURES = {
     "gb_batch_leaves": (_i32, [_vp, _vp]),
     "gb_batch_device_ptrs": (_i32, [_vp, _pvp, _pvp, _pvp]),
     "gb_batch_eval_ext": (_i32, [_vp, _vp, _vp]),
+    "gb_verify": (_i32, [_vp, _vp, _sz]),
     "gb_pow_grind": (_i32, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gb_permute": (_i32, [_vp, _u32, _vp, _vp, _u64]),
     "gb_circuit_create": (_i32, [_vp, _vp, _vp, _vp, _u32, _pvp]),
@@ -91,6 +92,10 @@ class TooManyPermArgFailuresError(GoldibearError):
     the circuit has no random wire to re-randomise."""
 
 
+class VerifyError(GoldibearError):
+    """GB_ERR_VERIFY: the proof does not verify (the message names the failed check)."""
+
+
 class ShapeError(GoldibearError, ValueError):
     """GB_ERR_INVALID: where the reference would assert!/panic! on a shape violation."""
 
@@ -100,5 +105,5 @@ def check(status, ctx_handle=None):
         return
     msg = load().gb_last_error(ctx_handle)
     msg = msg.decode() if msg else ""
-    cls = {GB_ERR_INVALID: ShapeError, GB_ERR_PERM_ARG_ZERO: PermArgZeroError}.get(status, GoldibearError)
+    cls = {GB_ERR_INVALID: ShapeError, GB_ERR_PERM_ARG_ZERO: PermArgZeroError, GB_ERR_VERIFY: VerifyError}.get(status, GoldibearError)
     raise cls(status, msg)

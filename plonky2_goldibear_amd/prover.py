@@ -114,6 +114,13 @@ class CircuitData:
         del keep
         return self._proof_buf[: n.value].tobytes()
 
+    def verify(self, proof_bytes):
+        """CircuitData::verify (plonk/circuit_data.rs:290-300 -> plonk/verifier.rs:17-128): True, or raises VerifyError naming
+        the failed check (ShapeError for malformed bytes).  Runs on the host, like the reference's verifier."""
+        buf = np.frombuffer(bytes(proof_bytes), dtype=np.uint8)
+        N.check(self._lib.gb_verify(self.handle, buf.ctypes.data, buf.size), self.ctx.handle)
+        return True
+
     def free(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self._lib.gb_circuit_free(self.handle)

@@ -102,6 +102,7 @@ def test_full_size_2pow20_proof_verifies(ctx):
     stats = {}
     assert D.verify(circ, proof, stats)
     assert stats["merkle_paths"] == 28 * (4 + 4)
+    assert gpu.verify(proof)  # the product's own host-side verifier (gb_verify)
     assert gpu.prove(w) == proof
     gpu.free()
     ctx.trim()

@@ -86,6 +86,7 @@ def test_bb_config4_2p20_rows(ctx):
     stats = {}
     assert D.verify(circ, proof, stats)
     assert stats["merkle_paths"] == 28 * (4 + 5)
+    assert gpu.verify(proof)  # the product's own host-side verifier (gb_verify)
 
 
 def test_bb_error_behaviour(ctx):
