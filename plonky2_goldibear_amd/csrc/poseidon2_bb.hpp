@@ -32,32 +32,89 @@ namespace raw {
 constexpr u32 EXT[128] = {BB_POSEIDON2_EXTERNAL_CONSTANTS_LIST};
 constexpr u32 INT[13] = {BB_POSEIDON2_INTERNAL_CONSTANTS_LIST};
 }  // namespace raw
-__device__ static const MontTable<128> EXT_RC = to_mont_table(raw::EXT);
-__device__ static const MontTable<13> INT_RC = to_mont_table(raw::INT);
+// ------------------------------------------------------------------ scale tracking
+// The external linear layer is computed on UNREDUCED 64-bit sums (every word of a layer is a sum of at most 35 inputs
+// < p, plus the next round's constant) and brought back with ONE Montgomery reduction per word.  That reduction
+// multiplies by R^-1, so a word holds kappa * R * x for a scale kappa that is the same for all 16 words and is known at
+// compile time: the layer turns kappa into kappa / R, the s-box into kappa^7.  Round constants are pre-multiplied by
+// the scale in force, the single s-box of an internal round is followed by one multiplication by kappa^-6 to bring
+// word 0 back to the common scale, and the last step of the permutation multiplies by 1 / kappa_final.
+// Canonical add = 3 instructions, so the 68 additions + 16 constant additions of a layer (252) become 76 one-instruction
+// 64-bit adds / mads + 16 reductions of 5 (156).
+namespace plan {
+constexpr u32 cmul(u32 a, u32 b) { return (u32)((u64)a * b % bb::P); }
+constexpr u32 cpow(u32 b, u64 e) {
+    u32 r = 1;
+    while (e) {
+        if (e & 1) r = cmul(r, b);
+        b = cmul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+constexpr u32 cinv(u32 a) { return cpow(a, bb::P - 2); }
+constexpr u32 R = (u32)(((u64)1 << 32) % bb::P);
+constexpr u32 RINV = cinv(R);
+struct Plan {
+    u32 ext[8][16];  // Montgomery form of kappa * EXTERNAL_CONSTANTS[r], kappa = the scale when round r's constants are added
+    u32 in[13];      // Montgomery form of kappa * INTERNAL_CONSTANTS[r]
+    u32 fix6;        // Montgomery form of kappa^-6 during the internal rounds
+    u32 out;         // Montgomery form of 1 / kappa_final
+};
+constexpr Plan make_plan() {
+    Plan p{};
+    u32 k = 1;
+    auto fill_ext = [&](int r, u32 kappa) {
+        for (int i = 0; i < 16; i++) p.ext[r][i] = cmul(cmul(kappa, raw::EXT[16 * r + i] % bb::P), R);
+    };
+    // initial layer adds round 0's constants; it is followed by rounds 0..3, each: s-box, layer (+ next constants)
+    fill_ext(0, k);
+    k = cmul(k, RINV);
+    for (int r = 0; r < 4; r++) {
+        k = cpow(k, 7);
+        if (r < 3) fill_ext(r + 1, k);
+        k = cmul(k, RINV);
+    }
+    for (int r = 0; r < 13; r++) p.in[r] = cmul(cmul(k, raw::INT[r] % bb::P), R);
+    p.fix6 = cmul(cinv(cpow(k, 6)), R);
+    fill_ext(4, k);  // added canonically before round 4's s-box
+    for (int r = 4; r < 8; r++) {
+        k = cpow(k, 7);
+        if (r < 7) fill_ext(r + 1, k);
+        k = cmul(k, RINV);
+    }
+    p.out = cmul(cinv(k), R);
+    return p;
+}
+constexpr Plan PLAN = make_plan();
+}  // namespace plan
+__device__ static const plan::Plan PLAN = plan::PLAN;
+__device__ static const u32 ZERO16[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 __device__ __forceinline__ u32 sbox7(u32 x) {
     u32 x2 = bb::sqr(x), x4 = bb::sqr(x2), x3 = bb::mul(x, x2);
     return bb::mul(x3, x4);
 }
 
-__device__ __forceinline__ void apply_mat4(u32& a, u32& b, u32& c, u32& d) {
-    u32 t01 = bb::add(a, b), t23 = bb::add(c, d), t0123 = bb::add(t01, t23);
-    u32 t01123 = bb::add(t0123, b), t01233 = bb::add(t0123, d);
-    u32 n3 = bb::add(t01233, bb::add(a, a));
-    u32 n1 = bb::add(t01123, bb::add(c, c));
-    u32 n0 = bb::add(t01123, t01);
-    u32 n2 = bb::add(t01233, t23);
-    a = n0; b = n1; c = n2; d = n3;
-}
-
-__device__ __forceinline__ void external_layer(u32 (&s)[16]) {
+// M_E (gates/poseidon2_babybear.rs:804-832, 903-917): per 4-block [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], i.e.
+// n0 = T + a + 2b, n1 = T + b + 2c, n2 = T + c + 2d, n3 = T + d + 2a with T = a + b + c + d, then every word gets the sum
+// of its column class.  All in 64 bits, `c` (the next constants, scaled) added, one reduction per word (scale / R).
+__device__ __forceinline__ void external_layer(u32 (&s)[16], const u32* __restrict__ c) {
+    u64 n[16];
 #pragma unroll
-    for (int i = 0; i < 16; i += 4) apply_mat4(s[i], s[i + 1], s[i + 2], s[i + 3]);
-    u32 sums[4];
+    for (int b = 0; b < 16; b += 4) {
+        const u64 x0 = s[b], x1 = s[b + 1], x2 = s[b + 2], x3 = s[b + 3];
+        const u64 t = x0 + x1 + x2 + x3;
+        n[b] = t + x0 + 2 * x1;
+        n[b + 1] = t + x1 + 2 * x2;
+        n[b + 2] = t + x2 + 2 * x3;
+        n[b + 3] = t + x3 + 2 * x0;
+    }
+    u64 sums[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) sums[k] = bb::add(bb::add(s[k], s[4 + k]), bb::add(s[8 + k], s[12 + k]));
+    for (int k = 0; k < 4; k++) sums[k] = n[k] + n[4 + k] + n[8 + k] + n[12 + k];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = bb::add(s[i], sums[i & 3]);
+    for (int i = 0; i < 16; i++) s[i] = bb::reduce(n[i] + sums[i & 3] + c[i]);  // < 36 p
 }
 
 __device__ __forceinline__ void internal_layer(u32 (&s)[16]) {
@@ -73,25 +130,28 @@ __device__ __forceinline__ void internal_layer(u32 (&s)[16]) {
     for (int i = 0; i < 15; i++) s[i + 1] = bb::add(full, bb::reduce((u64)s[i + 1] << SH[i]));  // (s_{i+1} 2^-32) 2^k
 }
 
-// state: Montgomery form in, Montgomery form out
+// state: Montgomery form in, Montgomery form out (scale 1 on both sides)
 __device__ __forceinline__ void permute(u32 (&s)[16]) {
-    external_layer(s);
+    external_layer(s, PLAN.ext[0]);
     for (int r = 0; r < 4; r++) {
-        const u32* rc = EXT_RC.v + 16 * r;
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7(bb::add(s[i], rc[i]));
-        external_layer(s);
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
+        external_layer(s, r < 3 ? PLAN.ext[r + 1] : ZERO16);
     }
     for (int r = 0; r < 13; r++) {
-        s[0] = sbox7(bb::add(s[0], INT_RC.v[r]));
+        s[0] = bb::mul(sbox7(bb::add(s[0], PLAN.in[r])), PLAN.fix6);
         internal_layer(s);
     }
-    for (int r = 4; r < 8; r++) {
-        const u32* rc = EXT_RC.v + 16 * r;
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7(bb::add(s[i], rc[i]));
-        external_layer(s);
+    for (int i = 0; i < 16; i++) s[i] = bb::add(s[i], PLAN.ext[4][i]);
+    for (int r = 4; r < 8; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
+        external_layer(s, r < 7 ? PLAN.ext[r + 1] : ZERO16);
     }
+    const u32 out = PLAN.out;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = bb::mul(s[i], out);
 }
 
 }  // namespace poseidon2_bb
