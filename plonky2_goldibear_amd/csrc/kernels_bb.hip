@@ -196,24 +196,35 @@ __global__ __launch_bounds__(256) void k_bb_merkle_leaves(const u32* __restrict_
     u32 s[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = 0;
-    if (width <= 8) {  // hash_or_noop (plonk/config.rs:70-84), NUM_HASH_OUT_ELTS = 8
-        for (u32 c = 0; c < width; c++) s[c] = cols[(size_t)c * col_stride + j];
-    } else {
-        for (u32 c0 = 0; c0 < width; c0 += 8) {  // one loop, one inlined copy of the permutation
-            if (c0 + 8 <= width) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
-            }
-            poseidon2_bb::permute(s);
-        }
-    }
     uint4* o = reinterpret_cast<uint4*>(out + 8 * j);
-    o[0] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
-    o[1] = make_uint4(bb::from_mont(s[4]), bb::from_mont(s[5]), bb::from_mont(s[6]), bb::from_mont(s[7]));
+    if (width <= 8) {  // hash_or_noop (plonk/config.rs:70-84), NUM_HASH_OUT_ELTS = 8
+        for (u32 c = 0; c < width; c++) s[c] = bb::from_mont(cols[(size_t)c * col_stride + j]);
+        o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+        o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+        return;
+    }
+    for (u32 c0 = 0; c0 < width; c0 += 8) {  // one loop, one inlined copy of the permutation
+        if (c0) {  // the capacity words go on at scale 1; the rate words are overwritten (partially in the last absorption)
+#pragma unroll
+            for (int i = 8; i < 16; i++) s[i] = poseidon2_bb::renorm(s[i]);
+            if (c0 + 8 > width) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) s[i] = poseidon2_bb::renorm(s[i]);
+            }
+        }
+        if (c0 + 8 <= width) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+        }
+        poseidon2_bb::permute_scaled(s);
+    }
+    using poseidon2_bb::canonical_out;
+    o[0] = make_uint4(canonical_out(s[0]), canonical_out(s[1]), canonical_out(s[2]), canonical_out(s[3]));
+    o[1] = make_uint4(canonical_out(s[4]), canonical_out(s[5]), canonical_out(s[6]), canonical_out(s[7]));
 }
 __global__ __launch_bounds__(256) void k_bb_merkle_level(const u32* __restrict__ in, u32* __restrict__ out, u64 num_out) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,10 +234,11 @@ __global__ __launch_bounds__(256) void k_bb_merkle_level(const u32* __restrict__
     u32 s[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
 #pragma unroll
     for (int k = 0; k < 16; k++) s[k] = bb::to_mont(s[k]);
-    poseidon2_bb::permute(s);
+    poseidon2_bb::permute_scaled(s);
+    using poseidon2_bb::canonical_out;
     uint4* o = reinterpret_cast<uint4*>(out + 8 * i);
-    o[0] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
-    o[1] = make_uint4(bb::from_mont(s[4]), bb::from_mont(s[5]), bb::from_mont(s[6]), bb::from_mont(s[7]));
+    o[0] = make_uint4(canonical_out(s[0]), canonical_out(s[1]), canonical_out(s[2]), canonical_out(s[3]));
+    o[1] = make_uint4(canonical_out(s[4]), canonical_out(s[5]), canonical_out(s[6]), canonical_out(s[7]));
 }
 __global__ __launch_bounds__(256) void k_bb_permute(const u32* __restrict__ in, u32* __restrict__ out, u64 count) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

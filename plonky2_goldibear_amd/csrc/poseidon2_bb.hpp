@@ -58,8 +58,9 @@ constexpr u32 RINV = cinv(R);
 struct Plan {
     u32 ext[8][16];  // Montgomery form of kappa * EXTERNAL_CONSTANTS[r], kappa = the scale when round r's constants are added
     u32 in[13];      // Montgomery form of kappa * INTERNAL_CONSTANTS[r]
-    u32 fix6;        // Montgomery form of kappa^-6 during the internal rounds
-    u32 out;         // Montgomery form of 1 / kappa_final
+    u32 fix6;        // kappa^-6 (plain) during the internal rounds: mont(s-box output, fix6) = (word 0 at the common scale) * 2^-32
+    u32 out;         // Montgomery form of 1 / kappa_final: mont(word, out) = Montgomery form at scale 1
+    u32 out_canon;   // 1 / kappa_final (plain): mont(word, out_canon) = the canonical value
 };
 constexpr Plan make_plan() {
     Plan p{};
@@ -76,7 +77,7 @@ constexpr Plan make_plan() {
         k = cmul(k, RINV);
     }
     for (int r = 0; r < 13; r++) p.in[r] = cmul(cmul(k, raw::INT[r] % bb::P), R);
-    p.fix6 = cmul(cinv(cpow(k, 6)), R);
+    p.fix6 = cinv(cpow(k, 6));
     fill_ext(4, k);  // added canonically before round 4's s-box
     for (int r = 4; r < 8; r++) {
         k = cpow(k, 7);
@@ -84,6 +85,7 @@ constexpr Plan make_plan() {
         k = cmul(k, RINV);
     }
     p.out = cmul(cinv(k), R);
+    p.out_canon = cinv(k);
     return p;
 }
 constexpr Plan PLAN = make_plan();
@@ -117,31 +119,32 @@ __device__ __forceinline__ void external_layer(u32 (&s)[16], const u32* __restri
     for (int i = 0; i < 16; i++) s[i] = bb::reduce(n[i] + sums[i & 3] + c[i]);  // < 36 p
 }
 
-__device__ __forceinline__ void internal_layer(u32 (&s)[16]) {
+// One internal round: s0 <- (s0 + rc)^7, then M_I (gates/poseidon2_babybear.rs:787-802).  `rc` is scaled (PLAN.in);
+// the s-box leaves word 0 at scale kappa^7, and y0 = (word 0 at the common scale) * 2^-32 comes out of ONE Montgomery
+// multiplication by kappa^-6.
+__device__ __forceinline__ void internal_round(u32 (&s)[16], u32 rc) {
     constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};  // gates/poseidon2_babybear.rs:41-42
     // part = sum_{i>=1} s_i 2^-32: the reduction is linear, so reduce the 35-bit sum once instead of 15 words
     const u64 sum = (u64)(s[1] + s[2]) + (u64)(s[3] + s[4]) + (u64)(s[5] + s[6]) + (u64)(s[7] + s[8]) + (u64)(s[9] + s[10]) +
                     (u64)(s[11] + s[12]) + (u64)(s[13] + s[14]) + (u64)s[15];  // words < 2^31: the pair sums fit 32 bits
     const u32 part = bb::reduce(sum);
-    const u32 y0 = bb::reduce((u64)s[0]);
+    const u32 y0 = bb::mul(sbox7(bb::add(s[0], rc)), PLAN.fix6);
     const u32 full = bb::add(part, y0);
     s[0] = bb::sub(part, y0);
 #pragma unroll
     for (int i = 0; i < 15; i++) s[i + 1] = bb::add(full, bb::reduce((u64)s[i + 1] << SH[i]));  // (s_{i+1} 2^-32) 2^k
 }
 
-// state: Montgomery form in, Montgomery form out (scale 1 on both sides)
-__device__ __forceinline__ void permute(u32 (&s)[16]) {
+// The permutation up to the final common scale kappa_final: finish every word that is used afterwards with
+// renorm() (-> Montgomery form at scale 1, e.g. the capacity words of a sponge) or canonical_out() (-> canonical value).
+__device__ __forceinline__ void permute_scaled(u32 (&s)[16]) {
     external_layer(s, PLAN.ext[0]);
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
         external_layer(s, r < 3 ? PLAN.ext[r + 1] : ZERO16);
     }
-    for (int r = 0; r < 13; r++) {
-        s[0] = bb::mul(sbox7(bb::add(s[0], PLAN.in[r])), PLAN.fix6);
-        internal_layer(s);
-    }
+    for (int r = 0; r < 13; r++) internal_round(s, PLAN.in[r]);
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = bb::add(s[i], PLAN.ext[4][i]);
     for (int r = 4; r < 8; r++) {
@@ -149,9 +152,15 @@ __device__ __forceinline__ void permute(u32 (&s)[16]) {
         for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
         external_layer(s, r < 7 ? PLAN.ext[r + 1] : ZERO16);
     }
-    const u32 out = PLAN.out;
+}
+__device__ __forceinline__ u32 renorm(u32 x) { return bb::mul(x, PLAN.out); }
+__device__ __forceinline__ u32 canonical_out(u32 x) { return bb::mul(x, PLAN.out_canon); }
+
+// state: Montgomery form in, Montgomery form out (scale 1 on both sides)
+__device__ __forceinline__ void permute(u32 (&s)[16]) {
+    permute_scaled(s);
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = bb::mul(s[i], out);
+    for (int i = 0; i < 16; i++) s[i] = renorm(s[i]);
 }
 
 }  // namespace poseidon2_bb
