@@ -122,17 +122,20 @@ __device__ __forceinline__ void external_layer(u32 (&s)[16], const u32* __restri
 // One internal round: s0 <- (s0 + rc)^7, then M_I (gates/poseidon2_babybear.rs:787-802).  `rc` is scaled (PLAN.in);
 // the s-box leaves word 0 at scale kappa^7, and y0 = (word 0 at the common scale) * 2^-32 comes out of ONE Montgomery
 // multiplication by kappa^-6.
+// Words 1..15 are LAZY inside the internal rounds: full + v_i < 2p is kept unreduced (it only feeds a Montgomery
+// reduction, which takes any 32-bit word, and the 64-bit sum); they are brought back below p once after the last round.
 __device__ __forceinline__ void internal_round(u32 (&s)[16], u32 rc) {
     constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};  // gates/poseidon2_babybear.rs:41-42
-    // part = sum_{i>=1} s_i 2^-32: the reduction is linear, so reduce the 35-bit sum once instead of 15 words
-    const u64 sum = (u64)(s[1] + s[2]) + (u64)(s[3] + s[4]) + (u64)(s[5] + s[6]) + (u64)(s[7] + s[8]) + (u64)(s[9] + s[10]) +
-                    (u64)(s[11] + s[12]) + (u64)(s[13] + s[14]) + (u64)s[15];  // words < 2^31: the pair sums fit 32 bits
+    // part = sum_{i>=1} s_i 2^-32: the reduction is linear, so reduce the 36-bit sum once instead of 15 words
+    u64 sum = s[1];
+#pragma unroll
+    for (int i = 2; i < 16; i++) sum += s[i];  // words < 2p < 2^32
     const u32 part = bb::reduce(sum);
     const u32 y0 = bb::mul(sbox7(bb::add(s[0], rc)), PLAN.fix6);
     const u32 full = bb::add(part, y0);
     s[0] = bb::sub(part, y0);
 #pragma unroll
-    for (int i = 0; i < 15; i++) s[i + 1] = bb::add(full, bb::reduce((u64)s[i + 1] << SH[i]));  // (s_{i+1} 2^-32) 2^k
+    for (int i = 0; i < 15; i++) s[i + 1] = full + bb::reduce((u64)s[i + 1] << SH[i]);  // (s_{i+1} 2^-32) 2^k, < 2p
 }
 
 // The permutation up to the final common scale kappa_final: finish every word that is used afterwards with
@@ -145,6 +148,11 @@ __device__ __forceinline__ void permute_scaled(u32 (&s)[16]) {
         external_layer(s, r < 3 ? PLAN.ext[r + 1] : ZERO16);
     }
     for (int r = 0; r < 13; r++) internal_round(s, PLAN.in[r]);
+#pragma unroll
+    for (int i = 1; i < 16; i++) {  // lazy words back below p
+        const u32 t = s[i] - bb::P;
+        s[i] = t < s[i] ? t : s[i];
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = bb::add(s[i], PLAN.ext[4][i]);
     for (int r = 4; r < 8; r++) {
