@@ -93,9 +93,12 @@ constexpr Plan PLAN = make_plan();
 __device__ static const plan::Plan PLAN = plan::PLAN;
 __device__ static const u32 ZERO16[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+// x^7 for canonical x; the result is LAZY (< 2p): x3 = x x2 and x7 = x3 x4 skip the final selection of the Montgomery
+// reduction (x2 and x4 are canonical, so every product stays below p 2^32).  Every consumer here takes a lazy word:
+// the unreduced sums of the external layer and the multiplication by kappa^-6 of the internal rounds.
 __device__ __forceinline__ u32 sbox7(u32 x) {
-    u32 x2 = bb::sqr(x), x4 = bb::sqr(x2), x3 = bb::mul(x, x2);
-    return bb::mul(x3, x4);
+    u32 x2 = bb::sqr(x), x4 = bb::sqr(x2), x3 = bb::mul_lazy(x, x2);
+    return bb::mul_lazy(x3, x4);
 }
 
 // M_E (gates/poseidon2_babybear.rs:804-832, 903-917): per 4-block [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], i.e.
