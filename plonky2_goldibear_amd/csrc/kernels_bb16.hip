@@ -40,7 +40,7 @@ static_assert(cpow(W16, 16) == 1 && cpow(W16, 8) == bb::P - 1, "W16 must be a pr
 template <bool INV, int M>
 __device__ __forceinline__ u32 sub_twiddle(u32 a, u32 b) {
     if constexpr (M == 0) return bb::sub(a, b);
-    else return bb::mul(bb::sub(a, b), bbc::tw<INV, M>());
+    else return bb::mul(a - b + bb::P, bbc::tw<INV, M>());  // a - b + p in (0, 2p): the product takes it unreduced
 }
 
 template <bool INV, int H, int J>
