@@ -39,6 +39,8 @@ struct GlF {
         return gl::mul(a, b);
 #endif
     }
+    // a + b for a result that is only multiplied (by a canonical partner): canonical here
+    static GB_HD T add_lazy(T a, T b) { return gl::add(a, b); }
     static GB_HD T inv(T a) { return gl::inv(a); }
     static GB_HD T pow(T a, u64 e) { return gl::pow(a, e); }
     static GB_HD T generator() { return gl::GENERATOR; }
@@ -71,6 +73,8 @@ struct BbF {
     static GB_HD T sub(T a, T b) { return bb::sub(a, b); }
     static GB_HD T mul(T a, T b) { return bb::mul(a, b); }
     static GB_HD T mul_lazy(T a, T b) { return bb::mul(a, b); }
+    // a + b < 2p unreduced: fine as ONE operand of a Montgomery product whose other operand is canonical (2 p^2 < p 2^32)
+    static GB_HD T add_lazy(T a, T b) { return a + b; }
     static GB_HD T inv(T a) { return bb::inv(a); }
     static GB_HD T pow(T a, u64 e) { return bb::pow(a, e); }
     static GB_HD T generator() { return bb::to_mont(bb::GENERATOR); }

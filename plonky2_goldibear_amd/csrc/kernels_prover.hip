@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void k_zs_quotients(ZsParams<F> p, const typen
         const u32 j1 = min((m + 1) * p.chunk, p.num_routed);
         for (u32 j = m * p.chunk; j < j1; j++) {
             T w = witness[(size_t)j * n + row];
-            T num = F::add(F::add(w, F::mul(bx, k_is[j])), gamma);
-            T den = F::add(F::add(w, F::mul(beta, sigma[(size_t)j * n + row])), gamma);
+            const T wg = F::add(w, gamma);
+            T num = F::add_lazy(wg, F::mul(bx, k_is[j]));
+            T den = F::add_lazy(wg, F::mul(beta, sigma[(size_t)j * n + row]));
             np = F::mul_lazy(np, num);
             dp = F::mul_lazy(dp, den);
         }
@@ -233,8 +234,9 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
             for (u32 q = 0; q < CH; q++) {
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
-                    T num = F::add(F::add(wv[q], F::mul(bk[k * nr + w0 + q], x)), gammas[k]);
-                    T den = F::add(F::add(wv[q], F::mul(betas[k], sg[q])), gammas[k]);
+                    const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
+                    T num = F::add_lazy(wg, F::mul(bk[k * nr + w0 + q], x));
+                    T den = F::add_lazy(wg, F::mul(betas[k], sg[q]));
                     np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
                     dp[k] = F::mul_lazy(dp[k], den);
                 }
@@ -245,8 +247,9 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
                 if (q >= live) continue;
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
-                    T num = F::add(F::add(wv[q], F::mul(bk[k * nr + w0 + q], x)), gammas[k]);
-                    T den = F::add(F::add(wv[q], F::mul(betas[k], sg[q])), gammas[k]);
+                    const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
+                    T num = F::add_lazy(wg, F::mul(bk[k * nr + w0 + q], x));
+                    T den = F::add_lazy(wg, F::mul(betas[k], sg[q]));
                     np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
                     dp[k] = F::mul_lazy(dp[k], den);
                 }
