@@ -1,0 +1,252 @@
+//! Safe wrappers over the C ABI of `libgoldibear_gpu.so` (`include/goldibear_gpu.h`).
+//!
+//! This is the shim the reference crate would depend on under a `gpu-mi355x` feature: field elements
+//! cross the boundary as canonical little-endian words (`u64` Goldilocks, `u32` BabyBear), which is what
+//! `as_canonical_u64()` / `as_canonical_u32()` give.  Written against the header; not compiled in this repository
+//! (the build image has no Rust toolchain).
+use std::ffi::{c_char, c_void, CStr};
+use std::ptr;
+
+#[repr(C)]
+pub struct gb_ctx { _p: [u8; 0] }
+#[repr(C)]
+pub struct gb_batch { _p: [u8; 0] }
+#[repr(C)]
+pub struct gb_circuit { _p: [u8; 0] }
+
+pub const GB_OK: i32 = 0;
+pub const GB_ERR_PERM_ARG_ZERO: i32 = 16;
+pub const GB_ERR_VERIFY: i32 = 19;
+pub const GB_GOLDILOCKS: u32 = 0;
+pub const GB_BABYBEAR: u32 = 1;
+pub const GB_INPUT_HOST: u32 = 0;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct gb_circuit_config {
+    pub field: u32,
+    pub degree_bits: u32,
+    pub num_wires: u32,
+    pub num_routed_wires: u32,
+    pub num_constants: u32,
+    pub num_challenges: u32,
+    pub max_quotient_degree_factor: u32,
+    pub rate_bits: u32,
+    pub cap_height: u32,
+    pub proof_of_work_bits: u32,
+    pub num_query_rounds: u32,
+    pub arity_bits: u32,
+    pub final_poly_bits: u32,
+    pub num_selectors: u32,
+    pub gate_constant: u32,
+    pub gate_pi: u32,
+}
+
+extern "C" {
+    fn gb_ctx_create(device: i32, out: *mut *mut gb_ctx) -> i32;
+    fn gb_ctx_destroy(ctx: *mut gb_ctx) -> i32;
+    fn gb_last_error(ctx: *const gb_ctx) -> *const c_char;
+    fn gb_commit_values(ctx: *mut gb_ctx, field: u32, cols: *const c_void, ncols: usize, log_n: u32, rate_bits: u32,
+                        cap_height: u32, salts: *const c_void, flags: u32, out: *mut *mut gb_batch) -> i32;
+    fn gb_commit_coeffs(ctx: *mut gb_ctx, field: u32, cols: *const c_void, ncols: usize, log_n: u32, rate_bits: u32,
+                        cap_height: u32, salts: *const c_void, flags: u32, out: *mut *mut gb_batch) -> i32;
+    fn gb_batch_free(b: *mut gb_batch) -> i32;
+    fn gb_batch_cap(b: *mut gb_batch, out: *mut c_void) -> i32;
+    fn gb_batch_coeffs(b: *mut gb_batch, col: usize, out: *mut c_void) -> i32;
+    fn gb_batch_lde_values(b: *mut gb_batch, index: u64, step: u64, out: *mut c_void) -> i32;
+    fn gb_batch_leaf(b: *mut gb_batch, leaf_index: u64, row: *mut c_void, siblings: *mut c_void, nsib: *mut u32) -> i32;
+    fn gb_batch_eval_ext(b: *mut gb_batch, z: *const c_void, out: *mut c_void) -> i32;
+    fn gb_circuit_create(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, constants_sigmas: *const c_void, k_is: *const c_void,
+                         flags: u32, out: *mut *mut gb_circuit) -> i32;
+    fn gb_circuit_free(c: *mut gb_circuit) -> i32;
+    fn gb_circuit_verifier_data(c: *mut gb_circuit, cap_out: *mut c_void, digest_out: *mut c_void) -> i32;
+    fn gb_prove(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
+                proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
+    fn gb_verify(c: *mut gb_circuit, proof: *const c_void, proof_len: usize) -> i32;
+}
+
+/// Status code + the library's message.
+#[derive(Debug)]
+pub struct GpuError {
+    pub status: i32,
+    pub message: String,
+}
+
+fn check(ctx: *const gb_ctx, status: i32) -> Result<(), GpuError> {
+    if status == GB_OK {
+        return Ok(());
+    }
+    let p = unsafe { gb_last_error(ctx) };
+    let message = if p.is_null() { String::new() } else { unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned() };
+    Err(GpuError { status, message })
+}
+
+/// One per HIP device; calls on a context are serialised by the caller (the prover thread).
+pub struct GpuContext(*mut gb_ctx);
+unsafe impl Send for GpuContext {}
+
+impl GpuContext {
+    pub fn new(device: i32) -> Result<Self, GpuError> {
+        let mut h = ptr::null_mut();
+        check(ptr::null(), unsafe { gb_ctx_create(device, &mut h) })?;
+        Ok(GpuContext(h))
+    }
+}
+impl Drop for GpuContext {
+    fn drop(&mut self) {
+        unsafe { gb_ctx_destroy(self.0) };
+    }
+}
+
+/// `PolynomialBatch` with coefficients, LDE (leaf order) and Merkle digests resident on the GPU (fri/oracle.rs:29-40).
+/// `W` is the canonical word type: `u64` for Goldilocks, `u32` for BabyBear.
+pub struct GpuPolynomialBatch<'c, W> {
+    ctx: &'c GpuContext,
+    handle: *mut gb_batch,
+    pub num_polys: usize,
+    pub degree_log: u32,
+    pub rate_bits: u32,
+    pub cap_height: u32,
+    pub blinding: bool,
+    _w: std::marker::PhantomData<W>,
+}
+
+fn field_tag<W>() -> u32 {
+    if std::mem::size_of::<W>() == 8 { GB_GOLDILOCKS } else { GB_BABYBEAR }
+}
+
+impl<'c, W: Copy + Default> GpuPolynomialBatch<'c, W> {
+    /// `PolynomialBatch::from_values` (oracle.rs:68-90): `values` = the columns laid end to end ([ncols][n]);
+    /// `salts` = [4][n << rate_bits] when blinding.
+    pub fn from_values(ctx: &'c GpuContext, values: &[W], num_polys: usize, rate_bits: u32, cap_height: u32,
+                       salts: Option<&[W]>) -> Result<Self, GpuError> {
+        Self::commit(ctx, values, num_polys, rate_bits, cap_height, salts, false)
+    }
+    /// `PolynomialBatch::from_coeffs` (oracle.rs:93-123)
+    pub fn from_coeffs(ctx: &'c GpuContext, coeffs: &[W], num_polys: usize, rate_bits: u32, cap_height: u32,
+                       salts: Option<&[W]>) -> Result<Self, GpuError> {
+        Self::commit(ctx, coeffs, num_polys, rate_bits, cap_height, salts, true)
+    }
+    fn commit(ctx: &'c GpuContext, cols: &[W], num_polys: usize, rate_bits: u32, cap_height: u32, salts: Option<&[W]>,
+              coeffs: bool) -> Result<Self, GpuError> {
+        assert!(num_polys > 0 && cols.len() % num_polys == 0);
+        let n = cols.len() / num_polys;
+        assert!(n.is_power_of_two());
+        let degree_log = n.trailing_zeros();
+        let mut h = ptr::null_mut();
+        let sp = salts.map_or(ptr::null(), |s| s.as_ptr() as *const c_void);
+        let f = if coeffs { gb_commit_coeffs } else { gb_commit_values };
+        check(ctx.0, unsafe {
+            f(ctx.0, field_tag::<W>(), cols.as_ptr() as *const c_void, num_polys, degree_log, rate_bits, cap_height, sp, GB_INPUT_HOST, &mut h)
+        })?;
+        Ok(Self { ctx, handle: h, num_polys, degree_log, rate_bits, cap_height, blinding: salts.is_some(), _w: std::marker::PhantomData })
+    }
+    fn hash_len() -> usize {
+        if std::mem::size_of::<W>() == 8 { 4 } else { 8 }
+    }
+    /// `merkle_tree.cap`: 2^cap_height hashes of NUM_HASH_OUT_ELTS words
+    pub fn cap(&self) -> Result<Vec<W>, GpuError> {
+        let mut out = vec![W::default(); Self::hash_len() << self.cap_height];
+        check(self.ctx.0, unsafe { gb_batch_cap(self.handle, out.as_mut_ptr() as *mut c_void) })?;
+        Ok(out)
+    }
+    /// `.polynomials[col]`
+    pub fn polynomial(&self, col: usize) -> Result<Vec<W>, GpuError> {
+        let mut out = vec![W::default(); 1usize << self.degree_log];
+        check(self.ctx.0, unsafe { gb_batch_coeffs(self.handle, col, out.as_mut_ptr() as *mut c_void) })?;
+        Ok(out)
+    }
+    /// `get_lde_values(index, step)` (oracle.rs:153-158)
+    pub fn get_lde_values(&self, index: usize, step: usize) -> Result<Vec<W>, GpuError> {
+        let mut out = vec![W::default(); self.num_polys];
+        check(self.ctx.0, unsafe { gb_batch_lde_values(self.handle, index as u64, step as u64, out.as_mut_ptr() as *mut c_void) })?;
+        Ok(out)
+    }
+    /// `merkle_tree.get(i)` and `merkle_tree.prove(i)` (merkle_tree.rs:183-222): (leaf row incl. salts, siblings)
+    pub fn leaf_and_proof(&self, leaf_index: usize) -> Result<(Vec<W>, Vec<W>), GpuError> {
+        let width = self.num_polys + if self.blinding { 4 } else { 0 };
+        let layers = (self.degree_log + self.rate_bits - self.cap_height) as usize;
+        let mut row = vec![W::default(); width];
+        let mut sib = vec![W::default(); layers.max(1) * Self::hash_len()];
+        let mut nsib = 0u32;
+        check(self.ctx.0, unsafe {
+            gb_batch_leaf(self.handle, leaf_index as u64, row.as_mut_ptr() as *mut c_void, sib.as_mut_ptr() as *mut c_void, &mut nsib)
+        })?;
+        sib.truncate(nsib as usize * Self::hash_len());
+        Ok((row, sib))
+    }
+    /// every polynomial at the extension point `z` (D canonical words): plonk/proof.rs:359-363
+    pub fn eval_ext(&self, z: &[W]) -> Result<Vec<W>, GpuError> {
+        let d = z.len();
+        let mut out = vec![W::default(); self.num_polys * d];
+        check(self.ctx.0, unsafe { gb_batch_eval_ext(self.handle, z.as_ptr() as *const c_void, out.as_mut_ptr() as *mut c_void) })?;
+        Ok(out)
+    }
+}
+impl<'c, W> Drop for GpuPolynomialBatch<'c, W> {
+    fn drop(&mut self) {
+        unsafe { gb_batch_free(self.handle) };
+    }
+}
+
+/// What `CircuitBuilder::build()` leaves for the prover, resident on the GPU (circuit_builder.rs:1214-1312).
+pub struct GpuCircuit<'c, W> {
+    ctx: &'c GpuContext,
+    handle: *mut gb_circuit,
+    pub config: gb_circuit_config,
+    _w: std::marker::PhantomData<W>,
+}
+
+pub enum ProveOutcome {
+    Proof(Vec<u8>),
+    /// `ProverError::InvZeroPermArg`: re-randomise the random wire and call again (plonk/prover.rs:183-226)
+    PermArgZero,
+}
+
+impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
+    pub fn new(ctx: &'c GpuContext, mut config: gb_circuit_config, constants_sigmas: &[W], k_is: &[W]) -> Result<Self, GpuError> {
+        config.field = field_tag::<W>();
+        let mut h = ptr::null_mut();
+        check(ctx.0, unsafe {
+            gb_circuit_create(ctx.0, &config, constants_sigmas.as_ptr() as *const c_void, k_is.as_ptr() as *const c_void, GB_INPUT_HOST, &mut h)
+        })?;
+        Ok(Self { ctx, handle: h, config, _w: std::marker::PhantomData })
+    }
+    /// (constants_sigmas_cap, circuit_digest)
+    pub fn verifier_data(&self) -> Result<(Vec<W>, Vec<W>), GpuError> {
+        let hl = if std::mem::size_of::<W>() == 8 { 4 } else { 8 };
+        let mut cap = vec![W::default(); hl << self.config.cap_height];
+        let mut digest = vec![W::default(); hl];
+        check(self.ctx.0, unsafe { gb_circuit_verifier_data(self.handle, cap.as_mut_ptr() as *mut c_void, digest.as_mut_ptr() as *mut c_void) })?;
+        Ok((cap, digest))
+    }
+    /// `internal_prove_with_partition_witness` (plonk/prover.rs:228-447): `witness` = wire_values [num_wires][n]
+    pub fn prove(&self, witness: &[W], public_inputs: &[u64]) -> Result<ProveOutcome, GpuError> {
+        let mut buf = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        let st = unsafe {
+            gb_prove(self.handle, witness.as_ptr() as *const c_void, GB_INPUT_HOST, public_inputs.as_ptr(), public_inputs.len(),
+                     buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
+        };
+        if st == GB_ERR_PERM_ARG_ZERO {
+            return Ok(ProveOutcome::PermArgZero);
+        }
+        check(self.ctx.0, st)?;
+        buf.truncate(len);
+        Ok(ProveOutcome::Proof(buf))
+    }
+    /// `CircuitData::verify` for the dummy gate set, on the host: Ok(true), Ok(false) when a check fails
+    pub fn verify(&self, proof: &[u8]) -> Result<bool, GpuError> {
+        let st = unsafe { gb_verify(self.handle, proof.as_ptr() as *const c_void, proof.len()) };
+        if st == GB_ERR_VERIFY {
+            return Ok(false);
+        }
+        check(self.ctx.0, st)?;
+        Ok(true)
+    }
+}
+impl<'c, W> Drop for GpuCircuit<'c, W> {
+    fn drop(&mut self) {
+        unsafe { gb_circuit_free(self.handle) };
+    }
+}
