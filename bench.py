@@ -114,10 +114,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
+    # rehearsal switches (not used by the driver): GB_BENCH_BACKEND=gloo and GB_BENCH_SHARE_DEVICE=1 let several ranks share
+    # the one GPU of a test box, to exercise the multi-rank flow without a multi-GPU node
+    if os.environ.get("GB_BENCH_SHARE_DEVICE"):
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GB_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from plonky2_goldibear_amd import CircuitData, GpuContext, PolynomialBatch, sharding
     from plonky2_goldibear_amd import dummy_circuit as DC
