@@ -138,6 +138,27 @@ typedef struct gb_circuit_config {
 gb_status gb_circuit_create(gb_ctx* ctx, const gb_circuit_config* cfg, const void* constants_sigmas, const void* k_is,
                             uint32_t flags, gb_circuit** out);
 gb_status gb_circuit_free(gb_circuit* c);
+/* The same for a general gate set: `gates` is CommonCircuitData.gates - sorted by (degree, id) as
+ * circuit_builder.rs:1194-1196 leaves them - with selectors_info flattened into each entry (gates/selectors.rs:16-26:
+ * selector_indices[i], groups[selector_indices[i]]); entry i is the gate whose selector value is i.  The constraint evaluators
+ * (csrc/gates.hpp) cover NoopGate, ConstantGate{param = num_consts} (gates/constant.rs), PublicInputGate<H>
+ * (gates/public_input.rs), ArithmeticGate{param = num_ops} (gates/arithmetic_base.rs) and, for Goldilocks, PoseidonGate
+ * (gates/poseidon_goldilocks.rs); any other kind is GB_ERR_UNSUPPORTED.  cfg->num_selectors = selectors_info.groups.len(),
+ * cfg->num_constants = the constant columns after the selectors (max over the gates' num_constants()); cfg->gate_constant and
+ * cfg->gate_pi are ignored.  constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits]. */
+#define GB_GATE_NOOP 0
+#define GB_GATE_CONSTANT 1
+#define GB_GATE_PUBLIC_INPUT 2
+#define GB_GATE_ARITHMETIC 3
+#define GB_GATE_POSEIDON 4
+typedef struct gb_gate {
+    uint32_t kind;            /* GB_GATE_* */
+    uint32_t param;           /* ConstantGate num_consts / ArithmeticGate num_ops; 0 otherwise */
+    uint32_t selector_index;  /* which selector column carries this gate */
+    uint32_t group_start, group_end; /* the gate indices sharing that column */
+} gb_gate;
+gb_status gb_circuit_create_gates(gb_ctx* ctx, const gb_circuit_config* cfg, const gb_gate* gates, uint32_t num_gates,
+                                  const void* constants_sigmas, const void* k_is, uint32_t flags, gb_circuit** out);
 /* VerifierOnlyCircuitData: constants_sigmas_cap [2^cap_height][H] and circuit_digest [H], field elements */
 gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_out);
 /* prove_with_partition_witness -> internal_prove_with_partition_witness (plonk/prover.rs:160-447):

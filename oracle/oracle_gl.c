@@ -125,6 +125,71 @@ void gbo_gl_poseidon(const gl_t in[W], gl_t out[W]) {
     memcpy(out, s, sizeof s);
 }
 
+/* gates/poseidon_goldilocks.rs:223-313 PoseidonGate::eval_unfiltered_base_one: the 123 constraints of one row, in the
+ * reference's order.  w = the row's wire values: 0..11 inputs, 12..23 outputs, 24 swap, 25..28 deltas, then the s-box
+ * inputs of full rounds 1..3, of the 22 partial rounds (fast form) and of full rounds 4..7 (:44-97). */
+void gbo_gl_poseidon_gate_constraints(const gl_t *w, gl_t *out) {
+    enum { WIRE_SWAP = 24, START_DELTA = 25, START_FULL_0 = 29, START_PARTIAL = START_FULL_0 + W * (HALF_FULL - 1),
+           START_FULL_1 = START_PARTIAL + N_PARTIAL };
+    int t = 0, round = 0;
+    gl_t swap = w[WIRE_SWAP], s[W];
+    out[t++] = gl_mul(swap, gl_sub(swap, 1));
+    for (int i = 0; i < 4; i++) out[t++] = gl_sub(gl_mul(swap, gl_sub(w[i + 4], w[i])), w[START_DELTA + i]);
+    for (int i = 0; i < 4; i++) {
+        s[i] = gl_add(w[i], w[START_DELTA + i]);
+        s[i + 4] = gl_sub(w[i + 4], w[START_DELTA + i]);
+    }
+    for (int i = 8; i < W; i++) s[i] = w[i];
+    for (int r = 0; r < HALF_FULL; r++) {
+        constant_layer(s, round);
+        if (r != 0)
+            for (int i = 0; i < W; i++) {
+                gl_t in = w[START_FULL_0 + W * (r - 1) + i];
+                out[t++] = gl_sub(s[i], in);
+                s[i] = in;
+            }
+        for (int i = 0; i < W; i++) s[i] = sbox(s[i]);
+        mds_layer(s);
+        round++;
+    }
+    for (int i = 0; i < W; i++) s[i] = gl_add(s[i], gl_canon(FP_FIRST[i]));
+    {
+        gl_t r[W];
+        r[0] = s[0];
+        for (int c = 1; c < W; c++) {
+            gl_t sum = 0;
+            for (int rr = 1; rr < W; rr++) sum = gl_add(sum, gl_mul(s[rr], gl_canon(FP_INIT[rr - 1][c - 1])));
+            r[c] = sum;
+        }
+        memcpy(s, r, sizeof r);
+    }
+    for (int k = 0; k < N_PARTIAL; k++) {
+        gl_t in = w[START_PARTIAL + k];
+        out[t++] = gl_sub(s[0], in);
+        s[0] = sbox(in);
+        if (k != N_PARTIAL - 1) s[0] = gl_add(s[0], gl_canon(FP_RC[k]));
+        gl_t d = gl_mul(s[0], MDS_CIRC[0] + MDS_DIAG[0]);
+        for (int i = 1; i < W; i++) d = gl_add(d, gl_mul(s[i], gl_canon(FP_WHATS[k][i - 1])));
+        gl_t r[W];
+        r[0] = d;
+        for (int i = 1; i < W; i++) r[i] = gl_add(s[i], gl_mul(s[0], gl_canon(FP_VS[k][i - 1])));
+        memcpy(s, r, sizeof r);
+    }
+    round += N_PARTIAL;
+    for (int r = 0; r < HALF_FULL; r++) {
+        constant_layer(s, round);
+        for (int i = 0; i < W; i++) {
+            gl_t in = w[START_FULL_1 + W * r + i];
+            out[t++] = gl_sub(s[i], in);
+            s[i] = in;
+        }
+        for (int i = 0; i < W; i++) s[i] = sbox(s[i]);
+        mds_layer(s);
+        round++;
+    }
+    for (int i = 0; i < W; i++) out[t++] = gl_sub(s[i], w[W + i]);
+}
+
 /* ------------------------------------------------------------------ sponge / compression */
 
 /* hash/hashing.rs:100-123 hash_n_to_m_no_pad with num_outputs = 4 (overwrite mode, rate 8) */

@@ -15,6 +15,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import gates as G
 from . import oracle as O
 from . import verifier as V
 from .fields import BB, GL
@@ -90,6 +91,9 @@ class DummyCircuit:
         self.reduction_arity_bits = reduction_arity_bits(cfg, degree_bits)
         self._digest = None
         self.constants_sigmas_cap = None
+        # CommonCircuitData.gates / selectors_info in table form (oracle/gates.py)
+        self.num_selectors, self.num_public_inputs = 1, 0
+        self.gate_table = [(G.NOOP, 0, 0, 0, 3), (G.CONSTANT, cfg.num_constants, 0, 0, 3), (G.PUBLIC_INPUT, H, 0, 0, 3)]
 
     def set_cap(self, cap):
         """circuit_digest = hash_no_pad(cap.flatten() ++ hash_pad(domain_sep = []) ++ [degree_bits])"""
@@ -129,15 +133,34 @@ class DummyCircuit:
                             hiding=False),
             quotient_degree_factor=cfg.max_quotient_degree_factor, num_constants=self.num_constants,
             num_partial_products=self.num_partial_products, num_lookup_polys=0, k_is=[int(k) for k in self.k_is],
-            num_public_inputs=0)
+            num_public_inputs=self.num_public_inputs)
 
     def c_cfg(self):
         cfg = self.cfg
         vals = [cfg.num_wires, cfg.num_routed_wires, self.num_constants, cfg.num_challenges, cfg.rate_bits, cfg.cap_height,
                 cfg.proof_of_work_bits, cfg.num_query_rounds, cfg.arity_bits, cfg.final_poly_bits,
-                cfg.max_quotient_degree_factor, self.degree_bits, 1, self.GATE_NOOP, self.GATE_CONSTANT, self.GATE_PI,
-                cfg.num_constants]
+                cfg.max_quotient_degree_factor, self.degree_bits, self.num_selectors, self.GATE_NOOP, self.GATE_CONSTANT,
+                self.GATE_PI, cfg.num_constants, len(self.gate_table)]
+        for g in self.gate_table:
+            vals += list(g)
+        vals += [0] * (5 * (16 - len(self.gate_table)))
         return (C.c_uint * len(vals))(*vals)
+
+
+class BuiltCircuit(DummyCircuit):
+    """CircuitData of any circuit given by its build() outputs - constants||sigmas values, k_is and the sorted gate set with
+    selectors_info as (kind, param, selector_index, group_start, group_end) tuples - for the gate kinds of oracle/gates.py."""
+
+    def __init__(self, cfg, F, degree_bits, constants_sigmas, k_is, gate_table, num_selectors, num_public_inputs):
+        self.cfg, self.degree_bits, self.F, self.n = cfg, degree_bits, F, 1 << degree_bits
+        self.constants_sigmas = np.ascontiguousarray(constants_sigmas, dtype=F.dtype)
+        self.k_is = np.ascontiguousarray(k_is, dtype=F.dtype)
+        self.gate_table, self.num_selectors, self.num_public_inputs = [tuple(g) for g in gate_table], num_selectors, num_public_inputs
+        self.num_constants = self.constants_sigmas.shape[0] - cfg.num_routed_wires   # selectors + constant columns
+        self.sigma = self.constants_sigmas[self.num_constants:]
+        self.num_partial_products = -(-cfg.num_routed_wires // cfg.max_quotient_degree_factor) - 1
+        self.reduction_arity_bits = reduction_arity_bits(cfg, degree_bits)
+        self._digest, self.constants_sigmas_cap = None, None
 
 
 def prove_cpu(circ, witness, public_inputs=()):
@@ -175,21 +198,13 @@ def eval_vanishing_poly(circ, zeta, openings, pi_hash, betas, gammas, alphas):
     consts, wires, sig = openings["constants"], openings["wires"], openings["plonk_sigmas"]
     zs, zs_next, pps = openings["plonk_zs"], openings["plonk_zs_next"], openings["partial_products"]
     qdf, num_prods = cfg.max_quotient_degree_factor, circ.num_partial_products
-    # gate constraints (filter * unfiltered; compute_filter gates/gate.rs:391-404)
-    s = consts[0]
-    gc = consts[1:]
-    cons = [zero] * max(H, cfg.num_constants)
-    for g in range(3):
-        f = one
-        for i in range(3):
-            if i != g:
-                f = e.emul(f, e.esub(e.efrom(i), s))
-        if g == circ.GATE_CONSTANT:
-            for j in range(cfg.num_constants):
-                cons[j] = e.eadd(cons[j], e.emul(f, e.esub(gc[j], wires[j])))
-        elif g == circ.GATE_PI:
-            for j in range(H):
-                cons[j] = e.eadd(cons[j], e.emul(f, e.esub(wires[j], e.efrom(int(pi_hash[j])))))
+    # gate constraints: sum over the gate set of filter * unfiltered per constraint index (vanishing_poly.rs:129-170)
+    nsel = circ.num_selectors
+    cons = [zero] * max(G.num_constraints(g, H) for g in circ.gate_table)
+    for row, g in enumerate(circ.gate_table):
+        f = G.compute_filter(e, row, g, consts[g[2]], nsel > 1)
+        for j, c in enumerate(G.eval_unfiltered(e, g, wires, consts[nsel:], pi_hash)):
+            cons[j] = e.eadd(cons[j], e.emul(f, c))
     # eval_l_0 (plonk_common.rs:56-66)
     zn = e.epow(zeta, n)
     if zeta == one:
@@ -223,9 +238,9 @@ def verify(circ, proof_bytes, stats=None):
     cd = circ.common_data()
     F = circ.F
     proof, pis = V.read_proof_with_pis(proof_bytes, cd, F)
-    assert len(pis) == 0
+    assert len(pis) == circ.num_public_inputs, "Number of public inputs doesn't match circuit data."
     ch = V.get_challenges(proof, pis, circ.circuit_digest, cd, F)
-    pi_hash = F.hash_no_pad(np.zeros(0, F.dtype))
+    pi_hash = F.hash_no_pad(np.asarray(pis, dtype=F.dtype))
     van = eval_vanishing_poly(circ, ch["plonk_zeta"], proof["openings"], pi_hash, ch["plonk_betas"], ch["plonk_gammas"],
                               ch["plonk_alphas"])
     zeta_pow = F.epow(ch["plonk_zeta"], circ.n)

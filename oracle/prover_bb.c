@@ -75,4 +75,5 @@ void gbo_bb_challenger_init(challenger_t *c);
 void gbo_bb_challenger_observe(challenger_t *c, const bb_t *e, size_t n);
 bb_t gbo_bb_challenger_get(challenger_t *c);
 
+#define X_POSEIDON_GATE(w, out) do { (void)(w); for (unsigned q_ = 0; q_ < 123; q_++) (out)[q_] = 0; rc = -12; } while (0) /* Goldilocks gate */
 #include "prover_impl.h"

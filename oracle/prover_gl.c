@@ -42,9 +42,11 @@ int gbo_gl_merkle_prove(const gl_t *digests, size_t log_l, unsigned cap_height, 
 void gbo_gl_coset_ifft(gl_t *v, unsigned lg_n, gl_t shift);
 void gbo_gl_coset_fft(gl_t *v, unsigned lg_n, gl_t shift, unsigned zero_factor);
 void gbo_gl_poseidon(const gl_t in[12], gl_t out[12]);
+void gbo_gl_poseidon_gate_constraints(const gl_t *w, gl_t *out);
 typedef struct { gl_t state[12]; gl_t in[8]; int nin; gl_t out[8]; int nout; } challenger_t;
 void gbo_gl_challenger_init(challenger_t *c);
 void gbo_gl_challenger_observe(challenger_t *c, const gl_t *e, size_t n);
 gl_t gbo_gl_challenger_get(challenger_t *c);
 
+#define X_POSEIDON_GATE(w, out) gbo_gl_poseidon_gate_constraints(w, out)
 #include "prover_impl.h"

@@ -28,9 +28,16 @@ typedef struct {
     unsigned num_selectors;      /* 1 */
     unsigned gate_noop, gate_constant, gate_pi; /* indices in the sorted gate list (selector values) */
     unsigned num_gate_consts;    /* ConstantGate num_consts */
+    /* CommonCircuitData.gates sorted by (degree, id) with selectors_info flattened: {kind, param, selector_index,
+     * group_start, group_end}; kind 0 Noop, 1 Constant{param}, 2 PublicInput, 3 Arithmetic{param = num_ops}, 4 Poseidon */
+    unsigned num_gates;
+    unsigned gates[16][5];
 } gbo_circuit_cfg;
 #endif
 
+
+#define GBO_MAX_GATE_CONSTRAINTS 128
+#define GBO_MAX_TERMS 512
 
 typedef struct {
     size_t ncols;
@@ -181,12 +188,20 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
         F_T wr = F_TWO_ADIC(r), xr = 1;
         for (unsigned i = 0; i < (1u << r); i++) { zh[i] = F_SUB(F_MUL(g_pow_n, xr), 1); zh_inv[i] = F_INV(zh[i]); xr = F_MUL(xr, wr); }
         F_T wN = F_TWO_ADIC(lgN);
-        const unsigned nterms = c + c * nchunks + HOUT; /* z_1 terms, partial product terms, gate constraints (max = 4) */
+        /* num_gate_constraints = max over the gate set (circuit_builder.rs:1286-1290) */
+        unsigned ngc = 0;
+        for (unsigned g = 0; g < cfg->num_gates; g++) {
+            const unsigned kind = cfg->gates[g][0], param = cfg->gates[g][1];
+            unsigned m = kind == 1 || kind == 3 ? param : (kind == 2 ? HOUT : (kind == 4 ? 123 : 0));
+            if (m > ngc) ngc = m;
+        }
+        const unsigned nterms = c + c * nchunks + ngc; /* z_1 terms, partial product terms, gate constraints */
         const unsigned nsel = cfg->num_selectors;
+        if (nterms > GBO_MAX_TERMS || ngc > GBO_MAX_GATE_CONSTRAINTS || cfg->num_gates > 16) { rc = -11; goto done; }
         /* Rayon par_chunks(BATCH_SIZE = 32) over the points (prover.rs:791-797) */
 #pragma omp parallel for schedule(static)
         for (size_t i0 = 0; i0 < N; i0 += 32) {
-        F_T terms[256];
+        F_T terms[GBO_MAX_TERMS];
         F_T pt = F_POW(wN, i0);
         for (size_t i = i0; i < i0 + 32 && i < N; i++, pt = F_MUL(pt, wN)) {
             F_T x = F_MUL(F_GENERATOR, pt); /* shifted_x */
@@ -212,20 +227,31 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
             }
             /* gate constraints (vanishing_poly.rs:741-774): filter * unfiltered, summed per constraint index */
             {
-                F_T s = consts[0]; /* selector polynomial of the single group */
                 const F_T *gc = consts + nsel; /* remove_prefix(num_selectors) */
-                unsigned ng = 3;
-                F_T cons[HOUT] = {0, 0, 0, 0};
-                for (unsigned g = 0; g < ng; g++) {
-                    /* compute_filter (gates/gate.rs:391-404): prod_{i in group, i != g} (i - s); single selector => no UNUSED term */
+                F_T cons[GBO_MAX_GATE_CONSTRAINTS], gcons[GBO_MAX_GATE_CONSTRAINTS];
+                for (unsigned j = 0; j < ngc; j++) cons[j] = 0;
+                for (unsigned g = 0; g < cfg->num_gates; g++) {
+                    const unsigned kind = cfg->gates[g][0], param = cfg->gates[g][1];
+                    /* compute_filter (gates/gate.rs:391-404): prod_{i in group, i != g} (i - s) [* (UNUSED - s)] */
+                    F_T s = consts[cfg->gates[g][2]];
                     F_T f = 1;
-                    for (unsigned ii = 0; ii < ng; ii++) if (ii != g) f = F_MUL(f, F_SUB((F_T)ii, s));
-                    if (g == cfg->gate_constant)
-                        for (unsigned j = 0; j < cfg->num_gate_consts; j++) cons[j] = F_ADD(cons[j], F_MUL(f, F_SUB(gc[j], lw[j])));
-                    else if (g == cfg->gate_pi)
-                        for (unsigned j = 0; j < HOUT; j++) cons[j] = F_ADD(cons[j], F_MUL(f, F_SUB(lw[j], pi_hash[j])));
+                    for (unsigned ii = cfg->gates[g][3]; ii < cfg->gates[g][4]; ii++) if (ii != g) f = F_MUL(f, F_SUB(F_FROM_U64(ii), s));
+                    if (nsel > 1) f = F_MUL(f, F_SUB(F_FROM_U64(0xFFFFFFFFull), s));
+                    unsigned m = 0;
+                    if (kind == 1)         /* gates/constant.rs:64-72 */
+                        for (; m < param; m++) gcons[m] = F_SUB(gc[m], lw[m]);
+                    else if (kind == 2)    /* gates/public_input.rs:52-60 */
+                        for (; m < HOUT; m++) gcons[m] = F_SUB(lw[m], pi_hash[m]);
+                    else if (kind == 3)    /* gates/arithmetic_base.rs:209-226 */
+                        for (; m < param; m++)
+                            gcons[m] = F_SUB(lw[4 * m + 3], F_ADD(F_MUL(F_MUL(lw[4 * m], lw[4 * m + 1]), gc[0]), F_MUL(lw[4 * m + 2], gc[1])));
+                    else if (kind == 4) {  /* gates/poseidon_goldilocks.rs:223-313 */
+                        X_POSEIDON_GATE(lw, gcons);
+                        m = 123;
+                    }
+                    for (unsigned j = 0; j < m; j++) cons[j] = F_ADD(cons[j], F_MUL(f, gcons[j]));
                 }
-                for (unsigned j = 0; j < HOUT; j++) terms[t++] = cons[j];
+                for (unsigned j = 0; j < ngc; j++) terms[t++] = cons[j];
             }
             /* reduce_with_powers_multi (plonk_common.rs:105-122), then * 1/Z_H (prover.rs:909-916) */
             for (unsigned k = 0; k < c; k++) {
@@ -235,7 +261,6 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
             }
         }
         }
-        if (nterms > 256) rc = -11;
     }
     /* coset_ifft (prover.rs:921-925), trim_to_len + chunks (:361-374): c * qdf chunk polys of n coefficients */
     qchunks = malloc((size_t)c * qdf * n * sizeof(F_T));

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "field_traits.hpp"
+#include "gate_set.hpp"
 
 namespace gbk {
 
@@ -115,6 +116,12 @@ struct QuotientParams {
     u32 gate_constant, gate_pi, num_gate_consts;
     PowTab<F> w_N;   // LDE domain generator powers
     const typename F::T* l0;  // [N] L_0 on the LDE domain, leaf order (l0_table)
+    u32 ext_gates;            // 1: the gate terms are already in qv (gate_constraints); 0: the dummy gate set, evaluated inline
+};
+template <class F>
+struct GateParams {
+    u32 log_n, rate_bits, num_challenges, nterms, t0 /* index of the first gate term */;
+    gates::GateSet gs;
 };
 template <class F>
 struct PolyGroups {
@@ -137,6 +144,10 @@ template <class F>
 bool quotient_values(const QuotientParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* zs,
                      const typename F::T* uniforms, typename F::T* qv, hipStream_t st);
 bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges);
+// qv <- the alpha-folded gate constraints of a general gate set (kernels_gates.hip); false if num_challenges has no instance
+template <class F>
+bool gate_constraints(const GateParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* apow,
+                      const typename F::T* pi_hash, typename F::T* qv, hipStream_t st);
 // l0[j] = Z_H(x_j) / (n (x_j - 1)), zh = device copy of the 2^rate_bits values of Z_H on the cosets
 template <class F>
 void l0_table(u32 log_n, u32 rate_bits, const PowTab<F>& w_N, const typename F::T* zh, typename F::T* l0, hipStream_t st);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
 
     T acc[C];
 #pragma unroll
-    for (u32 k = 0; k < C; k++) acc[k] = F::zero();
+    for (u32 k = 0; k < C; k++) acc[k] = p.ext_gates ? qv[(((size_t)k << r) + cidx) * n + il] : F::zero();
     u32 t = 0;
     // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61); L_0 on the LDE domain is a per-circuit table (k_l0_table)
     const T l0 = p.l0[j];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
     // gate constraints: filter * unfiltered, summed per constraint index (vanishing_poly.rs:741-774,
     // gates/gate.rs:188-215,391-404).  One selector group {0,1,2}; no UNUSED factor (single selector).
     // PublicInputGate<H> has H constraints, ConstantGate num_gate_consts <= H.
-    {
+    if (!p.ext_gates) {
         const T s = cs[j];  // constants[0] = selector
         T f[3];
 #pragma unroll

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gb_pow_grind": (_i32, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gb_permute": (_i32, [_vp, _u32, _vp, _vp, _u64]),
     "gb_circuit_create": (_i32, [_vp, _vp, _vp, _vp, _u32, _pvp]),
+    "gb_circuit_create_gates": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _pvp]),
     "gb_circuit_free": (_i32, [_vp]),
     "gb_circuit_verifier_data": (_i32, [_vp, _vp, _vp]),
     "gb_prove": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),

@@ -25,6 +25,10 @@ class gb_circuit_config(C.Structure):
         "arity_bits", "final_poly_bits", "num_selectors", "gate_constant", "gate_pi")]
 
 
+class gb_gate(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("kind", "param", "selector_index", "group_start", "group_end")]
+
+
 class CircuitData:
     """Defaults are standard_recursion_config_gl (plonk/circuit_data.rs:102-116); `CircuitData.babybear(...)`
     fills in recursion_config_bb_narrow (:131-139)."""
@@ -38,7 +42,11 @@ class CircuitData:
     def __init__(self, ctx, degree_bits, constants_sigmas, k_is, *, num_wires=135, num_routed_wires=80, num_constants=2,
                  num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16,
                  num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1, gate_constant=1, gate_pi=2,
-                 field=N.GB_GOLDILOCKS):
+                 field=N.GB_GOLDILOCKS, gates=None):
+        """`gates` = None: the dummy circuit's gate set, given by the selector values gate_constant / gate_pi
+        (gb_circuit_create).  Otherwise CommonCircuitData.gates with selectors_info, one tuple
+        (kind, param, selector_index, group_start, group_end) per gate in sorted order (gb_circuit_create_gates; what
+        circuit_builder.CircuitBuilder.build() passes); num_constants then counts the constant columns after the selectors."""
         self.ctx, self._lib = ctx, ctx._lib
         self.field, self._dt = field, _dtype(field)
         hout = 4 if field == N.GB_GOLDILOCKS else 8
@@ -59,7 +67,12 @@ class CircuitData:
         else:
             kptr, keep2 = k.ctypes.data, k
         h = C.c_void_p()
-        N.check(self._lib.gb_circuit_create(ctx.handle, C.byref(self.cfg), ptr, kptr, flags, C.byref(h)), ctx.handle)
+        if gates is None:
+            N.check(self._lib.gb_circuit_create(ctx.handle, C.byref(self.cfg), ptr, kptr, flags, C.byref(h)), ctx.handle)
+        else:
+            arr = (gb_gate * len(gates))(*[gb_gate(*g) for g in gates])
+            N.check(self._lib.gb_circuit_create_gates(ctx.handle, C.byref(self.cfg), arr, len(gates), ptr, kptr, flags, C.byref(h)),
+                    ctx.handle)
         del keep, keep2
         self.handle = h
         cap = np.empty((1 << cap_height, hout), dtype=self._dt)
