@@ -142,8 +142,10 @@ gb_status gb_circuit_free(gb_circuit* c);
  * circuit_builder.rs:1194-1196 leaves them - with selectors_info flattened into each entry (gates/selectors.rs:16-26:
  * selector_indices[i], groups[selector_indices[i]]); entry i is the gate whose selector value is i.  The constraint evaluators
  * (csrc/gates.hpp) cover NoopGate, ConstantGate{param = num_consts} (gates/constant.rs), PublicInputGate<H>
- * (gates/public_input.rs), ArithmeticGate{param = num_ops} (gates/arithmetic_base.rs) and, for Goldilocks, PoseidonGate
- * (gates/poseidon_goldilocks.rs); any other kind is GB_ERR_UNSUPPORTED.  cfg->num_selectors = selectors_info.groups.len(),
+ * (gates/public_input.rs), ArithmeticGate{param = num_ops} (gates/arithmetic_base.rs) and the in-circuit hash of the field's
+ * configuration - PoseidonGate for Goldilocks (gates/poseidon_goldilocks.rs), Poseidon2BabyBearGate{param = num_ops} for
+ * BabyBear (gates/poseidon2_babybear.rs) - which build() needs for any circuit with public inputs (circuit_builder.rs:1126-1137);
+ * any other kind is GB_ERR_UNSUPPORTED.  cfg->num_selectors = selectors_info.groups.len(),
  * cfg->num_constants = the constant columns after the selectors (max over the gates' num_constants()); cfg->gate_constant and
  * cfg->gate_pi are ignored.  constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits]. */
 #define GB_GATE_NOOP 0
@@ -151,9 +153,10 @@ gb_status gb_circuit_free(gb_circuit* c);
 #define GB_GATE_PUBLIC_INPUT 2
 #define GB_GATE_ARITHMETIC 3
 #define GB_GATE_POSEIDON 4
+#define GB_GATE_POSEIDON2_BABYBEAR 5
 typedef struct gb_gate {
     uint32_t kind;            /* GB_GATE_* */
-    uint32_t param;           /* ConstantGate num_consts / ArithmeticGate num_ops; 0 otherwise */
+    uint32_t param;           /* ConstantGate num_consts / ArithmeticGate, Poseidon2BabyBearGate num_ops; 0 otherwise */
     uint32_t selector_index;  /* which selector column carries this gate */
     uint32_t group_start, group_end; /* the gate indices sharing that column */
 } gb_gate;

@@ -88,6 +88,54 @@ void gbo_bb_poseidon2(const bb_t in[W], bb_t out[W]) {
 }
 
 /* hash/hashing.rs:100-123, rate 8, 8 outputs */
+/* gates/poseidon2_babybear.rs:315-413 Poseidon2BabyBearGate::eval_unfiltered_base_one: 150 constraints per operation, in the
+ * reference's order.  w = the row's wires: per op 33 routed (16 inputs, 16 outputs, swap) for all ops first, then per op 133
+ * non-routed (8 deltas; s-box inputs of full rounds 1..3, of the 13 internal rounds, of full rounds 4..7) (:56-147). */
+void gbo_bb_poseidon2_gate_constraints(const bb_t *w, unsigned num_ops, bb_t *out) {
+    unsigned t = 0;
+    for (unsigned op = 0; op < num_ops; op++) {
+        const unsigned in0 = 33 * op, out0 = in0 + W, start_delta = num_ops * 33 + op * 133;
+        const unsigned start_full_0 = start_delta + 8, start_partial = start_full_0 + W * 3, start_full_1 = start_partial + 13;
+        bb_t swap = w[in0 + 32], s[W];
+        out[t++] = bb_mul(swap, bb_sub(swap, 1));
+        for (int i = 0; i < 8; i++) out[t++] = bb_sub(bb_mul(swap, bb_sub(w[in0 + i + 8], w[in0 + i])), w[start_delta + i]);
+        for (int i = 0; i < 8; i++) {
+            s[i] = bb_add(w[in0 + i], w[start_delta + i]);
+            s[i + 8] = bb_sub(w[in0 + i + 8], w[start_delta + i]);
+        }
+        permute_external(s);
+        for (int r = 0; r < 4; r++) {
+            for (int i = 0; i < W; i++) s[i] = bb_add(s[i], EXT_RC[r][i]);
+            if (r > 0)
+                for (int i = 0; i < W; i++) {
+                    bb_t in = w[start_full_0 + W * (r - 1) + i];
+                    out[t++] = bb_sub(s[i], in);
+                    s[i] = in;
+                }
+            for (int i = 0; i < W; i++) s[i] = sbox7(s[i]);
+            permute_external(s);
+        }
+        for (int r = 0; r < 13; r++) {
+            s[0] = bb_add(s[0], INT_RC[r]);
+            bb_t in = w[start_partial + r];
+            out[t++] = bb_sub(s[0], in);
+            s[0] = sbox7(in);
+            permute_internal(s);
+        }
+        for (int r = 4; r < 8; r++) {
+            for (int i = 0; i < W; i++) s[i] = bb_add(s[i], EXT_RC[r][i]);
+            for (int i = 0; i < W; i++) {
+                bb_t in = w[start_full_1 + W * (r - 4) + i];
+                out[t++] = bb_sub(s[i], in);
+                s[i] = in;
+            }
+            for (int i = 0; i < W; i++) s[i] = sbox7(s[i]);
+            permute_external(s);
+        }
+        for (int i = 0; i < W; i++) out[t++] = bb_sub(s[i], w[out0 + i]);
+    }
+}
+
 void gbo_bb_hash_no_pad(const bb_t *in, size_t n, bb_t out[HOUT]) {
     bb_t st[W] = {0};
     for (size_t off = 0; off < n; off += RATE) {

@@ -76,4 +76,6 @@ void gbo_bb_challenger_observe(challenger_t *c, const bb_t *e, size_t n);
 bb_t gbo_bb_challenger_get(challenger_t *c);
 
 #define X_POSEIDON_GATE(w, out) do { (void)(w); for (unsigned q_ = 0; q_ < 123; q_++) (out)[q_] = 0; rc = -12; } while (0) /* Goldilocks gate */
+void gbo_bb_poseidon2_gate_constraints(const uint32_t *w, unsigned num_ops, uint32_t *out);
+#define X_POSEIDON2_GATE(w, nops, out) gbo_bb_poseidon2_gate_constraints(w, nops, out)
 #include "prover_impl.h"

@@ -49,4 +49,5 @@ void gbo_gl_challenger_observe(challenger_t *c, const gl_t *e, size_t n);
 gl_t gbo_gl_challenger_get(challenger_t *c);
 
 #define X_POSEIDON_GATE(w, out) gbo_gl_poseidon_gate_constraints(w, out)
+#define X_POSEIDON2_GATE(w, nops, out) do { (void)(w); (void)(nops); (out)[0] = 0; rc = -12; } while (0) /* BabyBear gate */
 #include "prover_impl.h"

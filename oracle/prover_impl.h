@@ -29,14 +29,15 @@ typedef struct {
     unsigned gate_noop, gate_constant, gate_pi; /* indices in the sorted gate list (selector values) */
     unsigned num_gate_consts;    /* ConstantGate num_consts */
     /* CommonCircuitData.gates sorted by (degree, id) with selectors_info flattened: {kind, param, selector_index,
-     * group_start, group_end}; kind 0 Noop, 1 Constant{param}, 2 PublicInput, 3 Arithmetic{param = num_ops}, 4 Poseidon */
+     * group_start, group_end}; kind 0 Noop, 1 Constant{param}, 2 PublicInput, 3 Arithmetic{param = num_ops}, 4 Poseidon,
+     * 5 Poseidon2BabyBear{param = num_ops} */
     unsigned num_gates;
     unsigned gates[16][5];
 } gbo_circuit_cfg;
 #endif
 
 
-#define GBO_MAX_GATE_CONSTRAINTS 128
+#define GBO_MAX_GATE_CONSTRAINTS 160
 #define GBO_MAX_TERMS 512
 
 typedef struct {
@@ -192,7 +193,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
         unsigned ngc = 0;
         for (unsigned g = 0; g < cfg->num_gates; g++) {
             const unsigned kind = cfg->gates[g][0], param = cfg->gates[g][1];
-            unsigned m = kind == 1 || kind == 3 ? param : (kind == 2 ? HOUT : (kind == 4 ? 123 : 0));
+            unsigned m = kind == 1 || kind == 3 ? param : (kind == 2 ? HOUT : (kind == 4 ? 123 : (kind == 5 ? 150 * param : 0)));
             if (m > ngc) ngc = m;
         }
         const unsigned nterms = c + c * nchunks + ngc; /* z_1 terms, partial product terms, gate constraints */
@@ -248,6 +249,9 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
                     else if (kind == 4) {  /* gates/poseidon_goldilocks.rs:223-313 */
                         X_POSEIDON_GATE(lw, gcons);
                         m = 123;
+                    } else if (kind == 5) { /* gates/poseidon2_babybear.rs:315-413 */
+                        X_POSEIDON2_GATE(lw, param, gcons);
+                        m = 150 * param;
                     }
                     for (unsigned j = 0; j < m; j++) cons[j] = F_ADD(cons[j], F_MUL(f, gcons[j]));
                 }

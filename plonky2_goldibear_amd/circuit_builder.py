@@ -11,9 +11,10 @@ Python so that circuits other than the dummy one - the reference's `factorial` e
     proof = data.prove(pw)                      # witness generation on the host, prove() on the GPU
     data.verify(proof)
 
-Gates: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate (gates/arithmetic_base.rs) and, for Goldilocks, PoseidonGate
-(gates/poseidon_goldilocks.rs) - which `build()` itself needs as soon as a circuit has public inputs, because it hashes them
-in-circuit (circuit_builder.rs:1126-1137).  Not the GPU hot path: plain Python integers.
+Gates: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate (gates/arithmetic_base.rs) and the in-circuit hash of the
+configuration - PoseidonGate (gates/poseidon_goldilocks.rs) for Goldilocks, Poseidon2BabyBearGate (gates/poseidon2_babybear.rs)
+for BabyBear - which `build()` itself needs as soon as a circuit has public inputs, because it hashes them in-circuit
+(circuit_builder.rs:1126-1137).  Not the GPU hot path: plain Python integers.
 """
 import os
 import re
@@ -23,7 +24,7 @@ import numpy as np
 from . import native as N
 from .dummy_circuit import BB_P, P as GL_P, bb_mul, bb_powers, gl_mul, gl_powers
 
-GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4  # gb_gate.kind
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_POSEIDON2_BABYBEAR = 0, 1, 2, 3, 4, 5  # gb_gate.kind
 
 
 class CircuitConfig:
@@ -140,6 +141,30 @@ class PoseidonGate(Gate):
         return [_PoseidonGenerator(row)]
 
 
+class Poseidon2BabyBearGate(Gate):
+    """gates/poseidon2_babybear.rs:48-147, 473-497: num_ops width-16 Poseidon2 permutations per row; per op 33 routed wires
+    (16 in, 16 out, swap) for all ops first, then per op 133 non-routed wires (8 deltas, the s-box inputs of full rounds 1..3,
+    of the 13 internal rounds and of full rounds 4..7).  recursion_config_bb_narrow (167 wires, 41 routed) fits one op."""
+    kind, degree = GATE_POSEIDON2_BABYBEAR, 7
+    ROUTED, NON_ROUTED = 33, 8 + 16 * 7 + 13
+
+    def __init__(self, num_ops):
+        self.param = self.num_ops = num_ops
+        self.num_wires = (self.ROUTED + self.NON_ROUTED) * num_ops
+        self.num_constraints = (1 + 8 + 16 * 7 + 13 + 16) * num_ops
+        # Debug of the gate struct; the type name inside PhantomData is p3's (BabyBear is an alias of MontyField31<..>).  Only
+        # the relative order of ids within one degree matters (circuit_builder.rs:1195-1196) and this is the only degree-7 gate.
+        self.id = ("Poseidon2BabyBearGate { num_ops: %d, _phantom: PhantomData<p3_monty_31::monty_31::MontyField31<"
+                   "p3_baby_bear::baby_bear::BabyBearParameters>> }<WIDTH=16>" % num_ops)
+
+    @classmethod
+    def new_from_config(cls, cfg):
+        return cls(min(cfg.num_wires // (cls.ROUTED + cls.NON_ROUTED), cfg.num_routed_wires // cls.ROUTED))
+
+    def generators(self, row, constants):
+        return [_Poseidon2Generator(row, self.num_ops, op) for op in range(self.num_ops)]
+
+
 # --------------------------------------------------------------------------------------------- targets, generators
 def wire(row, column):
     return ("w", row, column)
@@ -197,6 +222,27 @@ class _PoseidonGenerator:
             w.set(wire(row, col), v)
 
 
+class _Poseidon2Generator:
+    """gates/poseidon2_babybear.rs:536-676"""
+
+    def __init__(self, row, num_ops, op):
+        self.row, self.num_ops, self.op = row, num_ops, op
+        self.deps = [wire(row, 33 * op + c) for c in range(16)] + [wire(row, 33 * op + 32)]
+
+    def run(self, w, p):
+        row, op = self.row, self.op
+        state = [w.get(t) for t in self.deps[:16]]
+        swap = w.get(self.deps[16])
+        assert swap in (0, 1)
+        start_delta = self.num_ops * 33 + op * 133
+        for i in range(8):
+            w.set(wire(row, start_delta + i), swap * (state[i + 8] - state[i]) % p)
+        if swap:
+            state = state[8:] + state[:8]
+        for col, v in poseidon2_gate_trace(state, start_delta + 8, 33 * op + 16).items():
+            w.set(wire(row, col), v)
+
+
 _POSEIDON_TABLES = None
 
 
@@ -206,7 +252,7 @@ def _poseidon_tables():
     if _POSEIDON_TABLES is None:
         text = open(os.path.join(os.path.dirname(__file__), "csrc", "poseidon_constants.h")).read()
         tabs = {}
-        for m in re.finditer(r"#define GL_POSEIDON_(\w+)_LIST \\\n((?:[^\n]*\\\n)*[^\n]*)", text):
+        for m in re.finditer(r"#define (?:GL_POSEIDON|BB_POSEIDON2)_(\w+)_LIST \\\n((?:[^\n]*\\\n)*[^\n]*)", text):
             tabs[m.group(1)] = [int(x.rstrip("uUlL"), 0) for x in re.findall(r"0x[0-9a-fA-F]+[uUlL]*|\d+[uUlL]*", m.group(2))]
         _POSEIDON_TABLES = tabs
     return _POSEIDON_TABLES
@@ -250,6 +296,49 @@ def poseidon_gate_trace(state):
         ctr += 1
     for i in range(12):
         out[12 + i] = s[i]
+    return out
+
+
+def poseidon2_gate_trace(state, start_full_0, out0):
+    """The width-16 Poseidon2 permutation as Poseidon2BabyBearGenerator runs it (gates/poseidon2_babybear.rs:608-676),
+    returning {wire column: value} for the s-box-input wires (from start_full_0) and the outputs (from out0)."""
+    T, p = _poseidon_tables(), BB_P
+    ext, internal = T["EXTERNAL_CONSTANTS"], T["INTERNAL_CONSTANTS"]
+    shifts = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15]
+    out = {}
+
+    def external(s):
+        s = list(s)
+        for i in range(0, 16, 4):
+            x0, x1, x2, x3 = s[i:i + 4]
+            s[i:i + 4] = [2 * x0 + 3 * x1 + x2 + x3, x0 + 2 * x1 + 3 * x2 + x3, x0 + x1 + 2 * x2 + 3 * x3, 3 * x0 + x1 + x2 + 2 * x3]
+        sums = [sum(s[k::4]) for k in range(4)]
+        return [(s[i] + sums[i % 4]) % p for i in range(16)]
+
+    s = external(state)
+    for r in range(4):
+        s = [(s[i] + ext[16 * r + i]) % p for i in range(16)]
+        if r:
+            for i in range(16):
+                out[start_full_0 + 16 * (r - 1) + i] = s[i]
+        s = external([pow(x, 7, p) for x in s])
+    start_partial = start_full_0 + 48
+    for r in range(13):
+        s[0] = (s[0] + internal[r]) % p
+        out[start_partial + r] = s[0]
+        s[0] = pow(s[0], 7, p)
+        s = [x * 943718400 % p for x in s]
+        part = sum(s[1:]) % p
+        full = (part + s[0]) % p
+        s = [(part - s[0]) % p] + [(full + (s[i + 1] << shifts[i])) % p for i in range(15)]
+    start_full_1 = start_partial + 13
+    for r in range(4, 8):
+        s = [(s[i] + ext[16 * r + i]) % p for i in range(16)]
+        for i in range(16):
+            out[start_full_1 + 16 * (r - 4) + i] = s[i]
+        s = external([pow(x, 7, p) for x in s])
+    for i in range(16):
+        out[out0 + i] = s[i]
     return out
 
 
@@ -470,8 +559,15 @@ class CircuitBuilder:
     # ---- hashing (plonk/config.rs:135-166, hash/poseidon_goldilocks.rs:1116-1143)
     def permute(self, state):
         if self.config.field != N.GB_GOLDILOCKS:
-            raise NotImplementedError("in-circuit Poseidon2 (Poseidon2BabyBearGate) is not restated: BabyBear circuits "
-                                      "cannot have public inputs here")
+            # hash/poseidon2_babybear.rs:183-213: a slot of a Poseidon2BabyBearGate
+            gate = Poseidon2BabyBearGate.new_from_config(self.config)
+            if gate.num_ops != 1:
+                raise NotImplementedError("Poseidon2BabyBearGate with several operations per row (complete_wires) is not restated")
+            row, op = self.find_slot(gate, (), ())
+            self.connect(self.zero(), wire(row, 33 * op + 32))
+            for i in range(16):
+                self.connect(state[i], wire(row, 33 * op + i))
+            return [wire(row, 33 * op + 16 + i) for i in range(16)]
         row = self.add_gate(PoseidonGate())
         self.connect(self.zero(), wire(row, PoseidonGate.WIRE_SWAP))   # swap = _false()
         for i in range(12):

@@ -8,6 +8,8 @@
 //   ArithmeticGate{num_ops}  gates/arithmetic_base.rs:83-100   out - (c0 * m0 * m1 + c1 * addend), wires 4i..4i+3
 //   PoseidonGate (GL only)   gates/poseidon_goldilocks.rs:124-221  swap bit, 4 deltas, the s-box inputs of every round but the
 //                            first (fast partial-round form: hash/poseidon_goldilocks.rs:632-770), 12 outputs = 123 constraints
+//   Poseidon2BabyBearGate{num_ops} (BB only)  gates/poseidon2_babybear.rs:203-313  per operation: swap bit, 8 deltas, the s-box
+//                            inputs of every round but the first, 16 outputs = 150 constraints
 // The caller multiplies by the gate's filter (gates/gate.rs:391-404) and folds with powers of alpha.
 #pragma once
 #include "field_traits.hpp"
@@ -24,6 +26,7 @@ GB_HD u32 num_constraints(const gb_gate& g) {
         case GB_GATE_PUBLIC_INPUT: return F::H;
         case GB_GATE_ARITHMETIC: return g.param;
         case GB_GATE_POSEIDON: return POSEIDON_NUM_CONSTRAINTS;
+        case GB_GATE_POSEIDON2_BABYBEAR: return POSEIDON2_BB_CONSTRAINTS_PER_OP * g.param;
         default: return 0;
     }
 }
@@ -34,6 +37,7 @@ GB_HD u32 num_wires(const gb_gate& g) {
         case GB_GATE_PUBLIC_INPUT: return F::H;
         case GB_GATE_ARITHMETIC: return 4 * g.param;
         case GB_GATE_POSEIDON: return 135;
+        case GB_GATE_POSEIDON2_BABYBEAR: return POSEIDON2_BB_WIRES_PER_OP * g.param;
         default: return 0;
     }
 }
@@ -195,6 +199,112 @@ GB_HD void eval_poseidon(W&& wire, Emit&& emit) {
     for (u32 i = 0; i < 12; i++) emit(A::sub(s[i], wire(12 + i)));
 }
 
+// Poseidon2BabyBearGate::eval_unfiltered.  Wire layout (:56-147): per op 33 routed wires (16 in, 16 out, swap) first for all
+// ops, then per op 133 non-routed (8 deltas, s-box inputs of full rounds 1..3, of the 13 internal rounds, of full rounds 4..7).
+struct Poseidon2Tab {
+    u32 ext[128], internal[13];
+};
+#define GB_POSEIDON2_TAB_INIT {{BB_POSEIDON2_EXTERNAL_CONSTANTS_LIST}, {BB_POSEIDON2_INTERNAL_CONSTANTS_LIST}}
+static const Poseidon2Tab POSEIDON2_TAB_HOST = GB_POSEIDON2_TAB_INIT;
+__device__ static const Poseidon2Tab POSEIDON2_TAB_DEV = GB_POSEIDON2_TAB_INIT;
+GB_HD const Poseidon2Tab& poseidon2_tab() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return POSEIDON2_TAB_DEV;
+#else
+    return POSEIDON2_TAB_HOST;
+#endif
+}
+template <class A>
+GB_HD void p2_external(typename A::V (&s)[16]) {  // permute_external_mut (:804-832), apply_mat4 (:903-917)
+    typedef typename A::V V;
+#pragma unroll
+    for (u32 i = 0; i < 16; i += 4) {
+        const V t01 = A::add(s[i], s[i + 1]), t23 = A::add(s[i + 2], s[i + 3]), t0123 = A::add(t01, t23);
+        const V t01123 = A::add(t0123, s[i + 1]), t01233 = A::add(t0123, s[i + 3]);
+        const V n3 = A::add(t01233, A::add(s[i], s[i])), n1 = A::add(t01123, A::add(s[i + 2], s[i + 2]));
+        s[i] = A::add(t01123, t01);
+        s[i + 2] = A::add(t01233, t23);
+        s[i + 1] = n1;
+        s[i + 3] = n3;
+    }
+    V sums[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) sums[k] = A::add(A::add(s[k], s[4 + k]), A::add(s[8 + k], s[12 + k]));
+#pragma unroll
+    for (u32 i = 0; i < 16; i++) s[i] = A::add(s[i], sums[i % 4]);
+}
+template <class F, class A>
+GB_HD void p2_internal(typename A::V (&s)[16]) {  // permute_internal_mut (:787-802)
+    typedef typename A::V V;
+    constexpr u32 SHIFTS[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};
+    const typename F::T k = F::enc(943718400u);
+#pragma unroll
+    for (u32 i = 0; i < 16; i++) s[i] = A::mulc(s[i], k);
+    V part = s[1];
+#pragma unroll
+    for (u32 i = 2; i < 16; i++) part = A::add(part, s[i]);
+    const V full = A::add(part, s[0]);
+    s[0] = A::sub(part, s[0]);
+#pragma unroll
+    for (u32 i = 0; i < 15; i++) s[i + 1] = A::add(full, A::mulc(s[i + 1], F::enc((u64)1 << SHIFTS[i])));
+}
+template <class F, class A, class W, class Emit>
+GB_HD void eval_poseidon2_bb(u32 num_ops, W&& wire, Emit&& emit) {
+    typedef typename A::V V;
+    const Poseidon2Tab& t = poseidon2_tab();
+    constexpr u32 ROUTED = 33, NON_ROUTED = 8 + 16 * 7 + 13;
+    for (u32 op = 0; op < num_ops; op++) {
+        const u32 in0 = ROUTED * op, out0 = in0 + 16, start_delta = num_ops * ROUTED + op * NON_ROUTED;
+        const u32 start_full_0 = start_delta + 8, start_partial = start_full_0 + 48, start_full_1 = start_partial + 13;
+        const V swap = wire(in0 + 32);
+        emit(A::mul(swap, A::sub(swap, A::cst(F::one()))));
+        V s[16];
+#pragma unroll
+        for (u32 i = 0; i < 8; i++) {
+            const V lhs = wire(in0 + i), rhs = wire(in0 + i + 8), delta = wire(start_delta + i);
+            emit(A::sub(A::mul(swap, A::sub(rhs, lhs)), delta));
+            s[i] = A::add(lhs, delta);
+            s[i + 8] = A::sub(rhs, delta);
+        }
+        p2_external<A>(s);
+#pragma unroll 1
+        for (u32 r = 0; r < 4; r++) {
+#pragma unroll
+            for (u32 i = 0; i < 16; i++) s[i] = A::addc(s[i], F::enc(t.ext[16 * r + i]));
+            if (r > 0) {
+#pragma unroll
+                for (u32 i = 0; i < 16; i++) {
+                    const V in = wire(start_full_0 + 16 * (r - 1) + i);
+                    emit(A::sub(s[i], in));
+                    s[i] = in;
+                }
+            }
+#pragma unroll
+            for (u32 i = 0; i < 16; i++) s[i] = sbox7<A>(s[i]);
+            p2_external<A>(s);
+        }
+#pragma unroll 1
+        for (u32 r = 0; r < 13; r++) {
+            const V in = wire(start_partial + r);
+            emit(A::sub(A::addc(s[0], F::enc(t.internal[r])), in));
+            s[0] = sbox7<A>(in);
+            p2_internal<F, A>(s);
+        }
+#pragma unroll 1
+        for (u32 r = 4; r < 8; r++) {
+#pragma unroll
+            for (u32 i = 0; i < 16; i++) {
+                const V in = wire(start_full_1 + 16 * (r - 4) + i);
+                emit(A::sub(A::addc(s[i], F::enc(t.ext[16 * r + i])), in));
+                s[i] = sbox7<A>(in);
+            }
+            p2_external<A>(s);
+        }
+#pragma unroll
+        for (u32 i = 0; i < 16; i++) emit(A::sub(s[i], wire(out0 + i)));
+    }
+}
+
 // wire(col) / konst(i) give the opened (or LDE) value of a wire / of the i-th constant after the selectors
 template <class F, class A, class W, class K, class Emit>
 GB_HD void eval_gate(const gb_gate& g, W&& wire, K&& konst, const typename F::T* pi_hash, Emit&& emit) {
@@ -216,6 +326,9 @@ GB_HD void eval_gate(const gb_gate& g, W&& wire, K&& konst, const typename F::T*
         }
         case GB_GATE_POSEIDON:
             if constexpr (F::TAG == 0) eval_poseidon<A>(wire, emit);
+            break;
+        case GB_GATE_POSEIDON2_BABYBEAR:
+            if constexpr (F::TAG == 1) eval_poseidon2_bb<F, A>(g.param, wire, emit);
             break;
         default:
             break;

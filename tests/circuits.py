@@ -53,6 +53,20 @@ def poly_chain_circuit(config, steps, x0=3):
     return b, pw
 
 
+def babybear_public_input_circuit(steps=58, x0=5, **cfg_kw):
+    """y <- y * i + x for i = 2.., with x and the result as public inputs: build() hashes them through a Poseidon2BabyBearGate"""
+    b = CircuitBuilder(CircuitConfig.recursion_config_bb_narrow(**cfg_kw))
+    x = b.add_virtual_target()
+    cur = x
+    for i in range(2, 2 + steps):
+        cur = b.mul_add(cur, b.constant(i), x)
+    b.register_public_input(x)
+    b.register_public_input(cur)
+    pw = PartialWitness()
+    pw.set_target(x, x0)
+    return b, pw
+
+
 def oracle_circuit(built, num_public_inputs):
     cfg = built.config
     F = GL if cfg.field == N.GB_GOLDILOCKS else BB

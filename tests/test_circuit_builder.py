@@ -13,7 +13,7 @@ from oracle.fields import BB, GL
 from plonky2_goldibear_amd.circuit_builder import (ArithmeticGate, CircuitBuilder, CircuitConfig, PartialWitness, PoseidonGate,
                                                    poseidon_gate_trace)
 
-from circuits import factorial_circuit, fibonacci_circuit, oracle_circuit, poly_chain_circuit
+from circuits import babybear_public_input_circuit, factorial_circuit, fibonacci_circuit, oracle_circuit, poly_chain_circuit
 
 
 def test_factorial_build_structure():
@@ -141,3 +141,38 @@ def test_oracle_prove_verify_babybear_arithmetic():
     p2, _ = PD.prove_cpu(oc, w, pis)
     with pytest.raises(AssertionError):
         PD.verify(oc, p2)
+
+
+def test_babybear_public_inputs_poseidon2_gate():
+    from oracle import oracle_bb as B
+    b, pw = babybear_public_input_circuit()
+    c = b.build()
+    assert [g[0] for g in c.gate_table] == [0, 1, 2, 3, 5] and c.num_selectors == 2 and c.gate_table[4] == (5, 1, 1, 4, 5)
+    w, pis = c.generate_witness(pw)
+    row = next(r for r, (g, _) in enumerate(b.gate_instances) if g.kind == 5)
+    # the gate row is one Poseidon2 permutation of (x, result, 0, ...); the PublicInputGate row carries hash(public inputs)
+    assert (B.poseidon2(w[:16, row].copy()) == w[16:32, row]).all()
+    pi_row = next(r for r, (g, _) in enumerate(b.gate_instances) if g.kind == 2)
+    assert (w[:8, pi_row] == B.hash_no_pad(np.array(pis, dtype=np.uint32))).all()
+    # C (base field) and Python (extension field) restatements of the 150 constraints agree, on a valid and on a broken row
+    L = O.lib()
+    out = np.ones(150, dtype=np.uint32)
+    L.gbo_bb_poseidon2_gate_constraints(np.ascontiguousarray(w[:, row]).ctypes.data_as(O.C.c_void_p), 1, out.ctypes.data_as(O.C.c_void_p))
+    assert not out.any()
+    bad = w[:, row].copy()
+    bad[70] ^= 1
+    L.gbo_bb_poseidon2_gate_constraints(np.ascontiguousarray(bad).ctypes.data_as(O.C.c_void_p), 1, out.ctypes.data_as(O.C.c_void_p))
+    ext = G.eval_unfiltered(BB, (5, 1, 1, 4, 5), [BB.efrom(int(x)) for x in bad], [], None)
+    assert out.any() and [int(x) for x in out] == [v[0] for v in ext]
+    oc = oracle_circuit(c, 2)
+    proof, _ = PD.prove_cpu(oc, w, pis)
+    assert PD.verify(oc, proof)
+    p2, _ = PD.prove_cpu(oc, _with_row(w, row, bad), pis)
+    with pytest.raises(AssertionError):
+        PD.verify(oc, p2)
+
+
+def _with_row(w, row, col_values):
+    w2 = w.copy()
+    w2[:, row] = col_values
+    return w2

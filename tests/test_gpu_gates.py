@@ -12,7 +12,7 @@ from plonky2_goldibear_amd import CircuitData, GpuContext, ShapeError, VerifyErr
 from plonky2_goldibear_amd import native as N
 from plonky2_goldibear_amd.circuit_builder import CircuitConfig
 
-from circuits import factorial_circuit, fibonacci_circuit, oracle_circuit, poly_chain_circuit
+from circuits import babybear_public_input_circuit, factorial_circuit, fibonacci_circuit, oracle_circuit, poly_chain_circuit
 
 pytestmark = pytest.mark.gpu
 
@@ -72,6 +72,24 @@ def test_babybear_arithmetic_bytes_match_oracle(ctx):
     got = c.data.prove(w, pis)
     assert got == want
     assert c.data.verify(got) and PD.verify(oc, got)
+
+
+@pytest.mark.parametrize("kw", [{}, dict(steps=2000, num_challenges=7)])
+def test_babybear_public_inputs_bytes_match_oracle(ctx, kw):
+    """a BabyBear circuit with public inputs: Poseidon2BabyBearGate row + two selector groups"""
+    b, pw = babybear_public_input_circuit(**kw)
+    c = b.build(ctx)
+    w, pis = c.generate_witness(pw)
+    oc = oracle_circuit(c, 2)
+    assert (c.data.circuit_digest == oc.circuit_digest).all()
+    want, _ = PD.prove_cpu(oc, w, pis)
+    got = c.data.prove(w, pis)
+    assert got == want
+    assert c.data.verify(got) and PD.verify(oc, got)
+    row = next(r for r, (g, _) in enumerate(b.gate_instances) if g.kind == 5)
+    w[70, row] ^= 1
+    with pytest.raises(VerifyError, match="vanishing"):
+        c.data.verify(c.data.prove(w, pis))
 
 
 def test_goldilocks_arithmetic_only_single_selector(ctx):
