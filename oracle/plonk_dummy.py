@@ -95,6 +95,22 @@ class DummyCircuit:
         self.num_selectors, self.num_public_inputs = 1, 0
         self.gate_table = [(G.NOOP, 0, 0, 0, 3), (G.CONSTANT, cfg.num_constants, 0, 0, 3), (G.PUBLIC_INPUT, H, 0, 0, 3)]
 
+    @classmethod
+    def verifier_view(cls, degree_bits, cfg, F, k_is):
+        """Only what verify() reads (CommonCircuitData of the dummy gate set), without materialising the
+        constants/sigmas columns; call set_cap() with the prover side's cap afterwards."""
+        self = cls.__new__(cls)
+        H = F.hout
+        self.cfg, self.degree_bits, self.F, self.n = cfg, degree_bits, F, 1 << degree_bits
+        self.k_is = np.asarray(k_is, dtype=F.dtype)
+        self.num_constants = 1 + cfg.num_constants
+        self.num_partial_products = -(-cfg.num_routed_wires // cfg.max_quotient_degree_factor) - 1
+        self.reduction_arity_bits = reduction_arity_bits(cfg, degree_bits)
+        self._digest, self.constants_sigmas_cap = None, None
+        self.num_selectors, self.num_public_inputs = 1, 0
+        self.gate_table = [(G.NOOP, 0, 0, 0, 3), (G.CONSTANT, cfg.num_constants, 0, 0, 3), (G.PUBLIC_INPUT, H, 0, 0, 3)]
+        return self
+
     def set_cap(self, cap):
         """circuit_digest = hash_no_pad(cap.flatten() ++ hash_pad(domain_sep = []) ++ [degree_bits])"""
         F = self.F

@@ -74,12 +74,8 @@ def test_bb_config4_2p20_rows(ctx):
     k = 20
     cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(k)
     gpu = CircuitData.babybear(ctx, k, cs, k_is, num_challenges=10)
-    circ = D.DummyCircuit.__new__(D.DummyCircuit)  # verifier-side view without the CPU commit of 44 x 2^20 columns
-    cfg = D.CircuitConfig.babybear(10)
-    circ.cfg, circ.degree_bits, circ.F, circ.n = cfg, k, BB, 1 << k
-    circ.k_is, circ.num_constants = k_is, 1 + cfg.num_constants
-    circ.num_partial_products = -(-cfg.num_routed_wires // cfg.max_quotient_degree_factor) - 1
-    circ.reduction_arity_bits = D.reduction_arity_bits(cfg, k)
+    # verifier-side view without the CPU commit of 44 x 2^20 columns
+    circ = D.DummyCircuit.verifier_view(k, D.CircuitConfig.babybear(10), BB, k_is)
     circ.set_cap(gpu.constants_sigmas_cap)
     assert (gpu.circuit_digest == circ.circuit_digest).all()
     proof = gpu.prove(DC.dummy_witness_bb(k, pi_row, seed=3))

@@ -63,3 +63,19 @@ def test_bb_bad_witness_fails_the_identity():
     proof, _ = D.prove_cpu(circ, w)
     with pytest.raises(AssertionError):
         D.verify(circ, proof)
+
+
+def test_verifier_view_accepts_what_the_full_circuit_accepts():
+    """The GPU tests at 2^20 rows verify through DummyCircuit.verifier_view (no CPU commit of the constants/sigmas
+    columns); here the view is checked against the full object on a size the oracle prover finishes."""
+    circ = D.DummyCircuit(6, D.CircuitConfig.babybear(6), F=BB)
+    proof, _ = D.prove_cpu(circ, circ.witness(seed=2))
+    view = D.DummyCircuit.verifier_view(6, circ.cfg, BB, circ.k_is)
+    view.set_cap(circ.constants_sigmas_cap)
+    assert (view.circuit_digest == circ.circuit_digest).all()
+    assert view.common_data() == circ.common_data()
+    assert D.verify(view, proof)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises(AssertionError):
+        D.verify(view, bytes(bad))
