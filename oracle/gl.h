@@ -21,14 +21,16 @@ typedef uint64_t gl_t;
 #define GL_TWO_ADICITY 32
 #define GL_EXT_W 7ULL
 
-static inline gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
+/* All selections below are written as masks: on random field elements every carry is a coin flip and a
+ * mispredicted branch costs more than the arithmetic. */
+static inline gl_t gl_canon(uint64_t x) { return x - (-(uint64_t)(x >= GL_P) & GL_P); }
 
 static inline gl_t gl_add(gl_t a, gl_t b) {
     uint64_t s = a + b;
-    if (s < a) s += GL_EPS; /* wrapped: 2^64 = 2^32 - 1 (mod p) */
+    s += -(uint64_t)(s < a) & GL_EPS; /* wrapped: 2^64 = 2^32 - 1 (mod p) */
     return gl_canon(s);
 }
-static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
+static inline gl_t gl_sub(gl_t a, gl_t b) { return a - b + (-(uint64_t)(a < b) & GL_P); }
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 
 /* 128-bit -> canonical. Follows the same split the reference uses for its Poseidon
@@ -37,10 +39,10 @@ static inline gl_t gl_reduce128(unsigned __int128 x) {
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;
+    t0 -= -(uint64_t)(lo < hi_hi) & GL_EPS;
     uint64_t t1 = hi_lo * GL_EPS;
     uint64_t t2 = t0 + t1;
-    if (t2 < t0) t2 += GL_EPS;
+    t2 += -(uint64_t)(t2 < t0) & GL_EPS;
     return gl_canon(t2);
 }
 static inline gl_t gl_mul(gl_t a, gl_t b) { return gl_reduce128((unsigned __int128)a * b); }

@@ -28,8 +28,9 @@ typedef uint32_t bb_t;
 #define RATE 8
 #define HOUT 8
 
-static inline bb_t bb_add(bb_t a, bb_t b) { uint32_t s = a + b; return s >= BB_P ? s - BB_P : s; }
-static inline bb_t bb_sub(bb_t a, bb_t b) { return a >= b ? a - b : a + BB_P - b; }
+/* selections as masks (the carries are coin flips on random data; a mispredicted branch costs more than the arithmetic) */
+static inline bb_t bb_add(bb_t a, bb_t b) { uint32_t s = a + b; return s - (-(uint32_t)(s >= BB_P) & BB_P); }
+static inline bb_t bb_sub(bb_t a, bb_t b) { return a - b + (-(uint32_t)(a < b) & BB_P); }
 static inline bb_t bb_mul(bb_t a, bb_t b) { return (bb_t)(((uint64_t)a * b) % BB_P); }
 static inline bb_t bb_pow(bb_t b, uint64_t e) { bb_t r = 1; while (e) { if (e & 1) r = bb_mul(r, b); b = bb_mul(b, b); e >>= 1; } return r; }
 static inline bb_t bb_inv(bb_t a) { return bb_pow(a, BB_P - 2); }

@@ -90,39 +90,108 @@ void gbo_gl_poseidon_naive(const gl_t in[W], gl_t out[W]) {
     memcpy(out, s, sizeof s);
 }
 
-/* hash/poseidon_goldilocks.rs:899-922 (the optimised form the reference actually runs;
- * output-identical to the naive form, asserted by the reference at :1196-1198 and here in
- * tests/test_oracle_kats.py).  partial_first_constant_layer :632-638, mds_partial_layer_init
- * :657-683, mds_partial_layer_fast :718-744. */
+/* ---- the form the CPU baseline runs.  The reference's scalar path (hash/poseidon_goldilocks.rs:889-922) keeps the state as
+ * arbitrary u64 representatives between layers (reduce128 :254-267 does not canonicalise), accumulates the partial rounds' dot
+ * products in 128 bits before one reduction (mds_partial_layer_fast :718-744, reduce_u160) and fuses `s[i] + s0 * v[i]`
+ * (multiply_accumulate); restated here the same way.  Output-identical to gbo_gl_poseidon_naive, the defining form
+ * (the reference asserts the same at :1196-1198; here tests/test_oracle_kats.py). */
+static uint64_t RC_C[GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN], FP_FIRST_C[12], FP_RC_C[22], FP_VS_C[22][11], FP_WHATS_C[22][11],
+    FP_INIT_C[11][11];
+__attribute__((constructor)) static void poseidon_tables_init(void) {
+    for (size_t i = 0; i < GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN; i++) RC_C[i] = gl_canon(RC[i]);
+    for (int i = 0; i < 12; i++) FP_FIRST_C[i] = gl_canon(FP_FIRST[i]);
+    for (int k = 0; k < 22; k++) {
+        FP_RC_C[k] = gl_canon(FP_RC[k]);
+        for (int i = 0; i < 11; i++) { FP_VS_C[k][i] = gl_canon(FP_VS[k][i]); FP_WHATS_C[k][i] = gl_canon(FP_WHATS[k][i]); }
+    }
+    for (int r = 0; r < 11; r++) for (int c = 0; c < 11; c++) FP_INIT_C[r][c] = gl_canon(FP_INIT[r][c]);
+}
+/* any 128-bit value -> some u64 representative (gl_reduce128 without the final canonicalisation) */
+static inline uint64_t nc_reduce128(unsigned __int128 x) {
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    uint64_t t0 = lo - hi_hi;
+    t0 -= -(uint64_t)(lo < hi_hi) & GL_EPS; /* branch-free: the carries are coin flips on random data */
+    uint64_t t1 = hi_lo * GL_EPS;
+    uint64_t t2 = t0 + t1;
+    t2 += -(uint64_t)(t2 < t0) & GL_EPS;
+    return t2;
+}
+static inline uint64_t nc_mul(uint64_t a, uint64_t b) { return nc_reduce128((unsigned __int128)a * b); }
+/* a: any representative, c: canonical */
+static inline uint64_t nc_add_canon(uint64_t a, uint64_t c) {
+    uint64_t s = a + c;
+    return s + (-(uint64_t)(s < a) & GL_EPS);
+}
+static inline uint64_t nc_add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    uint64_t t = s + (-(uint64_t)(s < a) & GL_EPS);
+    return t + (-(uint64_t)(t < s) & GL_EPS);
+}
+static inline uint64_t nc_sbox(uint64_t x) {
+    uint64_t x2 = nc_mul(x, x), x4 = nc_mul(x2, x2), x3 = nc_mul(x, x2);
+    return nc_mul(x3, x4);
+}
+/* sum of up to 12 products held as (sum of low words, sum of high words) */
+typedef struct { unsigned __int128 lo, hi; } acc_t;
+static inline void acc_mul(acc_t *a, uint64_t x, uint64_t y) {
+    unsigned __int128 p = (unsigned __int128)x * y;
+    a->lo += (uint64_t)p;
+    a->hi += (uint64_t)(p >> 64);
+}
+static inline uint64_t acc_reduce(const acc_t *a) {
+    uint64_t h = nc_reduce128(a->hi);
+    return nc_add(nc_reduce128(a->lo), nc_reduce128((unsigned __int128)h << 64));
+}
+static inline void nc_mds_layer(uint64_t s[W]) {
+    uint64_t lo[2 * W], hi[2 * W];
+    for (int i = 0; i < W; i++) {
+        lo[i] = lo[i + W] = (uint32_t)s[i];
+        hi[i] = hi[i + W] = s[i] >> 32;
+    }
+    for (int r = 0; r < W; r++) {
+        uint64_t sl = lo[r] * MDS_DIAG[r], sh = hi[r] * MDS_DIAG[r];
+        for (int i = 0; i < W; i++) {
+            sl += lo[i + r] * MDS_CIRC[i];
+            sh += hi[i + r] * MDS_CIRC[i];
+        }
+        s[r] = nc_reduce128((unsigned __int128)sl + ((unsigned __int128)sh << 32));
+    }
+}
+static inline void nc_full_rounds(uint64_t s[W], int *round) {
+    for (int k = 0; k < HALF_FULL; k++) {
+        for (int i = 0; i < W; i++) s[i] = nc_sbox(nc_add_canon(s[i], RC_C[i + W * *round]));
+        nc_mds_layer(s);
+        (*round)++;
+    }
+}
 void gbo_gl_poseidon(const gl_t in[W], gl_t out[W]) {
-    gl_t s[W];
+    uint64_t s[W];
     memcpy(s, in, sizeof s);
     int round = 0;
-    full_rounds(s, &round);
-    for (int i = 0; i < W; i++) s[i] = gl_add(s[i], gl_canon(FP_FIRST[i]));
+    nc_full_rounds(s, &round);
+    for (int i = 0; i < W; i++) s[i] = nc_add_canon(s[i], FP_FIRST_C[i]);
     {
-        gl_t r[W];
+        uint64_t r[W];
         r[0] = s[0];
         for (int c = 1; c < W; c++) {
-            gl_t sum = 0;
-            for (int rr = 1; rr < W; rr++) sum = gl_add(sum, gl_mul(s[rr], gl_canon(FP_INIT[rr - 1][c - 1])));
-            r[c] = sum;
+            acc_t a = {0, 0};
+            for (int rr = 1; rr < W; rr++) acc_mul(&a, s[rr], FP_INIT_C[rr - 1][c - 1]);
+            r[c] = acc_reduce(&a);
         }
         memcpy(s, r, sizeof r);
     }
     for (int k = 0; k < N_PARTIAL; k++) {
-        s[0] = sbox(s[0]);
-        s[0] = gl_add(s[0], gl_canon(FP_RC[k]));
-        gl_t d = gl_mul(s[0], MDS_CIRC[0] + MDS_DIAG[0]);
-        for (int i = 1; i < W; i++) d = gl_add(d, gl_mul(s[i], gl_canon(FP_WHATS[k][i - 1])));
-        gl_t r[W];
-        r[0] = d;
-        for (int i = 1; i < W; i++) r[i] = gl_add(s[i], gl_mul(s[0], gl_canon(FP_VS[k][i - 1])));
-        memcpy(s, r, sizeof r);
+        uint64_t s0 = nc_add_canon(nc_sbox(s[0]), FP_RC_C[k]);
+        acc_t a = {0, 0};
+        acc_mul(&a, s0, MDS_CIRC[0] + MDS_DIAG[0]);
+        for (int i = 1; i < W; i++) acc_mul(&a, s[i], FP_WHATS_C[k][i - 1]);
+        for (int i = 1; i < W; i++) s[i] = nc_reduce128((unsigned __int128)s0 * FP_VS_C[k][i - 1] + s[i]);
+        s[0] = acc_reduce(&a);
     }
     round += N_PARTIAL;
-    full_rounds(s, &round);
-    memcpy(out, s, sizeof s);
+    nc_full_rounds(s, &round);
+    for (int i = 0; i < W; i++) out[i] = gl_canon(s[i]);
 }
 
 /* gates/poseidon_goldilocks.rs:223-313 PoseidonGate::eval_unfiltered_base_one: the 123 constraints of one row, in the

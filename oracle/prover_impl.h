@@ -16,6 +16,19 @@
 #include <omp.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+
+/* GBO_TIMING=1: wall time of each phase to stderr (named like the reference's timed!() scopes) */
+#ifndef GBO_SCOPE
+#define GBO_SCOPE(name)                                                                              \
+    do {                                                                                             \
+        if (gbo_timing_on) {                                                                         \
+            double t_now = omp_get_wtime();                                                          \
+            fprintf(stderr, "[oracle prove] %-44s %8.3f s\n", name, t_now - gbo_t_last);             \
+            gbo_t_last = t_now;                                                                      \
+        }                                                                                            \
+    } while (0)
+#endif
 
 extern double gbo_last_cs_commit_seconds; /* defined in oracle_gl.c */
 
@@ -104,6 +117,9 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     if (((size_t)1 << r) != qdf) return -10; /* step = 1 case only (prover.rs:746-749) */
     buf_t ob = {out, 0, out_cap};
     int rc = 0;
+    const int gbo_timing_on = getenv("GBO_TIMING") != NULL;
+    double gbo_t_last = omp_get_wtime();
+    (void)gbo_timing_on; (void)gbo_t_last;
     F_T *qvals = NULL, *qchunks = NULL, *fc0 = NULL, *fc1 = NULL, *fri_caps = NULL;
     E_T *final_poly = NULL, *values = NULL, *o_cs = NULL, *o_w = NULL, *o_z = NULL, *o_zn = NULL, *o_q = NULL;
     F_T **tree_leaves = NULL, **tree_digests = NULL;
@@ -119,6 +135,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     double t_cs = omp_get_wtime();
     if ((rc = batch_commit(&cs, constants_sigmas, ncs, lg, r, capH, 0))) return rc;
     gbo_last_cs_commit_seconds = omp_get_wtime() - t_cs;
+    GBO_SCOPE("constants/sigmas commit (build() work)");
     if ((rc = batch_commit(&wires, witness, nw, lg, r, capH, 0))) return rc;          /* prover.rs:261-272 */
 
     challenger_t ch;
@@ -135,6 +152,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     F_T *subgroup = malloc(n * sizeof(F_T));
     { F_T w = F_TWO_ADIC(lg), x = 1; for (size_t i = 0; i < n; i++) { subgroup[i] = x; x = F_MUL(x, w); } }
 
+    GBO_SCOPE("wires commit");
     /* ---- prover.rs:480-546: Z and partial products.  zs_pp columns: [Z_0..Z_{c-1}, pp_{0,0..}, pp_{1,0..}, ...] */
     const size_t nzs = (size_t)c * (1 + num_prods);
     F_T *zs_vals = malloc(nzs * n * sizeof(F_T));
@@ -176,10 +194,12 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
         free(cp);
     }
     if (rc) goto done_early;
+    GBO_SCOPE("Z and partial products");
     if ((rc = batch_commit(&zs, zs_vals, nzs, lg, r, capH, 0))) goto done_early;    /* prover.rs:328-339 */
     X_CH_OBSERVE(&ch, zs.cap, (size_t)HOUT << capH);
     for (unsigned i = 0; i < c; i++) alphas[i] = X_CH_GET(&ch);
 
+    GBO_SCOPE("zs commit");
     /* ---- prover.rs:712-926 compute_quotient_polys: step = 1, next_step = 2^r, lde_size = N */
     qvals = malloc((size_t)c * N * sizeof(F_T));
     {
@@ -272,6 +292,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
         X_COSET_IFFT(qvals + (size_t)k * N, lgN, F_GENERATOR);
         memcpy(qchunks + (size_t)k * qdf * n, qvals + (size_t)k * N, (size_t)qdf * n * sizeof(F_T));
     }
+    GBO_SCOPE("quotient values + coset_ifft");
     if ((rc = batch_commit(&quot, qchunks, (size_t)c * qdf, lg, r, capH, 1))) goto done;   /* prover.rs:376-387 */
     X_CH_OBSERVE(&ch, quot.cap, (size_t)HOUT << capH);
     E_T zeta = challenger_ext(&ch);
@@ -283,6 +304,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     E_T g_ext = E_FROM(F_TWO_ADIC(lg));
     E_T zeta_next = E_MUL(g_ext, zeta);
 
+    GBO_SCOPE("quotient commit");
     /* ---- OpeningSet::new (plonk/proof.rs:346-387) */
     const size_t nq = (size_t)c * qdf;
     o_cs = malloc(ncs * sizeof(E_T)); o_w = malloc(nw * sizeof(E_T)); o_z = malloc(nzs * sizeof(E_T));
@@ -317,6 +339,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     for (size_t j = 0; j < nq; j++) X_CH_OBSERVE(&ch, o_q[j].c, D);
     for (size_t j = 0; j < c; j++) X_CH_OBSERVE(&ch, o_zn[j].c, D);
 
+    GBO_SCOPE("opening set");
     /* ---- prove_openings (fri/oracle.rs:187-246) */
     E_T fri_alpha = challenger_ext(&ch);
     final_poly = calloc(N, sizeof(E_T)); /* lde(rate_bits): zero padded to N */
@@ -359,6 +382,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     size_t cur_len = N;
     unsigned cur_lg = lgN;
 
+    GBO_SCOPE("prove_openings");
     /* ---- fri_committed_trees (fri/prover.rs:83-133) */
     { /* ConstantArityBits (fri/reduction_strategies.rs:44-56) */
         unsigned db = lg;
@@ -408,6 +432,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     size_t final_len = cur_len >> r;
     for (size_t t = 0; t < final_len; t++) X_CH_OBSERVE(&ch, coeffs[t].c, D);
 
+    GBO_SCOPE("fri_committed_trees");
     /* ---- fri_proof_of_work (fri/prover.rs:136-188): minimum nonce (== find_any with one thread) */
     F_T pow_witness = 0;
     {
@@ -471,6 +496,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
         for (unsigned i = 0; i < c; i++) { debug_out[i] = betas[i]; debug_out[c + i] = gammas[i]; debug_out[2 * c + i] = alphas[i]; }
         for (int k = 0; k < D; k++) { debug_out[3 * c + k] = zeta.c[k]; debug_out[3 * c + D + k] = fri_alpha.c[k]; }
     }
+    GBO_SCOPE("pow + queries + serialise");
 done:
     if (tree_leaves) for (unsigned li = 0; li < narity; li++) { free(tree_leaves[li]); free(tree_digests[li]); }
     free(tree_leaves); free(tree_digests); free(tree_log); free(fri_caps);
