@@ -179,6 +179,37 @@ class BuiltCircuit(DummyCircuit):
         self._digest, self.constants_sigmas_cap = None, None
 
 
+class CommonDataCircuit(DummyCircuit):
+    """The verifier's view of a circuit given as serialized CommonCircuitData + VerifierOnlyCircuitData
+    (util/serialization/mod.rs:1862-1916, 1740-1760) - e.g. the reference's recursion regression fixture."""
+
+    def __init__(self, common_bytes, verifier_bytes, F=GL):
+        cd = V.read_common_data(common_bytes, F)
+        vd = V.read_verifier_data(verifier_bytes, F)
+        c, fc = cd["config"], cd["config"]["fri_config"]
+        self._cd = cd
+        self.F, self.degree_bits = F, cd["fri_params"]["degree_bits"]
+        self.n = 1 << self.degree_bits
+        self.cfg = CircuitConfig(num_wires=c["num_wires"], num_routed_wires=c["num_routed_wires"], num_constants=c["num_constants"],
+                                 num_challenges=c["num_challenges"], max_quotient_degree_factor=c["max_quotient_degree_factor"],
+                                 rate_bits=fc["rate_bits"], cap_height=fc["cap_height"], num_query_rounds=fc["num_query_rounds"],
+                                 proof_of_work_bits=fc["proof_of_work_bits"])
+        self.k_is = np.asarray(cd["k_is"], dtype=F.dtype)
+        self.num_constants = cd["num_constants"]
+        self.num_partial_products = cd["num_partial_products"]
+        self.reduction_arity_bits = cd["fri_params"]["reduction_arity_bits"]
+        self.num_public_inputs = cd["num_public_inputs"]
+        self.gate_table = V.read_gates(common_bytes, cd, F)
+        self.num_selectors = len(cd["selectors_info"]["groups"])
+        assert cd["num_gate_constraints"] == max(G.num_constraints(g, F.hout, F.D) for g in self.gate_table)
+        assert cd["quotient_degree_factor"] == self.cfg.max_quotient_degree_factor
+        self.constants_sigmas_cap = np.asarray(vd["constants_sigmas_cap"], dtype=F.dtype)
+        self._digest = np.asarray(vd["circuit_digest"], dtype=F.dtype)
+
+    def common_data(self):
+        return self._cd
+
+
 def prove_cpu(circ, witness, public_inputs=()):
     """Run the CPU oracle prover; returns (proof_bytes, debug challenges)."""
     L = O.lib()
@@ -216,7 +247,7 @@ def eval_vanishing_poly(circ, zeta, openings, pi_hash, betas, gammas, alphas):
     qdf, num_prods = cfg.max_quotient_degree_factor, circ.num_partial_products
     # gate constraints: sum over the gate set of filter * unfiltered per constraint index (vanishing_poly.rs:129-170)
     nsel = circ.num_selectors
-    cons = [zero] * max(G.num_constraints(g, H) for g in circ.gate_table)
+    cons = [zero] * max(G.num_constraints(g, H, e.D) for g in circ.gate_table)
     for row, g in enumerate(circ.gate_table):
         f = G.compute_filter(e, row, g, consts[g[2]], nsel > 1)
         for j, c in enumerate(G.eval_unfiltered(e, g, wires, consts[nsel:], pi_hash)):

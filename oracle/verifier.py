@@ -10,8 +10,8 @@ Test infrastructure only.  Follows (paths relative to /root/reference/plonky2/sr
 Used to pin the C oracle (hashes, Merkle indexing, Challenger order, PoW rule, LDE point
 order, two-adic generator, extension non-residue, FRI folding) against the reference's own
 serialized regression proof, and later to check proofs produced by the GPU prover.
-The PLONK vanishing-polynomial identity is only checked for the gate set of the dummy circuit
-(see check_vanishing in oracle/plonk_dummy.py) - the recursion circuit's gates are out of scope.
+The PLONK vanishing-polynomial identity (oracle/plonk_dummy.py eval_vanishing_poly) is checked with the gate evaluators of
+oracle/gates.py, which cover the recursion circuit's gate set: the regression proof's identity holds under them.
 """
 import struct
 
@@ -119,6 +119,62 @@ def read_common_data(data, F=GL):
     cd["num_luts"] = r.usize()
     cd["_gates_offset"] = r.o
     return cd
+
+
+def read_gates(data, cd, F=GL):
+    """The gate list that closes CommonCircuitData (util/serialization/mod.rs:1910-1913): per gate a u32 tag in the order of
+    DefaultGateSerializer (util/serialization/gate_serialization.rs:143-165) and the gate's own serialize() fields.
+    Returns the gate tuples of oracle/gates.py with selectors_info merged in:
+    (kind, param, selector_index, group_start, group_end, param2, param3)."""
+    from . import gates as G
+    r = Reader(data, F)
+    r.o = cd["_gates_offset"]
+    sel = cd["selectors_info"]
+    out = []
+    n = r.usize()
+    for row in range(n):
+        tag = r.u32()
+        p1 = p2 = p3 = 0
+        if tag == 0:
+            kind, p1 = G.ARITHMETIC, r.usize()
+        elif tag == 1:
+            kind, p1 = G.ARITHMETIC_EXTENSION, r.usize()
+        elif tag == 2:
+            kind, p1, p2 = G.BASE_SUM, r.usize(), 2
+        elif tag == 3:
+            kind, p1 = G.CONSTANT, r.usize()
+        elif tag == 4:
+            kind, p1, p2 = G.COSET_INTERPOLATION, r.usize(), r.usize()
+            weights = r.field_vec(r.usize())
+            assert weights == G.barycentric_weights(F, p1)[1], "barycentric weights are a function of subgroup_bits"
+        elif tag == 5:
+            kind, p1 = G.EXPONENTIATION, r.usize()
+        elif tag == 8:
+            kind, p1 = G.MUL_EXTENSION, r.usize()
+        elif tag == 9:
+            kind = G.NOOP
+        elif tag == 10:
+            kind = G.POSEIDON_MDS
+        elif tag == 11:
+            kind = G.POSEIDON
+        elif tag == 12:
+            kind = G.PUBLIC_INPUT
+        elif tag == 13:
+            kind, p1, p2, p3 = G.RANDOM_ACCESS, r.usize(), r.usize(), r.usize()
+        elif tag == 14:
+            kind, p1 = G.REDUCING_EXTENSION, r.usize()
+        elif tag == 15:
+            kind, p1 = G.REDUCING, r.usize()
+        elif tag == 16:
+            kind = G.POSEIDON2_BABYBEAR  # num_ops from the config (gates/poseidon2_babybear.rs:65-68)
+            p1 = min(cd["config"]["num_wires"] // 166, cd["config"]["num_routed_wires"] // 33)
+        else:
+            raise ValueError("gate tag %d (lookup gates / AddMany / ApplyMat4 / Poseidon2 internal) is not restated" % tag)
+        si = sel["selector_indices"][row]
+        gs, ge = sel["groups"][si]
+        out.append((kind, p1, si, gs, ge, p2, p3))
+    assert r.done()
+    return out
 
 
 def read_verifier_data(data, F=GL):

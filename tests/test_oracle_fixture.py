@@ -62,3 +62,51 @@ def test_tampered_proof_is_rejected(fixture):
     caps = [vd["constants_sigmas_cap"], bad["wires_cap"], bad["zs_cap"], bad["quotient_cap"]]
     with pytest.raises(AssertionError):
         V.verify_fri(bad, ch, caps, cd)
+
+
+def test_regression_proof_full_verify_with_the_recursion_gate_set(golden_dir):
+    """plonk/verifier.rs:17-128 on the reference's own recursion proof, INCLUDING vanishing(zeta) == Z_H(zeta) * quotient(zeta)
+    with the circuit's twelve gates (Noop, PoseidonMds, PublicInput, BaseSum<2>, ReducingExtension, Reducing,
+    ArithmeticExtension, Arithmetic, MulExtension, RandomAccess, CosetInterpolation, Poseidon) evaluated by oracle/gates.py:
+    the reference's numbers pin every one of those evaluators, the selector filters and the zero-knowledge (salted) openings."""
+    from oracle import gates as G
+    from oracle import plonk_dummy as D
+    rd = lambda n: open(os.path.join(golden_dir, n), "rb").read()
+    circ = D.CommonDataCircuit(rd("recursive_verifier_gl_common_data.bin"), rd("recursive_verifier_gl_verifier_data.bin"))
+    kinds = [g[0] for g in circ.gate_table]
+    assert kinds == [G.NOOP, G.POSEIDON_MDS, G.PUBLIC_INPUT, G.BASE_SUM, G.REDUCING_EXTENSION, G.REDUCING, G.ARITHMETIC_EXTENSION,
+                     G.ARITHMETIC, G.MUL_EXTENSION, G.RANDOM_ACCESS, G.COSET_INTERPOLATION, G.POSEIDON]
+    assert circ.gate_table[3][1] == 63 and circ.gate_table[9][1:2] + circ.gate_table[9][5:] == (4, 4, 2)
+    assert circ.gate_table[10][1] == 4 and circ.gate_table[10][5] == 6
+    raw = rd("recursive_verifier_gl_proof.bin")
+    stats = {}
+    assert D.verify(circ, raw, stats)
+    assert stats["merkle_paths"] == 28 * (4 + 3)
+    # one opened wire value off by one: the identity must fail (the transcript changes too, so every later check would as well)
+    proof, pis = V.read_proof_with_pis(raw, circ.common_data())
+    w0 = proof["openings"]["wires"][17]
+    proof["openings"]["wires"][17] = ((w0[0] + 1) % V.P, w0[1])
+    with pytest.raises(AssertionError):
+        D.verify(circ, V.write_proof_with_pis(proof, pis))
+
+
+def test_every_gate_of_the_fixture_is_pinned_by_its_identity(golden_dir, monkeypatch):
+    """Perturbing the last constraint of any one gate kind of the regression circuit breaks the identity: the reference's proof
+    pins each evaluator separately (a filter is non-zero at a random zeta, so every gate contributes)."""
+    from oracle import gates as G
+    from oracle import plonk_dummy as D
+    rd = lambda n: open(os.path.join(golden_dir, n), "rb").read()
+    circ = D.CommonDataCircuit(rd("recursive_verifier_gl_common_data.bin"), rd("recursive_verifier_gl_verifier_data.bin"))
+    raw = rd("recursive_verifier_gl_proof.bin")
+    orig = G.eval_unfiltered
+    for kind in sorted({g[0] for g in circ.gate_table} - {G.NOOP}):
+        def perturbed(e, gate, wires, consts, pi_hash, kind=kind):
+            out = list(orig(e, gate, wires, consts, pi_hash))
+            if gate[0] == kind:
+                out[-1] = e.eadd(out[-1], e.one)
+            return out
+        monkeypatch.setattr(G, "eval_unfiltered", perturbed)
+        with pytest.raises(AssertionError, match="vanishing"):
+            D.verify(circ, raw)
+    monkeypatch.setattr(G, "eval_unfiltered", orig)
+    assert D.verify(circ, raw)
