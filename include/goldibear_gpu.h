@@ -131,6 +131,8 @@ typedef struct gb_circuit_config {
     uint32_t arity_bits, final_poly_bits;  /* FriReductionStrategy::ConstantArityBits */
     uint32_t num_selectors;         /* 1 */
     uint32_t gate_constant, gate_pi;/* selector values of ConstantGate / PublicInputGate (NoopGate is the third) */
+    uint32_t zero_knowledge;        /* CircuitConfig.zero_knowledge (= FriParams.hiding): the wires / Zs / quotient leaves carry
+                                       SALT_SIZE salt elements (fri/oracle.rs:133-148).  gb_verify handles it; gb_prove does not */
 } gb_circuit_config;
 
 /* constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits] VALUES on H_n
@@ -145,7 +147,8 @@ gb_status gb_circuit_free(gb_circuit* c);
  * (gates/public_input.rs), ArithmeticGate{param = num_ops} (gates/arithmetic_base.rs) and the in-circuit hash of the field's
  * configuration - PoseidonGate for Goldilocks (gates/poseidon_goldilocks.rs), Poseidon2BabyBearGate{param = num_ops} for
  * BabyBear (gates/poseidon2_babybear.rs) - which build() needs for any circuit with public inputs (circuit_builder.rs:1126-1137);
- * any other kind is GB_ERR_UNSUPPORTED.  cfg->num_selectors = selectors_info.groups.len(),
+ * and the remaining gates of the recursion circuits listed below; any other kind (lookups, AddMany, ApplyMat4, ...) is
+ * GB_ERR_UNSUPPORTED.  cfg->num_selectors = selectors_info.groups.len(),
  * cfg->num_constants = the constant columns after the selectors (max over the gates' num_constants()); cfg->gate_constant and
  * cfg->gate_pi are ignored.  constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits]. */
 #define GB_GATE_NOOP 0
@@ -154,11 +157,24 @@ gb_status gb_circuit_free(gb_circuit* c);
 #define GB_GATE_ARITHMETIC 3
 #define GB_GATE_POSEIDON 4
 #define GB_GATE_POSEIDON2_BABYBEAR 5
+/* the rest of the recursion circuits' gate set (the gates of the reference's RECURSIVE_VERIFIER_GL fixture and
+ * ExponentiationGate); D = the extension degree of the field's configuration */
+#define GB_GATE_ARITHMETIC_EXTENSION 6 /* gates/arithmetic_extension.rs   param = num_ops */
+#define GB_GATE_MUL_EXTENSION 7        /* gates/multiplication_extension.rs param = num_ops */
+#define GB_GATE_BASE_SUM 8             /* gates/base_sum.rs               param = num_limbs, param2 = B (0 reads as 2) */
+#define GB_GATE_REDUCING 9             /* gates/reducing.rs               param = num_coeffs */
+#define GB_GATE_REDUCING_EXTENSION 10  /* gates/reducing_extension.rs     param = num_coeffs */
+#define GB_GATE_RANDOM_ACCESS 11       /* gates/random_access.rs          param = bits, param2 = num_copies, param3 = num_extra_constants */
+#define GB_GATE_POSEIDON_MDS 12        /* gates/poseidon_goldilocks_mds.rs (Goldilocks) */
+#define GB_GATE_COSET_INTERPOLATION 13 /* gates/coset_interpolation.rs    param = subgroup_bits (<= 4), param2 = degree; the
+                                          barycentric weights are x_i / 2^subgroup_bits and are not passed */
+#define GB_GATE_EXPONENTIATION 14      /* gates/exponentiation.rs         param = num_power_bits */
 typedef struct gb_gate {
     uint32_t kind;            /* GB_GATE_* */
-    uint32_t param;           /* ConstantGate num_consts / ArithmeticGate, Poseidon2BabyBearGate num_ops; 0 otherwise */
+    uint32_t param;           /* ConstantGate num_consts / ArithmeticGate, Poseidon2BabyBearGate num_ops; see above; 0 otherwise */
     uint32_t selector_index;  /* which selector column carries this gate */
     uint32_t group_start, group_end; /* the gate indices sharing that column */
+    uint32_t param2, param3;  /* see the gate list above; 0 otherwise */
 } gb_gate;
 gb_status gb_circuit_create_gates(gb_ctx* ctx, const gb_circuit_config* cfg, const gb_gate* gates, uint32_t num_gates,
                                   const void* constants_sigmas, const void* k_is, uint32_t flags, gb_circuit** out);
@@ -185,6 +201,13 @@ gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uin
  * malformed bytes. */
 #define GB_ERR_VERIFY 19
 gb_status gb_verify(gb_circuit* c, const void* proof, size_t proof_len);
+/* A circuit object for gb_verify alone, from what a verifier holds: CommonCircuitData (cfg + gates, as for
+ * gb_circuit_create_gates; k_is [num_routed_wires]) and VerifierOnlyCircuitData (constants_sigmas_cap [2^cap_height][H],
+ * circuit_digest [H]), all host pointers to canonical elements.  Touches no device: ctx may be NULL (gb_last_error(NULL) then
+ * reports).  With it gb_verify checks the reference's own serialized proofs - tests/test_abi_verify_fixture.py runs the
+ * RECURSIVE_VERIFIER_GL regression proof (recursion/regression_test_data.rs) through it.  Free with gb_circuit_free. */
+gb_status gb_verifier_create(gb_ctx* ctx, const gb_circuit_config* cfg, const gb_gate* gates, uint32_t num_gates, const void* k_is,
+                             const void* constants_sigmas_cap, const void* circuit_digest, gb_circuit** out);
 
 /* fri_proof_of_work (fri/prover.rs:136-188) on its own, for a host that keeps the Challenger: sponge_state is the
  * duplex state with the pending input buffer already written over lanes 0..witness_pos-1 (`duplex_intermediate_state`,

@@ -7,4 +7,4 @@ polynomial_batch  host-side mirror of PolynomialBatch / MerkleTree (fri/oracle.r
 from .native import GB_BABYBEAR, GB_GOLDILOCKS, GoldibearError, ShapeError  # noqa: F401
 from .native import PermArgZeroError, TooManyPermArgFailuresError, VerifyError  # noqa: F401
 from .polynomial_batch import GpuContext, MerkleTree, PolynomialBatch  # noqa: F401
-from .prover import CircuitData  # noqa: F401
+from .prover import CircuitData, VerifierCircuitData  # noqa: F401

@@ -45,6 +45,7 @@ struct GlF {
     static GB_HD T pow(T a, u64 e) { return gl::pow(a, e); }
     static GB_HD T generator() { return gl::GENERATOR; }
     static GB_HD T two_adic_generator(u32 bits) { return gl::two_adic_generator(bits); }
+    static GB_HD T ext_w() { return 7; }  // the extension is F[x]/(x^2 - 7)
     static GB_HD E ezero() { return gl::e2(0); }
     static GB_HD E efrom(T x) { return gl::e2(x); }
     static GB_HD E eadd(E a, E b) { return gl::add(a, b); }
@@ -79,6 +80,7 @@ struct BbF {
     static GB_HD T pow(T a, u64 e) { return bb::pow(a, e); }
     static GB_HD T generator() { return bb::to_mont(bb::GENERATOR); }
     static GB_HD T two_adic_generator(u32 bits) { return bb::two_adic_generator(bits); }
+    static GB_HD T ext_w() { return W_MONT; }
     static GB_HD E ezero() { return E{{0, 0, 0, 0}}; }
     static GB_HD E efrom(T x) { return E{{x, 0, 0, 0}}; }
     static GB_HD E eadd(E a, E b) { return E{{bb::add(a.c[0], b.c[0]), bb::add(a.c[1], b.c[1]), bb::add(a.c[2], b.c[2]), bb::add(a.c[3], b.c[3])}}; }

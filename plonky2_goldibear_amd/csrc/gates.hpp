@@ -10,6 +10,19 @@
 //                            first (fast partial-round form: hash/poseidon_goldilocks.rs:632-770), 12 outputs = 123 constraints
 //   Poseidon2BabyBearGate{num_ops} (BB only)  gates/poseidon2_babybear.rs:203-313  per operation: swap bit, 8 deltas, the s-box
 //                            inputs of every round but the first, 16 outputs = 150 constraints
+//   ArithmeticExtensionGate  gates/arithmetic_extension.rs:82-100      out - (c0 * m0 * m1 + c1 * addend) on D-tuples, D each
+//   MulExtensionGate         gates/multiplication_extension.rs:77-94  out - c0 * m0 * m1, D each
+//   BaseSumGate<B>           gates/base_sum.rs:77-93                  sum - reduce_with_powers(limbs, B); prod_{i<B} (limb - i) per limb
+//   ReducingGate             gates/reducing.rs:89-115                 acc * alpha + coeff_i - acc_i (base-field coefficients), D each
+//   ReducingExtensionGate    gates/reducing_extension.rs:95-120       the same with D-tuple coefficients
+//   RandomAccessGate         gates/random_access.rs:150-200           per copy: bits boolean, index reconstruction, folded list - claimed;
+//                                                                     then the extra constants
+//   PoseidonMdsGate (GL)     gates/poseidon_goldilocks_mds.rs:152-180 out_r - MDS row r on D-tuples
+//   CosetInterpolationGate   gates/coset_interpolation.rs:216-268     shifted point, the intermediate (eval, prod) pairs, the value
+//   ExponentiationGate       gates/exponentiation.rs:99-135           square-and-multiply chain, output
+// A D-tuple of consecutive wires is an element of the extension FIELD on the prover's LDE points (base-field wires) and of the
+// extension ALGEBRA F_ext[x]/(x^D - W) at the verifier's zeta (vars.get_local_ext / get_local_ext_algebra, plonk/vars.rs); Tup<>
+// below is written over the algebra A and is both.
 // The caller multiplies by the gate's filter (gates/gate.rs:391-404) and folds with powers of alpha.
 #pragma once
 #include "field_traits.hpp"
@@ -19,31 +32,62 @@
 namespace gbk {
 namespace gates {
 
+GB_HD u32 base_sum_base(const gb_gate& g) { return g.param2 ? g.param2 : 2; }
+GB_HD u32 interpolation_intermediates(const gb_gate& g) {  // coset_interpolation.rs:148-150
+    return g.param2 > 1 ? ((1u << g.param) - 2) / (g.param2 - 1) : 0;
+}
 template <class F>
 GB_HD u32 num_constraints(const gb_gate& g) {
+    constexpr u32 D = F::D;
     switch (g.kind) {
         case GB_GATE_CONSTANT: return g.param;
         case GB_GATE_PUBLIC_INPUT: return F::H;
         case GB_GATE_ARITHMETIC: return g.param;
         case GB_GATE_POSEIDON: return POSEIDON_NUM_CONSTRAINTS;
         case GB_GATE_POSEIDON2_BABYBEAR: return POSEIDON2_BB_CONSTRAINTS_PER_OP * g.param;
+        case GB_GATE_ARITHMETIC_EXTENSION:
+        case GB_GATE_MUL_EXTENSION:
+        case GB_GATE_REDUCING:
+        case GB_GATE_REDUCING_EXTENSION: return D * g.param;
+        case GB_GATE_BASE_SUM: return 1 + g.param;
+        case GB_GATE_RANDOM_ACCESS: return (g.param + 2) * g.param2 + g.param3;
+        case GB_GATE_POSEIDON_MDS: return 12 * D;
+        case GB_GATE_COSET_INTERPOLATION: return 2 * D + 2 * D * interpolation_intermediates(g);
+        case GB_GATE_EXPONENTIATION: return g.param + 1;
         default: return 0;
     }
 }
 template <class F>
 GB_HD u32 num_wires(const gb_gate& g) {
+    constexpr u32 D = F::D;
     switch (g.kind) {
         case GB_GATE_CONSTANT: return g.param;
         case GB_GATE_PUBLIC_INPUT: return F::H;
         case GB_GATE_ARITHMETIC: return 4 * g.param;
         case GB_GATE_POSEIDON: return 135;
         case GB_GATE_POSEIDON2_BABYBEAR: return POSEIDON2_BB_WIRES_PER_OP * g.param;
+        case GB_GATE_ARITHMETIC_EXTENSION: return 4 * D * g.param;
+        case GB_GATE_MUL_EXTENSION: return 3 * D * g.param;
+        case GB_GATE_BASE_SUM: return 1 + g.param;
+        case GB_GATE_REDUCING: return 2 * D + g.param * (D + 1);
+        case GB_GATE_REDUCING_EXTENSION: return 2 * D + 2 * D * g.param;
+        case GB_GATE_RANDOM_ACCESS: return (2 + (1u << g.param)) * g.param2 + g.param3 + g.param2 * g.param;
+        case GB_GATE_POSEIDON_MDS: return 24 * D;
+        case GB_GATE_COSET_INTERPOLATION: return 1 + (D << g.param) + 2 * D + D * (2 * interpolation_intermediates(g) + 1);
+        case GB_GATE_EXPONENTIATION: return 2 + 2 * g.param;
         default: return 0;
     }
 }
 template <class F>
 GB_HD u32 num_constants(const gb_gate& g) {
-    return g.kind == GB_GATE_CONSTANT ? g.param : (g.kind == GB_GATE_ARITHMETIC ? 2 : 0);
+    switch (g.kind) {
+        case GB_GATE_CONSTANT: return g.param;
+        case GB_GATE_ARITHMETIC:
+        case GB_GATE_ARITHMETIC_EXTENSION: return 2;
+        case GB_GATE_MUL_EXTENSION: return 1;
+        case GB_GATE_RANDOM_ACCESS: return g.param3;
+        default: return 0;
+    }
 }
 
 // base-field algebra (device form) and extension-field algebra; constants handed to mulc / addc are base elements in device form
@@ -305,9 +349,224 @@ GB_HD void eval_poseidon2_bb(u32 num_ops, W&& wire, Emit&& emit) {
     }
 }
 
+// A D-tuple of values of the algebra A: the extension field over base-field wires, the extension algebra over opened wires
+// (field/src/extension/algebra.rs: coordinate-wise add, x^D = W for the product, scalar_mul coordinate-wise).
+template <class F, class A>
+struct Tup {
+    typedef typename A::V V;
+    typedef typename F::T T;
+    static constexpr u32 D = F::D;
+    V c[D];
+    template <class W>
+    static GB_HD Tup load(W&& wire, u32 start) {
+        Tup r;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) r.c[k] = wire(start + k);
+        return r;
+    }
+    static GB_HD Tup zero() {
+        Tup r;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) r.c[k] = A::cst(F::zero());
+        return r;
+    }
+    static GB_HD Tup from_base(V v) {
+        Tup r = zero();
+        r.c[0] = v;
+        return r;
+    }
+    GB_HD Tup operator+(const Tup& o) const {
+        Tup r;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) r.c[k] = A::add(c[k], o.c[k]);
+        return r;
+    }
+    GB_HD Tup operator-(const Tup& o) const {
+        Tup r;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) r.c[k] = A::sub(c[k], o.c[k]);
+        return r;
+    }
+    GB_HD Tup operator*(const Tup& o) const {
+        Tup r;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) {
+            V lo = A::mul(c[0], o.c[k]);
+#pragma unroll
+            for (u32 i = 1; i <= k; i++) lo = A::add(lo, A::mul(c[i], o.c[k - i]));
+            if (k + 1 < D) {
+                V hi = A::mul(c[k + 1], o.c[D - 1]);
+#pragma unroll
+                for (u32 i = k + 2; i < D; i++) hi = A::add(hi, A::mul(c[i], o.c[k + D - i]));
+                lo = A::add(lo, A::mulc(hi, F::ext_w()));
+            }
+            r.c[k] = lo;
+        }
+        return r;
+    }
+    GB_HD Tup scalar(V s) const {  // ExtensionAlgebra::scalar_mul
+        Tup r;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) r.c[k] = A::mul(c[k], s);
+        return r;
+    }
+    GB_HD Tup scalar_c(T s) const {
+        Tup r;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) r.c[k] = A::mulc(c[k], s);
+        return r;
+    }
+    template <class Emit>
+    GB_HD void emit_all(Emit&& emit) const {
+#pragma unroll
+        for (u32 k = 0; k < D; k++) emit(c[k]);
+    }
+};
+
+// ArithmeticExtensionGate (with_addend) / MulExtensionGate
+template <class F, class A, class W, class K, class Emit>
+GB_HD void eval_arithmetic_extension(u32 num_ops, bool with_addend, W&& wire, K&& konst, Emit&& emit) {
+    typedef Tup<F, A> X;
+    constexpr u32 D = F::D;
+    const typename A::V c0 = konst(0), c1 = with_addend ? konst(1) : c0;
+    const u32 stride = (with_addend ? 4 : 3) * D;
+    for (u32 i = 0; i < num_ops; i++) {
+        const X m0 = X::load(wire, stride * i), m1 = X::load(wire, stride * i + D);
+        X computed = (m0 * m1).scalar(c0);
+        if (with_addend) computed = computed + X::load(wire, stride * i + 2 * D).scalar(c1);
+        (X::load(wire, stride * i + stride - D) - computed).emit_all(emit);
+    }
+}
+
+template <class F, class A, class W, class Emit>
+GB_HD void eval_base_sum(u32 num_limbs, u32 base, W&& wire, Emit&& emit) {
+    typedef typename A::V V;
+    V acc = A::cst(F::zero());
+    for (u32 i = num_limbs; i-- > 0;) acc = A::add(A::mulc(acc, F::enc(base)), wire(1 + i));  // reduce_with_powers
+    emit(A::sub(acc, wire(0)));
+    for (u32 i = 0; i < num_limbs; i++) {
+        const V limb = wire(1 + i);
+        V prod = limb;
+        for (u32 b = 1; b < base; b++) prod = A::mul(prod, A::sub(limb, A::cst(F::enc(b))));
+        emit(prod);
+    }
+}
+
+// ReducingGate (base-field coefficients, one wire each) / ReducingExtensionGate (D-tuple coefficients)
+template <class F, class A, class W, class Emit>
+GB_HD void eval_reducing(u32 num_coeffs, bool extension_coeffs, W&& wire, Emit&& emit) {
+    typedef Tup<F, A> X;
+    constexpr u32 D = F::D;
+    const X alpha = X::load(wire, D);
+    X acc = X::load(wire, 2 * D);
+    const u32 start_coeffs = 3 * D, start_accs = start_coeffs + num_coeffs * (extension_coeffs ? D : 1);
+    for (u32 i = 0; i < num_coeffs; i++) {
+        const X coeff = extension_coeffs ? X::load(wire, start_coeffs + i * D) : X::from_base(wire(start_coeffs + i));
+        const X acc_i = X::load(wire, i == num_coeffs - 1 ? 0 : start_accs + D * i);  // the last accumulator is the output
+        (acc * alpha + coeff - acc_i).emit_all(emit);
+        acc = acc_i;
+    }
+}
+
+template <class F, class A, class W, class K, class Emit>
+GB_HD void eval_random_access(u32 bits, u32 num_copies, u32 num_extra, W&& wire, K&& konst, Emit&& emit) {
+    typedef typename A::V V;
+    const u32 vec = 1u << bits, routed = (2 + vec) * num_copies + num_extra;
+    const V one = A::cst(F::one());
+    for (u32 copy = 0; copy < num_copies; copy++) {
+        const u32 base = (2 + vec) * copy, bit0 = routed + copy * bits;
+        for (u32 i = 0; i < bits; i++) {
+            const V b = wire(bit0 + i);
+            emit(A::mul(b, A::sub(b, one)));
+        }
+        V rec = A::cst(F::zero());
+        for (u32 i = bits; i-- > 0;) rec = A::add(A::add(rec, rec), wire(bit0 + i));
+        emit(A::sub(rec, wire(base)));
+        // fold the list pairwise, level k selecting with bit k (x + b (y - x)); the items are visited once, in order, with one
+        // pending value per level instead of the reference's shrinking vector
+        V pending[MAX_RANDOM_ACCESS_BITS + 1];
+        V cur = A::cst(F::zero());
+        for (u32 i = 0; i < vec; i++) {
+            cur = wire(base + 2 + i);
+            u32 lvl = 0;
+            for (u32 t = i; t & 1; t >>= 1, lvl++) {
+                const V x = pending[lvl];
+                cur = A::add(x, A::mul(wire(bit0 + lvl), A::sub(cur, x)));
+            }
+            pending[lvl] = cur;
+        }
+        emit(A::sub(cur, wire(base + 1)));
+    }
+    for (u32 i = 0; i < num_extra; i++) emit(A::sub(konst(i), wire((2 + vec) * num_copies + i)));
+}
+
+template <class F, class A, class W, class Emit>
+GB_HD void eval_poseidon_mds(W&& wire, Emit&& emit) {
+    typedef Tup<F, A> X;
+    constexpr u32 D = F::D;
+    const PoseidonTab& t = poseidon_tab();
+    X in[12];
+#pragma unroll
+    for (u32 i = 0; i < 12; i++) in[i] = X::load(wire, i * D);
+#pragma unroll 1
+    for (u32 r = 0; r < 12; r++) {
+        X res = in[r].scalar_c(F::enc(t.circ[0] + t.diag[r]));
+        for (u32 i = 1; i < 12; i++) res = res + in[(i + r) % 12].scalar_c(F::enc(t.circ[i]));
+        (X::load(wire, (12 + r) * D) - res).emit_all(emit);
+    }
+}
+
+template <class F, class A, class W, class Emit>
+GB_HD void eval_coset_interpolation(const GateSet& gs, const gb_gate& g, W&& wire, Emit&& emit) {
+    typedef Tup<F, A> X;
+    typedef typename F::T T;
+    constexpr u32 D = F::D;
+    const u32 bits = g.param, degree = g.param2, npts = 1u << bits, nint = interpolation_intermediates(g);
+    const u32 start_point = 1 + npts * D, start_int = start_point + 2 * D;
+    const X shifted = X::load(wire, start_int + 2 * D * nint);
+    (X::load(wire, start_point) - shifted.scalar(wire(0))).emit_all(emit);
+    const T inv_m = (T)gs.inv_pow2[bits];
+    X ev = X::zero(), prod = X::from_base(A::cst(F::one()));
+    auto partial = [&](u32 lo, u32 hi) {  // partial_interpolate_ext_algebra (:637-664)
+        for (u32 i = lo; i < hi; i++) {
+            const T x_i = (T)gs.subgroup16[i << (MAX_INTERPOLATION_BITS - bits)];
+            const X val = X::load(wire, 1 + i * D).scalar_c(F::mul(x_i, inv_m));  // barycentric weight x_i / 2^bits
+            X term = shifted;
+            term.c[0] = A::sub(term.c[0], A::cst(x_i));
+            ev = ev * term + val * prod;
+            prod = prod * term;
+        }
+    };
+    partial(0, degree);
+    for (u32 i = 0; i < nint; i++) {
+        const X iev = X::load(wire, start_int + D * i), iprod = X::load(wire, start_int + D * (nint + i));
+        (iev - ev).emit_all(emit);
+        (iprod - prod).emit_all(emit);
+        ev = iev;
+        prod = iprod;
+        const u32 lo = 1 + (degree - 1) * (i + 1), hi = lo + degree - 1 < npts ? lo + degree - 1 : npts;
+        partial(lo, hi);
+    }
+    (X::load(wire, start_point + D) - ev).emit_all(emit);
+}
+
+template <class F, class A, class W, class Emit>
+GB_HD void eval_exponentiation(u32 nbits, W&& wire, Emit&& emit) {
+    typedef typename A::V V;
+    const V base = wire(0), one = A::cst(F::one());
+    V prev = one;
+    for (u32 i = 0; i < nbits; i++) {
+        const V bit = wire(1 + (nbits - i - 1));  // power bits are little-endian, the chain runs big-endian
+        const V inter = wire(2 + nbits + i);
+        emit(A::sub(A::mul(prev, A::add(A::mul(bit, base), A::sub(one, bit))), inter));
+        prev = A::mul(inter, inter);
+    }
+    emit(A::sub(wire(1 + nbits), wire(2 + nbits + nbits - 1)));
+}
+
 // wire(col) / konst(i) give the opened (or LDE) value of a wire / of the i-th constant after the selectors
 template <class F, class A, class W, class K, class Emit>
-GB_HD void eval_gate(const gb_gate& g, W&& wire, K&& konst, const typename F::T* pi_hash, Emit&& emit) {
+GB_HD void eval_gate(const GateSet& gs, const gb_gate& g, W&& wire, K&& konst, const typename F::T* pi_hash, Emit&& emit) {
     typedef typename A::V V;
     switch (g.kind) {
         case GB_GATE_CONSTANT:
@@ -330,6 +589,17 @@ GB_HD void eval_gate(const gb_gate& g, W&& wire, K&& konst, const typename F::T*
         case GB_GATE_POSEIDON2_BABYBEAR:
             if constexpr (F::TAG == 1) eval_poseidon2_bb<F, A>(g.param, wire, emit);
             break;
+        case GB_GATE_ARITHMETIC_EXTENSION: eval_arithmetic_extension<F, A>(g.param, true, wire, konst, emit); break;
+        case GB_GATE_MUL_EXTENSION: eval_arithmetic_extension<F, A>(g.param, false, wire, konst, emit); break;
+        case GB_GATE_BASE_SUM: eval_base_sum<F, A>(g.param, base_sum_base(g), wire, emit); break;
+        case GB_GATE_REDUCING: eval_reducing<F, A>(g.param, false, wire, emit); break;
+        case GB_GATE_REDUCING_EXTENSION: eval_reducing<F, A>(g.param, true, wire, emit); break;
+        case GB_GATE_RANDOM_ACCESS: eval_random_access<F, A>(g.param, g.param2, g.param3, wire, konst, emit); break;
+        case GB_GATE_POSEIDON_MDS:
+            if constexpr (F::TAG == 0) eval_poseidon_mds<F, A>(wire, emit);
+            break;
+        case GB_GATE_COSET_INTERPOLATION: eval_coset_interpolation<F, A>(gs, g, wire, emit); break;
+        case GB_GATE_EXPONENTIATION: eval_exponentiation<F, A>(g.param, wire, emit); break;
         default:
             break;
     }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_gate_constraints(GateParams<F> p, const
             for (u32 k = 0; k < C; k++) sum[k] = F::add(sum[k], F::mul(c, apow[k * p.nterms + idx]));
             idx++;
         };
-        gates::eval_gate<F, A>(gd, wire, konst, pi_hash, emit);
+        gates::eval_gate<F, A>(p.gs, gd, wire, konst, pi_hash, emit);
 #pragma unroll
         for (u32 k = 0; k < C; k++) acc[k] = F::add(acc[k], F::mul(f, sum[k]));
     }

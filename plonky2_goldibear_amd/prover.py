@@ -22,11 +22,11 @@ class gb_circuit_config(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in (
         "field", "degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges",
         "max_quotient_degree_factor", "rate_bits", "cap_height", "proof_of_work_bits", "num_query_rounds",
-        "arity_bits", "final_poly_bits", "num_selectors", "gate_constant", "gate_pi")]
+        "arity_bits", "final_poly_bits", "num_selectors", "gate_constant", "gate_pi", "zero_knowledge")]
 
 
 class gb_gate(C.Structure):
-    _fields_ = [(k, C.c_uint32) for k in ("kind", "param", "selector_index", "group_start", "group_end")]
+    _fields_ = [(k, C.c_uint32) for k in ("kind", "param", "selector_index", "group_start", "group_end", "param2", "param3")]
 
 
 class CircuitData:
@@ -136,6 +136,49 @@ class CircuitData:
 
     def free(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self._lib.gb_circuit_free(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        if not sys.is_finalizing():
+            self.free()
+
+
+class VerifierCircuitData:
+    """VerifierCircuitData (plonk/circuit_data.rs:358-380): CommonCircuitData + VerifierOnlyCircuitData, enough to verify and
+    nothing else.  Built on gb_verifier_create, which touches no device - usable without a GPU context."""
+
+    def __init__(self, degree_bits, gates, k_is, constants_sigmas_cap, circuit_digest, *, num_wires=135, num_routed_wires=80,
+                 num_constants=2, num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4,
+                 proof_of_work_bits=16, num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1,
+                 zero_knowledge=False, field=N.GB_GOLDILOCKS):
+        """`gates`: (kind, param, selector_index, group_start, group_end[, param2, param3]) per gate, sorted as in
+        CommonCircuitData.gates; num_constants counts the constant columns after the selectors."""
+        self._lib = N.load()
+        self.field, self._dt = field, _dtype(field)
+        hout = 4 if field == N.GB_GOLDILOCKS else 8
+        self.cfg = gb_circuit_config(field, degree_bits, num_wires, num_routed_wires, num_constants, num_challenges,
+                                     max_quotient_degree_factor, rate_bits, cap_height, proof_of_work_bits, num_query_rounds,
+                                     arity_bits, final_poly_bits, num_selectors, 0, 0, 1 if zero_knowledge else 0)
+        k = np.ascontiguousarray(k_is, dtype=self._dt)
+        cap = np.ascontiguousarray(constants_sigmas_cap, dtype=self._dt)
+        dig = np.ascontiguousarray(circuit_digest, dtype=self._dt)
+        if k.shape != (num_routed_wires,) or cap.shape != (1 << cap_height, hout) or dig.shape != (hout,):
+            raise N.ShapeError(N.GB_ERR_INVALID, "k_is / constants_sigmas_cap / circuit_digest have the wrong shape")
+        arr = (gb_gate * len(gates))(*[gb_gate(*g) for g in gates])
+        h = C.c_void_p()
+        N.check(self._lib.gb_verifier_create(None, C.byref(self.cfg), arr, len(gates), k.ctypes.data, cap.ctypes.data,
+                                             dig.ctypes.data, C.byref(h)))
+        self.handle = h
+
+    def verify(self, proof_bytes):
+        """plonk/verifier.rs:17-128; True, or raises VerifyError naming the failed check."""
+        buf = np.frombuffer(bytes(proof_bytes), dtype=np.uint8)
+        N.check(self._lib.gb_verify(self.handle, buf.ctypes.data, buf.size))
+        return True
+
+    def free(self):
+        if getattr(self, "handle", None):
             self._lib.gb_circuit_free(self.handle)
         self.handle = None
 

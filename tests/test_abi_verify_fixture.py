@@ -1,0 +1,72 @@
+"""gb_verify (the product's host-side verifier, csrc/verifier_host.inc + the gate evaluators of csrc/gates.hpp) on the
+reference's OWN serialized recursion proof (recursion/regression_test_data.rs:5,62,93; verified by the reference at
+recursion/recursive_verifier.rs:280-314).  gb_verifier_create touches no device, so this runs without a GPU.
+
+The proof is zero-knowledge (salted leaves) and its circuit uses twelve gates - Noop, PoseidonMds, PublicInput, BaseSum<2>,
+ReducingExtension, Reducing, ArithmeticExtension, Arithmetic, MulExtension, RandomAccess, CosetInterpolation, Poseidon - so the
+vanishing identity at zeta pins the extension-field instantiation of every one of those evaluators with the reference's numbers;
+the quotient kernel runs the same source over the base field (tests/test_gpu_gates.py compares the two on the GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import verifier as V
+from plonky2_goldibear_amd import VerifierCircuitData, VerifyError, native as N
+
+
+def _fixture_circuit(golden_dir, **override):
+    rd = lambda n: open(os.path.join(golden_dir, n), "rb").read()
+    common = rd("recursive_verifier_gl_common_data.bin")
+    cd = V.read_common_data(common)
+    vd = V.read_verifier_data(rd("recursive_verifier_gl_verifier_data.bin"))
+    gates = V.read_gates(common, cd)
+    cfg, fc = cd["config"], cd["config"]["fri_config"]
+    assert fc["reduction_strategy"] == ("ConstantArityBits", 4, 5)
+    nsel = len(cd["selectors_info"]["groups"])
+    kw = dict(num_wires=cfg["num_wires"], num_routed_wires=cfg["num_routed_wires"], num_constants=cd["num_constants"] - nsel,
+              num_challenges=cfg["num_challenges"], max_quotient_degree_factor=cd["quotient_degree_factor"],
+              rate_bits=fc["rate_bits"], cap_height=fc["cap_height"], proof_of_work_bits=fc["proof_of_work_bits"],
+              num_query_rounds=fc["num_query_rounds"], arity_bits=4, final_poly_bits=5, num_selectors=nsel,
+              zero_knowledge=cd["fri_params"]["hiding"])
+    kw.update(override)
+    circ = VerifierCircuitData(cd["fri_params"]["degree_bits"], kw.pop("gates", gates), np.array(cd["k_is"], dtype=np.uint64),
+                               np.array(vd["constants_sigmas_cap"], dtype=np.uint64),
+                               np.array(vd["circuit_digest"], dtype=np.uint64), **kw)
+    return circ, cd, rd("recursive_verifier_gl_proof.bin")
+
+
+def test_reference_regression_proof_verifies_through_the_c_abi(golden_dir):
+    circ, cd, raw = _fixture_circuit(golden_dir)
+    assert circ.verify(raw)
+
+
+def test_tampered_opening_fails_the_vanishing_identity(golden_dir):
+    circ, cd, raw = _fixture_circuit(golden_dir)
+    proof, pis = V.read_proof_with_pis(raw, cd)
+    w0 = proof["openings"]["wires"][17]
+    proof["openings"]["wires"][17] = ((w0[0] + 1) % V.P, w0[1])
+    with pytest.raises(VerifyError, match="vanishing"):
+        circ.verify(V.write_proof_with_pis(proof, pis))
+    with pytest.raises(N.ShapeError):
+        circ.verify(raw[:-9])
+
+
+@pytest.mark.parametrize("victim", range(1, 12))
+def test_every_gate_evaluator_is_pinned(golden_dir, victim):
+    """Replace one gate of the set by a NoopGate (its constraints drop out of the sum): the identity must fail, i.e. the
+    reference's proof pins each evaluator separately."""
+    rd = lambda n: open(os.path.join(golden_dir, n), "rb").read()
+    common = rd("recursive_verifier_gl_common_data.bin")
+    gates = V.read_gates(common, V.read_common_data(common))
+    g = gates[victim]
+    gates[victim] = (0, 0) + tuple(g[2:5]) + (0, 0)
+    circ, cd, raw = _fixture_circuit(golden_dir, gates=gates)
+    with pytest.raises(VerifyError, match="vanishing"):
+        circ.verify(raw)
+
+
+def test_wrong_salt_setting_is_malformed(golden_dir):
+    circ, cd, raw = _fixture_circuit(golden_dir, zero_knowledge=False)
+    with pytest.raises((N.ShapeError, VerifyError)):
+        circ.verify(raw)
