@@ -47,7 +47,7 @@ def cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample_log_n):
     """The CPU oracle (same algorithm as the reference: per-column radix-2 NTTs, transpose,
     recursive Merkle) on all host cores, on a row-reduced sample of the same matrix."""
     from oracle import oracle as O
-    cores = int(O.lib().gbo_num_threads())
+    cores = O.use_host_cpu_share()  # a 1-GPU box grants 16 of the host's CPUs (cgroup quota): more threads only contend
     vals = splitmix64_matrix(0xC0FFEE ^ (ncols << 32) ^ sample_log_n, ncols, 1 << sample_log_n)
     O.PolynomialBatch.from_values(vals[:, : 1 << 10].copy(), rate_bits, cap_height)  # warm the library
     t0 = time.perf_counter()
@@ -67,7 +67,7 @@ def cpu_baseline_prove(log_n, num_challenges, sample_log_n, field="goldilocks"):
     Rayon) on a smaller dummy circuit of the same shape, scaled linearly in rows."""
     from oracle import oracle as O
     from oracle import plonk_dummy as D
-    cores = int(O.lib().gbo_num_threads())
+    cores = O.use_host_cpu_share()  # a 1-GPU box grants 16 of the host's CPUs (cgroup quota): more threads only contend
     if field == "babybear":
         from oracle.fields import BB
         circ = D.DummyCircuit(sample_log_n, D.CircuitConfig.babybear(num_challenges), check_security=False, F=BB)
@@ -290,10 +290,11 @@ def main():
             out["perm_arg_retries"] = retries[0]  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the driver's contract)
             sample = args.cpu_sample_log_n
-            cores = os.cpu_count() or 1
+            from oracle import oracle as _O
+            cores = _O.host_cpu_share()
             if args.workload == "prove":
                 if sample is None:
-                    sample = max(8, min(log_n, 17 if bb else 16, (11 if bb else 10) + (cores.bit_length() - 1)))  # ~10-30 s of CPU work
+                    sample = max(8, min(log_n, 19 if bb else 18, (15 if bb else 14) + (cores.bit_length() - 1)))  # ~10-30 s of CPU work
                 out["cpu_baseline"] = cpu_baseline_prove(log_n, args.challenges, sample, args.field)
             else:
                 if sample is None:

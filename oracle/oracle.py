@@ -69,6 +69,7 @@ def lib():
         L.gbo_gl_powers.argtypes = [C.c_uint64, C.c_size_t, _u64p]
         L.gbo_gl_scale_vec.argtypes = [_u64p, C.c_uint64, C.c_size_t, _u64p]
         L.gbo_num_threads.restype = C.c_int
+        L.gbo_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -286,3 +287,29 @@ def splitmix64_fill(seed, count, modulus=GL_P):
         z = z ^ (z >> np.uint64(31))
     out[:] = z % np.uint64(modulus)
     return out
+
+
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota_us)."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def use_host_cpu_share():
+    """Size the OpenMP pool to host_cpu_share(); returns the thread count in use."""
+    n = host_cpu_share()
+    lib().gbo_set_num_threads(n)
+    return int(lib().gbo_num_threads())

@@ -584,6 +584,14 @@ gl_t gbo_gl_mul(gl_t a, gl_t b) { return gl_mul(a, b); }
 gl_t gbo_gl_powu(gl_t a, uint64_t e) { return gl_pow(a, e); }
 gl_t gbo_gl_inv(gl_t a) { return gl_inv(a); }
 gl_t gbo_gl_two_adic_generator(unsigned bits) { return gl_two_adic_generator(bits); }
+/* the host may grant fewer CPUs than it shows (a cgroup quota): the caller sizes the pool to its share */
+void gbo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int gbo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

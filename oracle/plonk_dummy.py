@@ -158,7 +158,7 @@ class DummyCircuit:
                 cfg.max_quotient_degree_factor, self.degree_bits, self.num_selectors, self.GATE_NOOP, self.GATE_CONSTANT,
                 self.GATE_PI, cfg.num_constants, len(self.gate_table)]
         for g in self.gate_table:
-            vals += list(g)
+            vals += list(g[:5])   # the C oracle prover knows the kinds without a second parameter
         vals += [0] * (5 * (16 - len(self.gate_table)))
         return (C.c_uint * len(vals))(*vals)
 

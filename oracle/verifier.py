@@ -158,7 +158,7 @@ def read_gates(data, cd, F=GL):
         elif tag == 11:
             kind = G.POSEIDON
         elif tag == 12:
-            kind = G.PUBLIC_INPUT
+            kind, p1 = G.PUBLIC_INPUT, F.hout
         elif tag == 13:
             kind, p1, p2, p3 = G.RANDOM_ACCESS, r.usize(), r.usize(), r.usize()
         elif tag == 14:

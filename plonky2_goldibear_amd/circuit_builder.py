@@ -14,7 +14,8 @@ Python so that circuits other than the dummy one - the reference's `factorial` e
 Gates: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate (gates/arithmetic_base.rs) and the in-circuit hash of the
 configuration - PoseidonGate (gates/poseidon_goldilocks.rs) for Goldilocks, Poseidon2BabyBearGate (gates/poseidon2_babybear.rs)
 for BabyBear - which `build()` itself needs as soon as a circuit has public inputs, because it hashes them in-circuit
-(circuit_builder.rs:1126-1137).  Not the GPU hot path: plain Python integers.
+(circuit_builder.rs:1126-1137).  The other gates of the recursion circuits are in recursion_gates.py (add_gate() takes them).
+Not the GPU hot path: plain Python integers.
 """
 import os
 import re
@@ -635,8 +636,8 @@ class CircuitBuilder:
             if row in incomplete:
                 gg = gg[:incomplete[row]]
             gens += gg
-        gate_table = [(g.kind, g.param, selector_indices[i], groups[selector_indices[i]][0], groups[selector_indices[i]][1])
-                      for i, g in enumerate(gates)]
+        gate_table = [(g.kind, g.param, selector_indices[i], groups[selector_indices[i]][0], groups[selector_indices[i]][1],
+                       getattr(g, "param2", 0), getattr(g, "param3", 0)) for i, g in enumerate(gates)]
         return BuiltCircuit(ctx, cfg, F, degree_bits, constants_sigmas, k_is, gate_table, len(groups), max_constants, gens, find,
                             list(self.public_inputs), self.random_wire, [g.id for g in gates],
                             sorted({t for ab in self.copy_constraints for t in ab if t[0] == "w"}))

@@ -77,3 +77,72 @@ def oracle_circuit(built, num_public_inputs):
                             max_quotient_degree_factor=cfg.max_quotient_degree_factor)
     return PD.BuiltCircuit(ocfg, F, built.degree_bits, built.constants_sigmas, built.k_is, built.gate_table, built.num_selectors,
                            num_public_inputs)
+
+
+def recursion_gates_circuit(field=N.GB_GOLDILOCKS, seed=1, public_inputs=True, **cfg_kw):
+    """One row of each gate of plonky2_goldibear_amd/recursion_gates.py with random inputs (the generators fill the rest), next to
+    a short arithmetic chain.  Returns (builder, partial witness, {gate name: row})."""
+    from plonky2_goldibear_amd import recursion_gates as R
+    from plonky2_goldibear_amd.circuit_builder import wire
+    gl = field == N.GB_GOLDILOCKS
+    cfg = CircuitConfig.standard_recursion_config_gl(**cfg_kw) if gl else CircuitConfig.recursion_config_bb_narrow(**cfg_kw)
+    b = CircuitBuilder(cfg)
+    p, D = b.F.p, b.F.ext_degree
+    rng = np.random.default_rng(seed)
+    rnd = lambda: int(rng.integers(0, p, dtype=np.uint64))
+    pw = PartialWitness()
+    rows = {}
+
+    def fill(row, cols):
+        for c in cols:
+            pw.set_target(wire(row, c), rnd())
+
+    x = b.add_virtual_target()
+    y = b.mul_add(x, x, b.constant(5))
+    if public_inputs:
+        b.register_public_input(x)
+        b.register_public_input(y)
+    pw.set_target(x, 3)
+
+    g = R.ArithmeticExtensionGate.new_from_config(cfg)
+    rows["arithmetic_extension"] = r = b.add_gate(g, [rnd(), rnd()])
+    fill(r, [4 * D * i + k for i in range(g.num_ops) for k in range(3 * D)])
+    g = R.MulExtensionGate.new_from_config(cfg)
+    rows["mul_extension"] = r = b.add_gate(g, [rnd()])
+    fill(r, [3 * D * i + k for i in range(g.num_ops) for k in range(2 * D)])
+    g = R.BaseSumGate(min(63 if gl else 30, cfg.num_routed_wires - 1), 2)
+    rows["base_sum"] = r = b.add_gate(g)
+    pw.set_target(wire(r, 0), int(rng.integers(0, 1 << min(g.num_limbs, 62))))
+    g = R.BaseSumGate(10, 4)
+    rows["base_sum_4"] = r = b.add_gate(g)
+    pw.set_target(wire(r, 0), int(rng.integers(0, 4 ** 10)))
+    nc = min(cfg.num_routed_wires - 3 * D, (cfg.num_wires - 2 * D) // (D + 1))
+    g = R.ReducingGate(nc, field)
+    rows["reducing"] = r = b.add_gate(g)
+    fill(r, list(range(D, 3 * D + nc)))
+    nc = min((cfg.num_routed_wires - 3 * D) // D, (cfg.num_wires - 2 * D) // (2 * D))
+    g = R.ReducingExtensionGate(nc, field)
+    rows["reducing_extension"] = r = b.add_gate(g)
+    fill(r, list(range(D, 3 * D + nc * D)))
+    g = R.RandomAccessGate.new_from_config(cfg, 4 if gl else 3)
+    rows["random_access"] = r = b.add_gate(g)
+    for copy in range(g.num_copies):
+        items = [rnd() for _ in range(g.vec_size)]
+        idx = int(rng.integers(0, g.vec_size))
+        pw.set_target(wire(r, g.wire_access_index(copy)), idx)
+        pw.set_target(wire(r, g.wire_claimed_element(copy)), items[idx])
+        for i, v in enumerate(items):
+            pw.set_target(wire(r, g.wire_list_item(i, copy)), v)
+    if gl:
+        g = R.PoseidonMdsGate()
+        rows["poseidon_mds"] = r = b.add_gate(g)
+        fill(r, list(range(12 * D)))
+    g = R.CosetInterpolationGate(4 if gl else 3, field, max_degree=6 if gl else 4)
+    rows["coset_interpolation"] = r = b.add_gate(g)
+    fill(r, [0] + list(range(1, 1 + g.num_points * D)) + list(range(g.start_point, g.start_point + D)))
+    g = R.ExponentiationGate.new_from_config(cfg)
+    rows["exponentiation"] = r = b.add_gate(g)
+    fill(r, [0])
+    for i in range(g.num_power_bits):
+        pw.set_target(wire(r, 1 + i), int(rng.integers(0, 2)))
+    return b, pw, rows
