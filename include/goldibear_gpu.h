@@ -132,7 +132,7 @@ typedef struct gb_circuit_config {
     uint32_t num_selectors;         /* 1 */
     uint32_t gate_constant, gate_pi;/* selector values of ConstantGate / PublicInputGate (NoopGate is the third) */
     uint32_t zero_knowledge;        /* CircuitConfig.zero_knowledge (= FriParams.hiding): the wires / Zs / quotient leaves carry
-                                       SALT_SIZE salt elements (fri/oracle.rs:133-148).  gb_verify handles it; gb_prove does not */
+                                       SALT_SIZE salt elements (fri/oracle.rs:133-148): gb_prove_salted, gb_verify */
 } gb_circuit_config;
 
 /* constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits] VALUES on H_n
@@ -193,6 +193,14 @@ gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_ou
 #define GB_ERR_BUFFER_TOO_SMALL 18
 gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uint64_t* public_inputs,
                    size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);
+/* The same for a circuit built with cfg.zero_knowledge (prover.rs:267,334,382: `blinding` = true for the wires, Zs / partial
+ * products and quotient commitments).  salts: [3][GB_SALT_SIZE][N = 2^(degree_bits + rate_bits)] canonical elements in
+ * LDE-point order - the columns the reference draws with F::rand_vec (fri/oracle.rs:144-148) - for those three commitments,
+ * in the same memory space as `witness` (flags); a host input for the same reason the PublicInputGate's random wires are
+ * (determinism contract: same inputs, same proof bytes).  The circuit's blinding rows (circuit_builder.rs:935-975
+ * blind_and_pad) are the builder's business and part of `witness`. */
+gb_status gb_prove_salted(gb_circuit* c, const void* witness, uint32_t flags, const uint64_t* public_inputs,
+                          size_t num_public_inputs, const void* salts, void* proof_out, size_t proof_cap, size_t* proof_len);
 
 /* verify() of a proof produced for this circuit (plonk/verifier.rs:17-128, fri/verifier.rs:67-250,
  * plonk/get_challenges.rs:26-101), restated for the dummy gate set and run on the HOST like the reference's verifier: the

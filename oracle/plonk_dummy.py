@@ -54,6 +54,7 @@ def reduction_arity_bits(cfg, degree_bits):
 class DummyCircuit:
     """CircuitData of the bench-form dummy circuit with 2^degree_bits rows (degree_bits >= 3)."""
 
+    zero_knowledge = False  # CircuitConfig.zero_knowledge (= FriParams.hiding); set on an instance to get salted commitments
     GATE_NOOP, GATE_CONSTANT, GATE_PI = 0, 1, 2  # sorted by (degree, id): Noop(0), "ConstantGate {..}"(1), "PublicInputGate<4>"(1)
 
     def __init__(self, degree_bits, cfg=None, check_security=True, F=GL):
@@ -144,9 +145,9 @@ class DummyCircuit:
                        proof_of_work_bits=cfg.proof_of_work_bits)
         return dict(
             config=dict(num_wires=cfg.num_wires, num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
-                        num_challenges=cfg.num_challenges, fri_config=fri_cfg, zero_knowledge=False),
+                        num_challenges=cfg.num_challenges, fri_config=fri_cfg, zero_knowledge=self.zero_knowledge),
             fri_params=dict(config=fri_cfg, reduction_arity_bits=self.reduction_arity_bits, degree_bits=self.degree_bits,
-                            hiding=False),
+                            hiding=self.zero_knowledge),
             quotient_degree_factor=cfg.max_quotient_degree_factor, num_constants=self.num_constants,
             num_partial_products=self.num_partial_products, num_lookup_polys=0, k_is=[int(k) for k in self.k_is],
             num_public_inputs=self.num_public_inputs)
@@ -210,24 +211,31 @@ class CommonDataCircuit(DummyCircuit):
         return self._cd
 
 
-def prove_cpu(circ, witness, public_inputs=()):
-    """Run the CPU oracle prover; returns (proof_bytes, debug challenges)."""
+def prove_cpu(circ, witness, public_inputs=(), salts=None):
+    """Run the CPU oracle prover; returns (proof_bytes, debug challenges).  `salts`: None, or for a zero-knowledge circuit
+    (circ.zero_knowledge) the [3][4][N] salt columns of the wires / Zs / quotient commitments in LDE-point order - the values
+    the reference draws with F::rand_vec (fri/oracle.rs:144-148), a host input here."""
     L = O.lib()
     F = circ.F
-    fn = getattr(L, F.prove_symbol)
+    fn = getattr(L, F.prove_symbol + "_salted")
     fn.restype = C.c_int
     c = circ.cfg.num_challenges
     cs = np.ascontiguousarray(circ.constants_sigmas)
     wit = np.ascontiguousarray(witness, dtype=F.dtype)
     pis = np.ascontiguousarray(list(public_inputs) or [0], dtype=F.dtype)
     dig = np.ascontiguousarray(circ.circuit_digest)
+    assert (salts is not None) == bool(getattr(circ, "zero_knowledge", False)), "salts go with zero_knowledge circuits"
+    if salts is not None:
+        salts = np.ascontiguousarray(salts, dtype=F.dtype)
+        assert salts.shape == (3, 4, circ.n << circ.cfg.rate_bits)
     cap = 64 << 20
     out = np.zeros(cap, dtype=np.uint8)
     out_len = C.c_size_t()
     dbg = np.zeros(3 * c + 2 * F.D + 1, dtype=F.dtype)  # betas, gammas, alphas, zeta, fri_alpha, pow response
     rc = fn(circ.c_cfg(), cs.ctypes.data_as(C.c_void_p), dig.ctypes.data_as(C.c_void_p), circ.k_is.ctypes.data_as(C.c_void_p),
             wit.ctypes.data_as(C.c_void_p), pis.ctypes.data_as(C.c_void_p), C.c_size_t(len(public_inputs)),
-            out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p))
+            out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p),
+            salts.ctypes.data_as(C.c_void_p) if salts is not None else None)
     if rc != 0:
         raise RuntimeError("oracle prover failed: rc=%d" % rc)
     prove_cpu.last_cs_commit_seconds = C.c_double.in_dll(L, "gbo_last_cs_commit_seconds").value  # build() share of the call

@@ -60,6 +60,7 @@ static inline bb4_t bb4_pow(bb4_t b, uint64_t e) { bb4_t r = bb4_from(1); while 
 #define X_CH_OBSERVE gbo_bb_challenger_observe
 #define X_CH_GET gbo_bb_challenger_get
 #define X_PROVE_DUMMY gbo_bb_prove_dummy
+#define X_PROVE_DUMMY_SALTED gbo_bb_prove_dummy_salted
 
 /* from oracle_bb.c */
 void gbo_bb_hash_no_pad(const bb_t *in, size_t n, bb_t out[HOUT]);

@@ -32,6 +32,7 @@
 #define X_CH_OBSERVE gbo_gl_challenger_observe
 #define X_CH_GET gbo_gl_challenger_get
 #define X_PROVE_DUMMY gbo_gl_prove_dummy
+#define X_PROVE_DUMMY_SALTED gbo_gl_prove_dummy_salted
 
 /* from oracle_gl.c */
 void gbo_gl_hash_no_pad(const gl_t *in, size_t n, gl_t out[HOUT]);

@@ -54,7 +54,7 @@ typedef struct {
 #define GBO_MAX_TERMS 512
 
 typedef struct {
-    size_t ncols;
+    size_t ncols, width; /* width = ncols + salt columns */
     unsigned log_n, rate_bits, cap_height;
     F_T *coeffs, *leaves, *digests, *cap;
 } batch_t;
@@ -65,22 +65,24 @@ static size_t rev_bits_sz(size_t x, unsigned bits) {
     return r;
 }
 
+/* salts: NULL (blinding = false) or the SALT_SIZE = 4 salt columns [4][N] (fri/oracle.rs:133-148) */
 static int batch_commit(batch_t *b, const F_T *cols, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height,
-                        int is_coeffs) {
+                        int is_coeffs, const F_T *salts) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
     b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->width = ncols + (salts ? 4 : 0);
     b->coeffs = malloc(ncols * n * sizeof(F_T));
-    b->leaves = malloc(N * ncols * sizeof(F_T));
+    b->leaves = malloc(N * b->width * sizeof(F_T));
     b->digests = malloc((2 * (N - ((size_t)1 << cap_height)) + 1) * HOUT * sizeof(F_T));
     b->cap = malloc(((size_t)HOUT << cap_height) * sizeof(F_T));
     if (!b->coeffs || !b->leaves || !b->digests || !b->cap) return -2;
-    return X_COMMIT(cols, ncols, log_n, rate_bits, cap_height, is_coeffs, NULL, b->coeffs, b->leaves, b->digests, b->cap);
+    return X_COMMIT(cols, ncols, log_n, rate_bits, cap_height, is_coeffs, salts, b->coeffs, b->leaves, b->digests, b->cap);
 }
 static void batch_free(batch_t *b) { free(b->coeffs); free(b->leaves); free(b->digests); free(b->cap); }
 /* fri/oracle.rs:153-158 */
 static const F_T *batch_lde(const batch_t *b, size_t index, size_t step) {
     unsigned bits = b->log_n + b->rate_bits;
-    return b->leaves + rev_bits_sz(index * step, bits) * b->ncols;
+    return b->leaves + rev_bits_sz(index * step, bits) * b->width;
 }
 
 static E_T challenger_ext(challenger_t *c) { E_T r; for (int k = 0; k < D; k++) r.c[k] = X_CH_GET(c); return r; }
@@ -103,10 +105,11 @@ static E_T eval_base_poly_ext(const F_T *c, size_t n, E_T z) {
 }
 
 /* Status: 0 ok, 1 = InvZeroPermArg (plonk/prover.rs:512-514), 2 = opening point in subgroup, <0 internal */
-int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs][n] values*/,
+int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs][n] values*/,
                        const F_T *circuit_digest, const F_T *k_is, const F_T *witness /*[num_wires][n]*/,
                        const F_T *public_inputs, size_t num_public_inputs, uint8_t *out, size_t out_cap, size_t *out_len,
-                       F_T *debug_out /* optional: [betas c][gammas c][alphas c][zeta D][fri_alpha D][pow 1] */) {
+                       F_T *debug_out /* optional: [betas c][gammas c][alphas c][zeta D][fri_alpha D][pow 1] */,
+                       const F_T *salts /* NULL, or zero-knowledge (prover.rs:267,334,382): [3][4][N] for wires, zs, quotient */) {
     const unsigned c = cfg->num_challenges, r = cfg->rate_bits, lg = cfg->degree_bits, capH = cfg->cap_height;
     const size_t n = (size_t)1 << lg, N = n << r;
     const unsigned lgN = lg + r;
@@ -133,10 +136,10 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     /* the constants/sigmas commitment is build() work (circuit_builder.rs:1230-1239), redone here only because this
      * oracle keeps no circuit object; its wall time is reported so that a prove() timing can leave it out */
     double t_cs = omp_get_wtime();
-    if ((rc = batch_commit(&cs, constants_sigmas, ncs, lg, r, capH, 0))) return rc;
+    if ((rc = batch_commit(&cs, constants_sigmas, ncs, lg, r, capH, 0, NULL))) return rc;
     gbo_last_cs_commit_seconds = omp_get_wtime() - t_cs;
     GBO_SCOPE("constants/sigmas commit (build() work)");
-    if ((rc = batch_commit(&wires, witness, nw, lg, r, capH, 0))) return rc;          /* prover.rs:261-272 */
+    if ((rc = batch_commit(&wires, witness, nw, lg, r, capH, 0, salts))) return rc;          /* prover.rs:261-272 */
 
     challenger_t ch;
     X_CH_INIT(&ch);
@@ -195,7 +198,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
     }
     if (rc) goto done_early;
     GBO_SCOPE("Z and partial products");
-    if ((rc = batch_commit(&zs, zs_vals, nzs, lg, r, capH, 0))) goto done_early;    /* prover.rs:328-339 */
+    if ((rc = batch_commit(&zs, zs_vals, nzs, lg, r, capH, 0, salts ? salts + 4 * N : NULL))) goto done_early;    /* prover.rs:328-339 */
     X_CH_OBSERVE(&ch, zs.cap, (size_t)HOUT << capH);
     for (unsigned i = 0; i < c; i++) alphas[i] = X_CH_GET(&ch);
 
@@ -293,7 +296,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
         memcpy(qchunks + (size_t)k * qdf * n, qvals + (size_t)k * N, (size_t)qdf * n * sizeof(F_T));
     }
     GBO_SCOPE("quotient values + coset_ifft");
-    if ((rc = batch_commit(&quot, qchunks, (size_t)c * qdf, lg, r, capH, 1))) goto done;   /* prover.rs:376-387 */
+    if ((rc = batch_commit(&quot, qchunks, (size_t)c * qdf, lg, r, capH, 1, salts ? salts + 8 * N : NULL))) goto done;   /* prover.rs:376-387 */
     X_CH_OBSERVE(&ch, quot.cap, (size_t)HOUT << capH);
     E_T zeta = challenger_ext(&ch);
     {
@@ -466,7 +469,7 @@ int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs
             size_t x_index = (size_t)((uint64_t)X_CH_GET(&ch) % N);
             for (int o = 0; o < 4; o++) {
                 const batch_t *b = oracles[o];
-                put(&ob, b->leaves + x_index * b->ncols, b->ncols * sizeof(F_T));
+                put(&ob, b->leaves + x_index * b->width, b->width * sizeof(F_T)); /* salted rows when hiding */
                 int ns = X_MERKLE_PROVE(b->digests, lgN, capH, x_index, sib);
                 put_u8(&ob, (uint8_t)ns);
                 put(&ob, sib, (size_t)ns * HOUT * sizeof(F_T));
@@ -508,4 +511,11 @@ done_early:
     free(zs_vals); free(subgroup); free(betas); free(gammas); free(alphas);
     batch_free(&cs); batch_free(&wires); batch_free(&zs); batch_free(&quot);
     return rc;
+}
+
+int X_PROVE_DUMMY(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas, const F_T *circuit_digest, const F_T *k_is,
+                  const F_T *witness, const F_T *public_inputs, size_t num_public_inputs, uint8_t *out, size_t out_cap,
+                  size_t *out_len, F_T *debug_out) {
+    return X_PROVE_DUMMY_SALTED(cfg, constants_sigmas, circuit_digest, k_is, witness, public_inputs, num_public_inputs, out, out_cap,
+                                out_len, debug_out, NULL);
 }

@@ -49,6 +49,7 @@ SIGNATURES = {
     "gb_circuit_free": (_i32, [_vp]),
     "gb_circuit_verifier_data": (_i32, [_vp, _vp, _vp]),
     "gb_prove": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "gb_prove_salted": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
 }
 
 _lib = None

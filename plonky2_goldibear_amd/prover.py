@@ -42,7 +42,7 @@ class CircuitData:
     def __init__(self, ctx, degree_bits, constants_sigmas, k_is, *, num_wires=135, num_routed_wires=80, num_constants=2,
                  num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16,
                  num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1, gate_constant=1, gate_pi=2,
-                 field=N.GB_GOLDILOCKS, gates=None):
+                 field=N.GB_GOLDILOCKS, gates=None, zero_knowledge=False):
         """`gates` = None: the dummy circuit's gate set, given by the selector values gate_constant / gate_pi
         (gb_circuit_create).  Otherwise CommonCircuitData.gates with selectors_info, one tuple
         (kind, param, selector_index, group_start, group_end) per gate in sorted order (gb_circuit_create_gates; what
@@ -52,7 +52,8 @@ class CircuitData:
         hout = 4 if field == N.GB_GOLDILOCKS else 8
         self.cfg = gb_circuit_config(field, degree_bits, num_wires, num_routed_wires, num_constants, num_challenges,
                                      max_quotient_degree_factor, rate_bits, cap_height, proof_of_work_bits,
-                                     num_query_rounds, arity_bits, final_poly_bits, num_selectors, gate_constant, gate_pi)
+                                     num_query_rounds, arity_bits, final_poly_bits, num_selectors, gate_constant, gate_pi,
+                                     1 if zero_knowledge else 0)
         ptr, shape, flags, keep = _as_input(constants_sigmas, field)
         want = (num_selectors + num_constants + num_routed_wires, 1 << degree_bits)
         if tuple(shape) != want:
@@ -84,7 +85,7 @@ class CircuitData:
 
     MAX_PERM_ARG_RETRIES = 3  # plonk/prover.rs:183
 
-    def prove(self, witness, public_inputs=(), random_wire=None, rng=None):
+    def prove(self, witness, public_inputs=(), random_wire=None, rng=None, salts=None):
         """prove_with_partition_witness (plonk/prover.rs:160-226): the retry loop around the proof proper.  When the
         permutation argument hits a zero denominator (ProverError::InvZeroPermArg - with a 31-bit field and 2^20 rows
         about one proof in five) the reference overwrites `random_wire` (circuit_builder.rs:1073-1075: the last wire of the
@@ -106,13 +107,15 @@ class CircuitData:
                     witness[col, row] = val - (1 << (8 * witness.element_size())) if val >> (8 * witness.element_size() - 1) else val
                 self.perm_arg_retries = attempt
             try:
-                return self.prove_once(witness, public_inputs)
+                return self.prove_once(witness, public_inputs, salts)
             except N.PermArgZeroError:
                 continue
         raise N.TooManyPermArgFailuresError(N.GB_ERR_PERM_ARG_ZERO, "ProverError::TooManyPermArgFailures")
 
-    def prove_once(self, witness, public_inputs=()):
-        """internal_prove_with_partition_witness (plonk/prover.rs:228-447); raises PermArgZeroError."""
+    def prove_once(self, witness, public_inputs=(), salts=None):
+        """internal_prove_with_partition_witness (plonk/prover.rs:228-447); raises PermArgZeroError.  A circuit created with
+        zero_knowledge=True takes `salts`: [3][4][N] canonical elements (the F::rand_vec columns of the wires / Zs / quotient
+        commitments, fri/oracle.rs:144-148), in the same memory space as the witness."""
         ptr, shape, flags, keep = _as_input(witness, self.field)
         want = (self.cfg.num_wires, 1 << self.cfg.degree_bits)
         if tuple(shape) != want:
@@ -121,8 +124,18 @@ class CircuitData:
         if self._proof_buf is None:
             self._proof_buf = np.empty(8 << 20, dtype=np.uint8)
         n = C.c_size_t()
-        st = self._lib.gb_prove(self.handle, ptr, flags, pis.ctypes.data if pis.size else None, pis.size,
-                                self._proof_buf.ctypes.data, self._proof_buf.size, C.byref(n))
+        pis_ptr = pis.ctypes.data if pis.size else None
+        if salts is None:
+            st = self._lib.gb_prove(self.handle, ptr, flags, pis_ptr, pis.size, self._proof_buf.ctypes.data, self._proof_buf.size,
+                                    C.byref(n))
+        else:
+            sptr, sshape, sflags, skeep = _as_input(np.reshape(salts, (3 * N.GB_SALT_SIZE, -1)) if isinstance(salts, np.ndarray)
+                                                    else salts.reshape(3 * N.GB_SALT_SIZE, -1), self.field)
+            if tuple(sshape) != (3 * N.GB_SALT_SIZE, 1 << (self.cfg.degree_bits + self.cfg.rate_bits)) or sflags != flags:
+                raise N.ShapeError(N.GB_ERR_INVALID, "salts must be [3][4][N] in the same memory space as the witness")
+            st = self._lib.gb_prove_salted(self.handle, ptr, flags, pis_ptr, pis.size, sptr, self._proof_buf.ctypes.data,
+                                           self._proof_buf.size, C.byref(n))
+            del skeep
         N.check(st, self.ctx.handle)
         del keep
         return self._proof_buf[: n.value].tobytes()

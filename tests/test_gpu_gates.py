@@ -120,7 +120,9 @@ def test_gate_table_validation(ctx):
     b, pw = factorial_circuit()
     c = b.build()
     kw = dict(num_constants=c.max_constants, num_selectors=c.num_selectors)
-    with pytest.raises(N.GoldibearError, match="not evaluated"):
+    with pytest.raises(N.GoldibearError, match="no constraint evaluator"):   # e.g. LookupGate
+        CircuitData(ctx, c.degree_bits, c.constants_sigmas, c.k_is, gates=[(99, 0, 0, 0, 1)] + c.gate_table[1:], **kw)
+    with pytest.raises(ShapeError, match="param 0"):
         CircuitData(ctx, c.degree_bits, c.constants_sigmas, c.k_is, gates=[(9, 0, 0, 0, 1)] + c.gate_table[1:], **kw)
     with pytest.raises(ShapeError, match="selector group"):
         CircuitData(ctx, c.degree_bits, c.constants_sigmas, c.k_is, gates=[(0, 0, 0, 1, 4)] + c.gate_table[1:], **kw)
