@@ -209,6 +209,16 @@ gb_status gb_prove_salted(gb_circuit* c, const void* witness, uint32_t flags, co
  * malformed bytes. */
 #define GB_ERR_VERIFY 19
 gb_status gb_verify(gb_circuit* c, const void* proof, size_t proof_len);
+/* Compressed proofs, on the host like the reference's (hash/path_compression.rs, fri/proof.rs:137-384, plonk/proof.rs:96-260):
+ * gb_proof_compress = ProofWithPublicInputs::compress -> CompressedProofWithPublicInputs bytes (util/serialization/mod.rs:2168-2256:
+ * Merkle paths of one tree share their siblings, a repeated query index is stored once, the FRI evaluation the verifier can infer
+ * is dropped); gb_proof_decompress = CompressedProofWithPublicInputs::decompress (replays the transcript, recomputes the inferred
+ * evaluations, re-inflates the paths) -> the original bytes; gb_verify_compressed = CompressedProofWithPublicInputs::verify.
+ * *out_len receives the size written (or needed, with GB_ERR_BUFFER_TOO_SMALL).  They need the circuit's common data only, so a
+ * gb_verifier_create object serves as well. */
+gb_status gb_proof_compress(gb_circuit* c, const void* proof, size_t proof_len, void* out, size_t out_cap, size_t* out_len);
+gb_status gb_proof_decompress(gb_circuit* c, const void* compressed, size_t compressed_len, void* out, size_t out_cap, size_t* out_len);
+gb_status gb_verify_compressed(gb_circuit* c, const void* compressed, size_t compressed_len);
 /* A circuit object for gb_verify alone, from what a verifier holds: CommonCircuitData (cfg + gates, as for
  * gb_circuit_create_gates; k_is [num_routed_wires]) and VerifierOnlyCircuitData (constants_sigmas_cap [2^cap_height][H],
  * circuit_digest [H]), all host pointers to canonical elements.  Touches no device: ctx may be NULL (gb_last_error(NULL) then

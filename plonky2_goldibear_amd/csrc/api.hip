@@ -13,6 +13,8 @@
 #include <string>
 #include <tuple>
 #include <utility>
+#include <array>
+#include <set>
 #include <vector>
 
 #include "bb_field.hpp"
@@ -737,3 +739,4 @@ gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uin
 
 #include "prover_host.inc"
 #include "verifier_host.inc"
+#include "compress_host.inc"

@@ -41,6 +41,9 @@ SIGNATURES = {
     "gb_batch_device_ptrs": (_i32, [_vp, _pvp, _pvp, _pvp]),
     "gb_batch_eval_ext": (_i32, [_vp, _vp, _vp]),
     "gb_verify": (_i32, [_vp, _vp, _sz]),
+    "gb_proof_compress": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "gb_proof_decompress": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "gb_verify_compressed": (_i32, [_vp, _vp, _sz]),
     "gb_verifier_create": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _pvp]),
     "gb_pow_grind": (_i32, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gb_permute": (_i32, [_vp, _u32, _vp, _vp, _u64]),

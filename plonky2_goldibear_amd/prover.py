@@ -29,7 +29,33 @@ class gb_gate(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("kind", "param", "selector_index", "group_start", "group_end", "param2", "param3")]
 
 
-class CircuitData:
+class _ProofBytesOps:
+    """compress / decompress / verify_compressed over the C ABI (plonk/proof.rs:96-140, 183-265), shared by CircuitData and
+    VerifierCircuitData; all three run on the host."""
+
+    def _bytes_call(self, fn, data):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        out = np.empty(max(1 << 16, 2 * buf.size), dtype=np.uint8)
+        n = C.c_size_t()
+        N.check(fn(self.handle, buf.ctypes.data, buf.size, out.ctypes.data, out.size, C.byref(n)), getattr(getattr(self, "ctx", None), "handle", None))
+        return out[: n.value].tobytes()
+
+    def compress(self, proof_bytes):
+        """ProofWithPublicInputs::compress -> CompressedProofWithPublicInputs bytes"""
+        return self._bytes_call(self._lib.gb_proof_compress, proof_bytes)
+
+    def decompress(self, compressed_bytes):
+        """CompressedProofWithPublicInputs::decompress -> ProofWithPublicInputs bytes"""
+        return self._bytes_call(self._lib.gb_proof_decompress, compressed_bytes)
+
+    def verify_compressed(self, compressed_bytes):
+        """CompressedProofWithPublicInputs::verify; True, or raises VerifyError / ShapeError"""
+        buf = np.frombuffer(bytes(compressed_bytes), dtype=np.uint8)
+        N.check(self._lib.gb_verify_compressed(self.handle, buf.ctypes.data, buf.size), getattr(getattr(self, "ctx", None), "handle", None))
+        return True
+
+
+class CircuitData(_ProofBytesOps):
     """Defaults are standard_recursion_config_gl (plonk/circuit_data.rs:102-116); `CircuitData.babybear(...)`
     fills in recursion_config_bb_narrow (:131-139)."""
 
@@ -157,7 +183,7 @@ class CircuitData:
             self.free()
 
 
-class VerifierCircuitData:
+class VerifierCircuitData(_ProofBytesOps):
     """VerifierCircuitData (plonk/circuit_data.rs:358-380): CommonCircuitData + VerifierOnlyCircuitData, enough to verify and
     nothing else.  Built on gb_verifier_create, which touches no device - usable without a GPU context."""
 

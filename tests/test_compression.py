@@ -67,3 +67,46 @@ def test_oracle_proofs_round_trip(F):
 def struct_error():
     import struct
     return struct.error
+
+
+# ------------------------------------------------------------------------------------------------ the product (C ABI, host)
+def _abi_verifier(golden_dir):
+    from test_abi_verify_fixture import _fixture_circuit
+    return _fixture_circuit(golden_dir)
+
+
+def test_c_abi_compression_matches_oracle_on_the_reference_proof(golden_dir, fixture):
+    from plonky2_goldibear_amd import VerifyError
+    from plonky2_goldibear_amd import native as N
+    cd, vd, raw = fixture
+    circ, _, _ = _abi_verifier(golden_dir)
+    small = circ.compress(raw)
+    assert small == Z.compress_bytes(raw, vd["circuit_digest"], cd)
+    assert circ.decompress(small) == raw
+    assert circ.verify_compressed(small)
+    bad = bytearray(small)
+    bad[9000] ^= 1   # inside the openings: the transcript changes
+    with pytest.raises((VerifyError, N.ShapeError)):
+        circ.verify_compressed(bytes(bad))
+    with pytest.raises(N.ShapeError):
+        circ.decompress(small[:-5])
+
+
+@pytest.mark.parametrize("F", [GL, BB], ids=["goldilocks", "babybear"])
+def test_c_abi_compression_matches_oracle_on_small_proofs(F):
+    """2^8 LDE points and 28 queries: repeated indices and shared cosets in every layer"""
+    from plonky2_goldibear_amd import VerifierCircuitData
+    from plonky2_goldibear_amd import native as N
+    from test_zero_knowledge import _verifier
+    for zk in (False, True):
+        circ = D.DummyCircuit(5, F=F) if F is GL else D.DummyCircuit(5, D.CircuitConfig.babybear(6), F=BB)
+        salts = None
+        if zk:
+            circ.zero_knowledge = True
+            nl = circ.n << circ.cfg.rate_bits
+            salts = F.fill(77, 12 * nl).reshape(3, 4, nl)
+        proof, _ = D.prove_cpu(circ, circ.witness(seed=3), salts=salts)
+        v = _verifier(circ, zk)
+        small = v.compress(proof)
+        assert small == Z.compress_bytes(proof, circ.circuit_digest, circ.common_data(), F)
+        assert v.decompress(small) == proof and v.verify_compressed(small)
