@@ -40,6 +40,21 @@ pub struct gb_circuit_config {
     pub num_selectors: u32,
     pub gate_constant: u32,
     pub gate_pi: u32,
+    /// CircuitConfig.zero_knowledge (= FriParams.hiding): salted wires / Zs / quotient leaves
+    pub zero_knowledge: u32,
+}
+
+/// One entry of CommonCircuitData.gates with selectors_info flattened in (include/goldibear_gpu.h: gb_gate, GB_GATE_*).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct gb_gate {
+    pub kind: u32,
+    pub param: u32,
+    pub selector_index: u32,
+    pub group_start: u32,
+    pub group_end: u32,
+    pub param2: u32,
+    pub param3: u32,
 }
 
 extern "C" {
@@ -63,6 +78,16 @@ extern "C" {
     fn gb_prove(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
                 proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
     fn gb_verify(c: *mut gb_circuit, proof: *const c_void, proof_len: usize) -> i32;
+    fn gb_circuit_create_gates(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, gates: *const gb_gate, num_gates: u32,
+                               constants_sigmas: *const c_void, k_is: *const c_void, flags: u32, out: *mut *mut gb_circuit) -> i32;
+    fn gb_prove_salted(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
+                       salts: *const c_void, proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
+    fn gb_verifier_create(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, gates: *const gb_gate, num_gates: u32, k_is: *const c_void,
+                          constants_sigmas_cap: *const c_void, circuit_digest: *const c_void, out: *mut *mut gb_circuit) -> i32;
+    fn gb_verify_compressed(c: *mut gb_circuit, compressed: *const c_void, len: usize) -> i32;
+    fn gb_proof_compress(c: *mut gb_circuit, proof: *const c_void, len: usize, out: *mut c_void, cap: usize, out_len: *mut usize) -> i32;
+    fn gb_proof_decompress(c: *mut gb_circuit, compressed: *const c_void, len: usize, out: *mut c_void, cap: usize,
+                           out_len: *mut usize) -> i32;
 }
 
 /// Status code + the library's message.
@@ -212,6 +237,61 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         })?;
         Ok(Self { ctx, handle: h, config, _w: std::marker::PhantomData })
     }
+    /// The same for any gate set the library evaluates (`gates` = CommonCircuitData.gates with selectors_info, sorted as build()
+    /// leaves them); GB_ERR_UNSUPPORTED (status 4) tells the caller to keep the CPU prover for this circuit.
+    pub fn with_gates(ctx: &'c GpuContext, mut config: gb_circuit_config, gates: &[gb_gate], constants_sigmas: &[W], k_is: &[W])
+                      -> Result<Self, GpuError> {
+        config.field = field_tag::<W>();
+        let mut h = ptr::null_mut();
+        check(ctx.0, unsafe {
+            gb_circuit_create_gates(ctx.0, &config, gates.as_ptr(), gates.len() as u32, constants_sigmas.as_ptr() as *const c_void,
+                                    k_is.as_ptr() as *const c_void, GB_INPUT_HOST, &mut h)
+        })?;
+        Ok(Self { ctx, handle: h, config, _w: std::marker::PhantomData })
+    }
+    /// Zero-knowledge circuits: `salts` = [3][4][N] canonical words, the F::rand_vec columns of the wires / Zs / quotient
+    /// commitments (fri/oracle.rs:144-148)
+    pub fn prove_salted(&self, witness: &[W], public_inputs: &[u64], salts: &[W]) -> Result<ProveOutcome, GpuError> {
+        let mut buf = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        let st = unsafe {
+            gb_prove_salted(self.handle, witness.as_ptr() as *const c_void, GB_INPUT_HOST, public_inputs.as_ptr(), public_inputs.len(),
+                            salts.as_ptr() as *const c_void, buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
+        };
+        if st == GB_ERR_PERM_ARG_ZERO {
+            return Ok(ProveOutcome::PermArgZero);
+        }
+        check(self.ctx.0, st)?;
+        buf.truncate(len);
+        Ok(ProveOutcome::Proof(buf))
+    }
+    /// `ProofWithPublicInputs::compress` on serialized bytes (plonk/proof.rs:111-122)
+    pub fn compress(&self, proof: &[u8]) -> Result<Vec<u8>, GpuError> {
+        let mut buf = vec![0u8; proof.len().max(1 << 16)];
+        let mut len = 0usize;
+        check(self.ctx.0, unsafe { gb_proof_compress(self.handle, proof.as_ptr() as *const c_void, proof.len(),
+                                                     buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len) })?;
+        buf.truncate(len);
+        Ok(buf)
+    }
+    /// `CompressedProofWithPublicInputs::decompress` (plonk/proof.rs:221-236)
+    pub fn decompress(&self, compressed: &[u8]) -> Result<Vec<u8>, GpuError> {
+        let mut buf = vec![0u8; (2 * compressed.len()).max(1 << 16)];
+        let mut len = 0usize;
+        check(self.ctx.0, unsafe { gb_proof_decompress(self.handle, compressed.as_ptr() as *const c_void, compressed.len(),
+                                                       buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len) })?;
+        buf.truncate(len);
+        Ok(buf)
+    }
+    /// `CompressedProofWithPublicInputs::verify` (plonk/proof.rs:238-265)
+    pub fn verify_compressed(&self, compressed: &[u8]) -> Result<bool, GpuError> {
+        let st = unsafe { gb_verify_compressed(self.handle, compressed.as_ptr() as *const c_void, compressed.len()) };
+        if st == GB_ERR_VERIFY {
+            return Ok(false);
+        }
+        check(self.ctx.0, st)?;
+        Ok(true)
+    }
     /// (constants_sigmas_cap, circuit_digest)
     pub fn verifier_data(&self) -> Result<(Vec<W>, Vec<W>), GpuError> {
         let hl = if std::mem::size_of::<W>() == 8 { 4 } else { 8 };
@@ -235,7 +315,7 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         buf.truncate(len);
         Ok(ProveOutcome::Proof(buf))
     }
-    /// `CircuitData::verify` for the dummy gate set, on the host: Ok(true), Ok(false) when a check fails
+    /// `CircuitData::verify` for the gate sets the library evaluates, on the host: Ok(true), Ok(false) when a check fails
     pub fn verify(&self, proof: &[u8]) -> Result<bool, GpuError> {
         let st = unsafe { gb_verify(self.handle, proof.as_ptr() as *const c_void, proof.len()) };
         if st == GB_ERR_VERIFY {
@@ -246,6 +326,37 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
     }
 }
 impl<'c, W> Drop for GpuCircuit<'c, W> {
+    fn drop(&mut self) {
+        unsafe { gb_circuit_free(self.handle) };
+    }
+}
+
+/// `VerifierCircuitData` (plonk/circuit_data.rs:358-380): common data + verifier-only data; touches no device.
+pub struct Verifier<W> {
+    handle: *mut gb_circuit,
+    _w: std::marker::PhantomData<W>,
+}
+impl<W: Copy + Default> Verifier<W> {
+    pub fn new(mut config: gb_circuit_config, gates: &[gb_gate], k_is: &[W], constants_sigmas_cap: &[W], circuit_digest: &[W])
+               -> Result<Self, GpuError> {
+        config.field = field_tag::<W>();
+        let mut h = ptr::null_mut();
+        check(ptr::null(), unsafe {
+            gb_verifier_create(ptr::null_mut(), &config, gates.as_ptr(), gates.len() as u32, k_is.as_ptr() as *const c_void,
+                               constants_sigmas_cap.as_ptr() as *const c_void, circuit_digest.as_ptr() as *const c_void, &mut h)
+        })?;
+        Ok(Self { handle: h, _w: std::marker::PhantomData })
+    }
+    pub fn verify(&self, proof: &[u8]) -> Result<bool, GpuError> {
+        let st = unsafe { gb_verify(self.handle, proof.as_ptr() as *const c_void, proof.len()) };
+        if st == GB_ERR_VERIFY {
+            return Ok(false);
+        }
+        check(ptr::null(), st)?;
+        Ok(true)
+    }
+}
+impl<W> Drop for Verifier<W> {
     fn drop(&mut self) {
         unsafe { gb_circuit_free(self.handle) };
     }

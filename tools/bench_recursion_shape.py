@@ -1,0 +1,58 @@
+"""Timing of prove() on a recursion-SHAPED circuit: the gate set of the reference's recursion circuits (the twelve gates of its
+RECURSIVE_VERIFIER_GL fixture plus Constant, Exponentiation and a second BaseSum) at 2^12..2^14 rows, standard_recursion_config_gl
+(num_challenges 2).  One row of every gate carries a valid witness, the rest is NoopGate padding: the gate-constraint kernel
+evaluates every gate of the set at every LDE point whatever sits in the rows, so the time is that of a full recursion circuit of
+the same size; the proof is verified.  The reference's one published number is for this shape: "about 170 ms" for a recursion
+proof (~2^12 rows) on a MacBook Pro (plonky2/README.md:5).
+usage: python tools/bench_recursion_shape.py [log_n ...]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from plonky2_goldibear_amd import GpuContext  # noqa: E402
+from plonky2_goldibear_amd.circuit_builder import NoopGate  # noqa: E402
+from circuits import recursion_gates_circuit  # noqa: E402
+
+
+def main():
+    ctx = GpuContext(0)
+    ctx.set_profiling(True)
+    for log_n in [int(a) for a in sys.argv[1:]] or [12, 13, 14]:
+        b, pw, _ = recursion_gates_circuit(seed=log_n)
+        while b.num_gates() < (1 << log_n) - 8:
+            b.add_gate(NoopGate())
+        c = b.build(ctx)
+        assert c.degree_bits == log_n, c.degree_bits
+        w, pis = c.generate_witness(pw)
+        proof = c.data.prove(w, pis)
+        assert c.data.verify(proof)
+        import torch
+        wd = torch.from_numpy(w.view(np.int64)).to("cuda:0")
+        for _ in range(3):
+            c.data.prove(wd, pis)
+        ctx.scope_reset()
+        ts = []
+        for _ in range(20):
+            ctx.synchronize()
+            t = time.perf_counter()
+            c.data.prove(wd, pis)
+            ts.append(time.perf_counter() - t)
+        scopes = {}
+        for name in ("compute wires commitment", "compute partial products", "compute quotient polys", "construct the opening set",
+                     "compute opening proofs", "find proof-of-work witness", "build Merkle tree", "IFFT", "FFT + blinding"):
+            ms, cnt = ctx.scope_ms(name)
+            scopes[name] = round(ms / 20, 3)
+        print(json.dumps({"workload": "recursion-shaped circuit, %d gates in the set" % len(c.gate_table), "log_n": log_n,
+                          "prove_ms_median": round(1e3 * float(np.median(ts)), 3), "prove_ms_min": round(1e3 * min(ts), 3),
+                          "proofs_per_s": round(1.0 / float(np.median(ts)), 1), "proof_bytes": len(proof), "verified": True,
+                          "scopes_ms_per_proof": scopes}), flush=True)
+        c.data.free()
+
+
+if __name__ == "__main__":
+    main()
