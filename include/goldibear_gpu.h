@@ -147,7 +147,7 @@ gb_status gb_circuit_free(gb_circuit* c);
  * (gates/public_input.rs), ArithmeticGate{param = num_ops} (gates/arithmetic_base.rs) and the in-circuit hash of the field's
  * configuration - PoseidonGate for Goldilocks (gates/poseidon_goldilocks.rs), Poseidon2BabyBearGate{param = num_ops} for
  * BabyBear (gates/poseidon2_babybear.rs) - which build() needs for any circuit with public inputs (circuit_builder.rs:1126-1137);
- * and the remaining gates of the recursion circuits listed below; any other kind (lookups, AddMany, ApplyMat4, ...) is
+ * and the remaining gates of the recursion circuits listed below; any other kind (LookupGate, LookupTableGate) is
  * GB_ERR_UNSUPPORTED.  cfg->num_selectors = selectors_info.groups.len(),
  * cfg->num_constants = the constant columns after the selectors (max over the gates' num_constants()); cfg->gate_constant and
  * cfg->gate_pi are ignored.  constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits]. */
@@ -169,6 +169,9 @@ gb_status gb_circuit_free(gb_circuit* c);
 #define GB_GATE_COSET_INTERPOLATION 13 /* gates/coset_interpolation.rs    param = subgroup_bits (<= 4), param2 = degree; the
                                           barycentric weights are x_i / 2^subgroup_bits and are not passed */
 #define GB_GATE_EXPONENTIATION 14      /* gates/exponentiation.rs         param = num_power_bits */
+#define GB_GATE_ADD_MANY 15            /* gates/add_many.rs               param = num_addends, param2 = num_ops */
+#define GB_GATE_APPLY_MAT4 16          /* gates/apply_mat4.rs             param = num_ops */
+#define GB_GATE_POSEIDON2_INTERNAL_PERMUTATION 17 /* gates/poseidon2_internal_permutation.rs (BabyBear) */
 typedef struct gb_gate {
     uint32_t kind;            /* GB_GATE_* */
     uint32_t param;           /* ConstantGate num_consts / ArithmeticGate, Poseidon2BabyBearGate num_ops; see above; 0 otherwise */

@@ -4,7 +4,8 @@ Test infrastructure only.  Follows eval_unfiltered of (paths relative to /root/r
   noop.rs, constant.rs:64-72, public_input.rs:52-60, arithmetic_base.rs:83-100, poseidon_goldilocks.rs:124-221,
   poseidon2_babybear.rs:203-313, arithmetic_extension.rs:82-100, multiplication_extension.rs:77-94, base_sum.rs:77-93,
   reducing.rs:89-115, reducing_extension.rs:95-120, random_access.rs:150-200, poseidon_goldilocks_mds.rs:152-180,
-  coset_interpolation.rs:216-268 (+ partial_interpolate_ext_algebra :637-664), exponentiation.rs:99-135
+  coset_interpolation.rs:216-268 (+ partial_interpolate_ext_algebra :637-664), exponentiation.rs:99-135, add_many.rs:80-90,
+  apply_mat4.rs:80-108, poseidon2_internal_permutation.rs:75-112
 and compute_filter (gate.rs:391-404).  `e` is a Field of oracle/fields.py; extension elements are tuples.
 A gate is the tuple the C oracle and the product ABI use: (kind, param, selector_index, group_start, group_end[, param2,
 param3]); param2/param3 only for BaseSumGate (base B), RandomAccessGate (num_copies, num_extra_constants) and
@@ -21,6 +22,7 @@ import re
 NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, POSEIDON, POSEIDON2_BABYBEAR = 0, 1, 2, 3, 4, 5
 ARITHMETIC_EXTENSION, MUL_EXTENSION, BASE_SUM, REDUCING, REDUCING_EXTENSION = 6, 7, 8, 9, 10
 RANDOM_ACCESS, POSEIDON_MDS, COSET_INTERPOLATION, EXPONENTIATION = 11, 12, 13, 14
+ADD_MANY, APPLY_MAT4, POSEIDON2_INTERNAL_PERMUTATION = 15, 16, 17
 UNUSED_SELECTOR = 0xFFFFFFFF  # selectors.rs:13
 POSEIDON_NUM_CONSTRAINTS = 12 * 7 + 22 + 12 + 1 + 4
 POSEIDON2_BB_CONSTRAINTS_PER_OP = 1 + 8 + 16 * 7 + 13 + 16
@@ -54,7 +56,10 @@ def num_constraints(gate, hout, D=2):
         return (param + 2) * _p(gate, 5) + _p(gate, 6)
     if kind == COSET_INTERPOLATION:
         return 2 * D + 2 * D * num_intermediates(gate)
-    return {NOOP: 0, CONSTANT: param, PUBLIC_INPUT: hout, ARITHMETIC: param, POSEIDON: POSEIDON_NUM_CONSTRAINTS,
+    if kind == ADD_MANY:
+        return _p(gate, 5)
+    return {APPLY_MAT4: 4 * D * param, POSEIDON2_INTERNAL_PERMUTATION: 16 * D,
+            NOOP: 0, CONSTANT: param, PUBLIC_INPUT: hout, ARITHMETIC: param, POSEIDON: POSEIDON_NUM_CONSTRAINTS,
             POSEIDON2_BABYBEAR: POSEIDON2_BB_CONSTRAINTS_PER_OP * param, ARITHMETIC_EXTENSION: D * param,
             MUL_EXTENSION: D * param, BASE_SUM: 1 + param, REDUCING: D * param, REDUCING_EXTENSION: D * param,
             POSEIDON_MDS: 12 * D, EXPONENTIATION: param + 1}[kind]
@@ -79,7 +84,8 @@ def gate_degree(gate):
     kind = gate[0]
     return {NOOP: 0, CONSTANT: 1, PUBLIC_INPUT: 1, ARITHMETIC: 3, POSEIDON: 7, POSEIDON2_BABYBEAR: 7, ARITHMETIC_EXTENSION: 3,
             MUL_EXTENSION: 3, BASE_SUM: _p(gate, 5, 2), REDUCING: 2, REDUCING_EXTENSION: 2, RANDOM_ACCESS: gate[1] + 1,
-            POSEIDON_MDS: 1, COSET_INTERPOLATION: _p(gate, 5), EXPONENTIATION: 4}[kind]
+            POSEIDON_MDS: 1, COSET_INTERPOLATION: _p(gate, 5), EXPONENTIATION: 4, ADD_MANY: 1, APPLY_MAT4: 1,
+            POSEIDON2_INTERNAL_PERMUTATION: 1}[kind]
 
 
 def barycentric_weights(e, subgroup_bits):
@@ -418,6 +424,45 @@ def _exponentiation(e, w, nbits):
     return out
 
 
+def _add_many(e, w, num_addends, num_ops):
+    out = []
+    for i in range(num_ops):
+        base, acc = (num_addends + 1) * i, e.zero
+        for j in range(num_addends):
+            acc = e.eadd(acc, w[base + j])
+        out.append(e.esub(acc, w[base + num_addends]))
+    return out
+
+
+def _apply_mat4(e, w, num_ops):
+    D, out = e.D, []
+    for op in range(num_ops):
+        x = [_alg(w, op * 8 * D + i * D, D) for i in range(4)]
+        t01, t23 = _alg_add(e, x[0], x[1]), _alg_add(e, x[2], x[3])
+        t0123 = _alg_add(e, t01, t23)
+        t01123, t01233 = _alg_add(e, t0123, x[1]), _alg_add(e, t0123, x[3])
+        new = [_alg_add(e, t01123, t01), _alg_add(e, t01123, _alg_add(e, x[2], x[2])), _alg_add(e, t01233, t23),
+               _alg_add(e, t01233, _alg_add(e, x[0], x[0]))]
+        for i in range(4):
+            out += _alg_sub(e, _alg(w, op * 8 * D + (4 + i) * D, D), new[i])
+    return out
+
+
+def _poseidon2_internal_permutation(e, w):
+    D = e.D
+    shifts = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15]
+    s = [[e.escale(x, 943718400) for x in _alg(w, i * D, D)] for i in range(16)]
+    part = [e.zero] * D
+    for x in s[1:]:
+        part = _alg_add(e, part, x)
+    full = _alg_add(e, part, s[0])
+    new = [_alg_sub(e, part, s[0])] + [_alg_add(e, full, [e.escale(x, 1 << shifts[i]) for x in s[i + 1]]) for i in range(15)]
+    out = []
+    for i in range(16):
+        out += _alg_sub(e, _alg(w, (16 + i) * D, D), new[i])
+    return out
+
+
 def eval_unfiltered(e, gate, wires, consts, pi_hash):
     """consts = local_constants after the selectors (vars.remove_prefix, gate.rs:165-186)"""
     kind, param = gate[0], gate[1]
@@ -456,4 +501,11 @@ def eval_unfiltered(e, gate, wires, consts, pi_hash):
         return _coset_interpolation(e, wires, param, _p(gate, 5))
     if kind == EXPONENTIATION:
         return _exponentiation(e, wires, param)
+    if kind == ADD_MANY:
+        return _add_many(e, wires, param, _p(gate, 5))
+    if kind == APPLY_MAT4:
+        return _apply_mat4(e, wires, param)
+    if kind == POSEIDON2_INTERNAL_PERMUTATION:
+        assert e.name == "babybear", "Poseidon2InternalPermutationGate is the BabyBear gate"
+        return _poseidon2_internal_permutation(e, wires)
     raise ValueError("gate kind %r" % (kind,))

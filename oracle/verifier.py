@@ -168,8 +168,14 @@ def read_gates(data, cd, F=GL):
         elif tag == 16:
             kind = G.POSEIDON2_BABYBEAR  # num_ops from the config (gates/poseidon2_babybear.rs:65-68)
             p1 = min(cd["config"]["num_wires"] // 166, cd["config"]["num_routed_wires"] // 33)
+        elif tag == 17:
+            kind, p1, p2 = G.ADD_MANY, r.usize(), r.usize()
+        elif tag == 18:
+            kind, p1 = G.APPLY_MAT4, r.usize()
+        elif tag == 19:
+            kind = G.POSEIDON2_INTERNAL_PERMUTATION
         else:
-            raise ValueError("gate tag %d (lookup gates / AddMany / ApplyMat4 / Poseidon2 internal) is not restated" % tag)
+            raise ValueError("gate tag %d (LookupGate / LookupTableGate) is not restated" % tag)
         si = sel["selector_indices"][row]
         gs, ge = sel["groups"][si]
         out.append((kind, p1, si, gs, ge, p2, p3))

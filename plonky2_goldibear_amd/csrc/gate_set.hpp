@@ -5,7 +5,7 @@
 namespace gbk {
 namespace gates {
 
-constexpr unsigned MAX_GATES = 16;
+constexpr unsigned MAX_GATES = 24;  // DefaultGateSerializer knows 20 gate types (util/serialization/gate_serialization.rs:143-165)
 constexpr unsigned UNUSED_SELECTOR = 0xFFFFFFFFu;  // gates/selectors.rs:13
 constexpr unsigned POSEIDON_NUM_CONSTRAINTS = 12 * 7 + 22 + 12 + 1 + 4;
 constexpr unsigned POSEIDON2_BB_CONSTRAINTS_PER_OP = 1 + 8 + 16 * 7 + 13 + 16;  // 150

@@ -20,6 +20,9 @@
 //   PoseidonMdsGate (GL)     gates/poseidon_goldilocks_mds.rs:152-180 out_r - MDS row r on D-tuples
 //   CosetInterpolationGate   gates/coset_interpolation.rs:216-268     shifted point, the intermediate (eval, prod) pairs, the value
 //   ExponentiationGate       gates/exponentiation.rs:99-135           square-and-multiply chain, output
+//   AddManyGate              gates/add_many.rs:80-90                  sum of the addends - sum wire, per operation
+//   ApplyMat4Gate            gates/apply_mat4.rs:80-108               out_i - (the Poseidon2 4x4 matrix on four D-tuples)_i
+//   Poseidon2InternalPermutationGate (BB)  gates/poseidon2_internal_permutation.rs:75-112  out_i - (M_I on sixteen D-tuples)_i
 // A D-tuple of consecutive wires is an element of the extension FIELD on the prover's LDE points (base-field wires) and of the
 // extension ALGEBRA F_ext[x]/(x^D - W) at the verifier's zeta (vars.get_local_ext / get_local_ext_algebra, plonk/vars.rs); Tup<>
 // below is written over the algebra A and is both.
@@ -54,6 +57,9 @@ GB_HD u32 num_constraints(const gb_gate& g) {
         case GB_GATE_POSEIDON_MDS: return 12 * D;
         case GB_GATE_COSET_INTERPOLATION: return 2 * D + 2 * D * interpolation_intermediates(g);
         case GB_GATE_EXPONENTIATION: return g.param + 1;
+        case GB_GATE_ADD_MANY: return g.param2;
+        case GB_GATE_APPLY_MAT4: return 4 * D * g.param;
+        case GB_GATE_POSEIDON2_INTERNAL_PERMUTATION: return 16 * D;
         default: return 0;
     }
 }
@@ -75,6 +81,9 @@ GB_HD u32 num_wires(const gb_gate& g) {
         case GB_GATE_POSEIDON_MDS: return 24 * D;
         case GB_GATE_COSET_INTERPOLATION: return 1 + (D << g.param) + 2 * D + D * (2 * interpolation_intermediates(g) + 1);
         case GB_GATE_EXPONENTIATION: return 2 + 2 * g.param;
+        case GB_GATE_ADD_MANY: return (g.param + 1) * g.param2;
+        case GB_GATE_APPLY_MAT4: return 8 * D * g.param;
+        case GB_GATE_POSEIDON2_INTERNAL_PERMUTATION: return 32 * D;
         default: return 0;
     }
 }
@@ -564,6 +573,50 @@ GB_HD void eval_exponentiation(u32 nbits, W&& wire, Emit&& emit) {
     emit(A::sub(wire(1 + nbits), wire(2 + nbits + nbits - 1)));
 }
 
+template <class F, class A, class W, class Emit>
+GB_HD void eval_add_many(u32 num_addends, u32 num_ops, W&& wire, Emit&& emit) {
+    typedef typename A::V V;
+    for (u32 i = 0; i < num_ops; i++) {
+        const u32 base = (num_addends + 1) * i;
+        V sum = A::cst(F::zero());
+        for (u32 j = 0; j < num_addends; j++) sum = A::add(sum, wire(base + j));
+        emit(A::sub(sum, wire(base + num_addends)));
+    }
+}
+
+// the 4x4 MDS block of Poseidon2's external layer ([[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]) on four D-tuples
+template <class F, class A, class W, class Emit>
+GB_HD void eval_apply_mat4(u32 num_ops, W&& wire, Emit&& emit) {
+    typedef Tup<F, A> X;
+    constexpr u32 D = F::D;
+    for (u32 op = 0; op < num_ops; op++) {
+        const u32 base = op * 8 * D;
+        const X x0 = X::load(wire, base), x1 = X::load(wire, base + D), x2 = X::load(wire, base + 2 * D), x3 = X::load(wire, base + 3 * D);
+        const X t01 = x0 + x1, t23 = x2 + x3, t0123 = t01 + t23, t01123 = t0123 + x1, t01233 = t0123 + x3;
+        (X::load(wire, base + 4 * D) - (t01123 + t01)).emit_all(emit);
+        (X::load(wire, base + 5 * D) - (t01123 + (x2 + x2))).emit_all(emit);
+        (X::load(wire, base + 6 * D) - (t01233 + t23)).emit_all(emit);
+        (X::load(wire, base + 7 * D) - (t01233 + (x0 + x0))).emit_all(emit);
+    }
+}
+
+// Poseidon2's internal linear layer M_I (hash/poseidon2_babybear.rs: 2^-32, then diag + all-ones) on sixteen D-tuples
+template <class F, class A, class W, class Emit>
+GB_HD void eval_poseidon2_internal_permutation(W&& wire, Emit&& emit) {
+    typedef Tup<F, A> X;
+    constexpr u32 D = F::D;
+    constexpr u32 SHIFTS[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};
+    const typename F::T k = F::enc(943718400u);
+    X part = X::zero();
+#pragma unroll 1
+    for (u32 i = 1; i < 16; i++) part = part + X::load(wire, i * D).scalar_c(k);
+    const X s0 = X::load(wire, 0).scalar_c(k), full = part + s0;
+    (X::load(wire, 16 * D) - (part - s0)).emit_all(emit);
+#pragma unroll 1
+    for (u32 i = 0; i < 15; i++)
+        (X::load(wire, (17 + i) * D) - (full + X::load(wire, (i + 1) * D).scalar_c(F::mul(k, F::enc((u64)1 << SHIFTS[i]))))).emit_all(emit);
+}
+
 // wire(col) / konst(i) give the opened (or LDE) value of a wire / of the i-th constant after the selectors
 template <class F, class A, class W, class K, class Emit>
 GB_HD void eval_gate(const GateSet& gs, const gb_gate& g, W&& wire, K&& konst, const typename F::T* pi_hash, Emit&& emit) {
@@ -600,6 +653,11 @@ GB_HD void eval_gate(const GateSet& gs, const gb_gate& g, W&& wire, K&& konst, c
             break;
         case GB_GATE_COSET_INTERPOLATION: eval_coset_interpolation<F, A>(gs, g, wire, emit); break;
         case GB_GATE_EXPONENTIATION: eval_exponentiation<F, A>(g.param, wire, emit); break;
+        case GB_GATE_ADD_MANY: eval_add_many<F, A>(g.param, g.param2, wire, emit); break;
+        case GB_GATE_APPLY_MAT4: eval_apply_mat4<F, A>(g.param, wire, emit); break;
+        case GB_GATE_POSEIDON2_INTERNAL_PERMUTATION:
+            if constexpr (F::TAG == 1) eval_poseidon2_internal_permutation<F, A>(wire, emit);
+            break;
         default:
             break;
     }

@@ -5,7 +5,8 @@ and witness generators - for CircuitBuilder.add_gate():
     BaseSumGate<B>           gates/base_sum.rs                 ReducingGate       gates/reducing.rs
     ReducingExtensionGate    gates/reducing_extension.rs       RandomAccessGate   gates/random_access.rs
     PoseidonMdsGate          gates/poseidon_goldilocks_mds.rs  CosetInterpolationGate  gates/coset_interpolation.rs
-    ExponentiationGate       gates/exponentiation.rs
+    ExponentiationGate       gates/exponentiation.rs           AddManyGate        gates/add_many.rs
+    ApplyMat4Gate            gates/apply_mat4.rs               Poseidon2InternalPermutationGate  gates/poseidon2_internal_permutation.rs
 
 The constraint evaluators are in csrc/gates.hpp (one source for the quotient kernel and gb_verify); what is here is what a
 Rust host already has: the layouts and the SimpleGenerators that fill a row's dependent wires from its inputs.  A row is used
@@ -16,7 +17,8 @@ from . import native as N
 from .circuit_builder import Gate, _poseidon_tables, wire
 
 (GATE_ARITHMETIC_EXTENSION, GATE_MUL_EXTENSION, GATE_BASE_SUM, GATE_REDUCING, GATE_REDUCING_EXTENSION, GATE_RANDOM_ACCESS,
- GATE_POSEIDON_MDS, GATE_COSET_INTERPOLATION, GATE_EXPONENTIATION) = range(6, 15)  # gb_gate.kind
+ GATE_POSEIDON_MDS, GATE_COSET_INTERPOLATION, GATE_EXPONENTIATION, GATE_ADD_MANY, GATE_APPLY_MAT4,
+ GATE_POSEIDON2_INTERNAL_PERMUTATION) = range(6, 18)  # gb_gate.kind
 
 _GL_NAME = "p3_goldilocks::goldilocks::Goldilocks"
 _BB_NAME = "p3_monty_31::monty_31::MontyField31<p3_baby_bear::baby_bear::BabyBearParameters>"
@@ -419,3 +421,103 @@ class _ExponentiationGenerator:
                 cur = cur * base % p
             w.set(wire(row, 2 + n + i), cur)
         w.set(wire(row, 1 + n), cur)
+
+
+# --------------------------------------------------------------------------------------------- the linear gates of the BabyBear recursion
+class AddManyGate(Gate):
+    """gates/add_many.rs:23-49: num_ops x (num_addends wires, then their sum)"""
+    kind, degree = GATE_ADD_MANY, 1
+
+    def __init__(self, num_addends, num_ops):
+        self.num_addends, self.num_ops = num_addends, num_ops
+        self.param, self.param2 = num_addends, num_ops
+        self.num_wires, self.num_constraints = (num_addends + 1) * num_ops, num_ops
+        self.id = "AddManyGate { num_addends: %d, num_ops: %d }" % (num_addends, num_ops)
+
+    @classmethod
+    def new_from_config(cls, cfg, num_addends):
+        return cls(num_addends, cfg.num_routed_wires // (num_addends + 1))
+
+    def generators(self, row, constants):
+        return [_AddManyGenerator(self, row, i) for i in range(self.num_ops)]
+
+
+class _AddManyGenerator:
+    """add_many.rs:167-215"""
+
+    def __init__(self, gate, row, i):
+        self.g, self.row, self.i = gate, row, i
+        self.deps = [wire(row, (gate.num_addends + 1) * i + j) for j in range(gate.num_addends)]
+
+    def run(self, w, p):
+        w.set(wire(self.row, (self.g.num_addends + 1) * self.i + self.g.num_addends), sum(w.get(t) for t in self.deps) % p)
+
+
+class ApplyMat4Gate(Gate):
+    """gates/apply_mat4.rs:26-50: num_ops x (four input D-tuples, four output D-tuples = the Poseidon2 4x4 block applied)"""
+    kind, degree = GATE_APPLY_MAT4, 1
+
+    def __init__(self, num_ops, field=N.GB_GOLDILOCKS):
+        E = self.E = Ext(field)
+        self.param = self.num_ops = num_ops
+        self.num_wires, self.num_constraints = 8 * E.D * num_ops, 4 * E.D * num_ops
+        self.id = "ApplyMat4Gate { num_ops: %d, _phantom: PhantomData<%s> } number of operations = %d" % (num_ops, E.name, num_ops)
+
+    @classmethod
+    def new_from_config(cls, cfg):
+        return cls(cfg.num_routed_wires // (8 * Ext(cfg.field).D), cfg.field)
+
+    def generators(self, row, constants):
+        return [_ApplyMat4Generator(self, row, op) for op in range(self.num_ops)]
+
+
+class _ApplyMat4Generator:
+    """apply_mat4.rs:216-270"""
+
+    def __init__(self, gate, row, op):
+        self.g, self.row, self.op = gate, row, op
+        self.deps = _ext_wires(row, op * 8 * gate.E.D, 4 * gate.E.D)
+
+    def run(self, w, p):
+        E, D = self.g.E, self.g.E.D
+        base = self.op * 8 * D
+        x = [_get_ext(w, self.row, base + i * D, D) for i in range(4)]
+        t01, t23 = E.add(x[0], x[1]), E.add(x[2], x[3])
+        t0123 = E.add(t01, t23)
+        t01123, t01233 = E.add(t0123, x[1]), E.add(t0123, x[3])
+        new = [E.add(t01123, t01), E.add(t01123, E.add(x[2], x[2])), E.add(t01233, t23), E.add(t01233, E.add(x[0], x[0]))]
+        for i in range(4):
+            _set_ext(w, self.row, base + (4 + i) * D, new[i])
+
+
+class Poseidon2InternalPermutationGate(Gate):
+    """gates/poseidon2_internal_permutation.rs:30-48: sixteen input D-tuples, sixteen output D-tuples = M_I applied (BabyBear)"""
+    kind, degree = GATE_POSEIDON2_INTERNAL_PERMUTATION, 1
+    SHIFTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15]
+    id = "Poseidon2InternalPermutationGate(PhantomData<%s>)<WIDTH=16>" % _BB_NAME
+
+    def __init__(self):
+        self.E = Ext(N.GB_BABYBEAR)
+        self.num_wires, self.num_constraints = 32 * self.E.D, 16 * self.E.D
+
+    def generators(self, row, constants):
+        return [_Poseidon2InternalGenerator(self, row)]
+
+
+class _Poseidon2InternalGenerator:
+    """poseidon2_internal_permutation.rs:225-290"""
+
+    def __init__(self, gate, row):
+        self.g, self.row = gate, row
+        self.deps = _ext_wires(row, 0, 16 * gate.E.D)
+
+    def run(self, w, p):
+        E, D = self.g.E, self.g.E.D
+        s = [E.scale(_get_ext(w, self.row, i * D, D), 943718400) for i in range(16)]
+        part = E.zero
+        for x in s[1:]:
+            part = E.add(part, x)
+        full = E.add(part, s[0])
+        new = [E.sub(part, s[0])] + [E.add(full, E.scale(s[i + 1], 1 << self.g.SHIFTS[i])) for i in range(15)]
+        for i in range(16):
+            _set_ext(w, self.row, (16 + i) * D, new[i])

@@ -140,6 +140,16 @@ def recursion_gates_circuit(field=N.GB_GOLDILOCKS, seed=1, public_inputs=True, *
     g = R.CosetInterpolationGate(4 if gl else 3, field, max_degree=6 if gl else 4)
     rows["coset_interpolation"] = r = b.add_gate(g)
     fill(r, [0] + list(range(1, 1 + g.num_points * D)) + list(range(g.start_point, g.start_point + D)))
+    g = R.AddManyGate.new_from_config(cfg, 7)
+    rows["add_many"] = r = b.add_gate(g)
+    fill(r, [8 * i + j for i in range(g.num_ops) for j in range(7)])
+    g = R.ApplyMat4Gate.new_from_config(cfg)
+    rows["apply_mat4"] = r = b.add_gate(g)
+    fill(r, [8 * D * op + k for op in range(g.num_ops) for k in range(4 * D)])
+    if not gl:
+        g = R.Poseidon2InternalPermutationGate()
+        rows["poseidon2_internal_permutation"] = r = b.add_gate(g)
+        fill(r, list(range(16 * D)))
     g = R.ExponentiationGate.new_from_config(cfg)
     rows["exponentiation"] = r = b.add_gate(g)
     fill(r, [0])

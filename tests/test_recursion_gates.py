@@ -34,7 +34,8 @@ def test_generated_witness_satisfies_every_gate(field):
     wires, pis = c.generate_witness(pw)
     kinds = {g[0] for g in c.gate_table}
     want = {G.ARITHMETIC_EXTENSION, G.MUL_EXTENSION, G.BASE_SUM, G.REDUCING, G.REDUCING_EXTENSION, G.RANDOM_ACCESS,
-            G.COSET_INTERPOLATION, G.EXPONENTIATION} | ({G.POSEIDON_MDS} if F is GL else set())
+            G.COSET_INTERPOLATION, G.EXPONENTIATION, G.ADD_MANY, G.APPLY_MAT4} | (
+        {G.POSEIDON_MDS} if F is GL else {G.POSEIDON2_INTERNAL_PERMUTATION})
     assert want <= kinds
     seen = set()
     for row in range(1 << c.degree_bits):
