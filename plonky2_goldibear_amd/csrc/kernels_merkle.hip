@@ -7,6 +7,7 @@
 // 4 x u64 per digest.  The reference's interleaved layout is produced on request only.
 #include "kernels.hpp"
 #include "poseidon_gl.hpp"
+#include "poseidon_gl_coop.hpp"
 
 namespace gbk {
 
@@ -54,6 +55,52 @@ __global__ __launch_bounds__(256) void k_gl_merkle_level(const u64* __restrict__
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
     o[0] = make_ulonglong2(to_canonical(s[0]), to_canonical(s[1]));
     o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
+}
+
+// The same two kernels with one state per 16-lane row (poseidon_gl_coop.hpp), for trees too small to fill the machine with
+// one permutation per lane.  Blocks are one wave = four states; nothing returns before the last __syncthreads().
+__global__ __launch_bounds__(64) void k_gl_merkle_level_coop(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
+    __shared__ u64 sh[64];
+    const u32 l = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const u64 node = (u64)blockIdx.x * 4 + row;
+    const bool valid = node < num_out;
+    u64 x = l < 8 ? in[8 * (valid ? node : 0) + l] : 0;
+    x = poseidon_gl_coop::permute(x, l, sh + 16 * row);
+    if (valid && l < 4) out[4 * node + l] = gl::canon(x);
+}
+// width > 4 (narrower leaves are not hashed, plonk/config.rs:70-84)
+__global__ __launch_bounds__(64) void k_gl_merkle_leaves_coop(const u64* __restrict__ cols, size_t col_stride, u32 width,
+                                                              u64 num_leaves, u64* __restrict__ out) {
+    __shared__ u64 sh[64];
+    const u32 l = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const u64 leaf = (u64)blockIdx.x * 4 + row;
+    const bool valid = leaf < num_leaves;
+    const u64 j = valid ? leaf : 0;
+    u64 x = 0;
+    for (u32 c0 = 0; c0 < width; c0 += 8) {
+        if (l < 8 && c0 + l < width) x = cols[(size_t)(c0 + l) * col_stride + j];  // overwrite-mode absorption
+        x = poseidon_gl_coop::permute(x, l, sh + 16 * row);
+    }
+    if (valid && l < 4) out[4 * leaf + l] = gl::canon(x);
+}
+
+// FRI layer leaves (fri/prover.rs:101-107): leaf m = the 2^arity_bits extension values of coset m, flattened (D = 2);
+// vals = [2][len] coordinate columns in leaf order.  2 * arity > 4 only (narrower leaves are not hashed).
+__global__ __launch_bounds__(64) void k_gl_fri_leaves_coop(const u64* __restrict__ vals, size_t len, u32 arity_bits, u64 num_leaves,
+                                                           u64* __restrict__ out) {
+    __shared__ u64 sh[64];
+    const u32 l = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const u64 leaf = (u64)blockIdx.x * 4 + row;
+    const bool valid = leaf < num_leaves;
+    const u64* a = vals + ((valid ? leaf : 0) << arity_bits);
+    const u32 arity = 1u << arity_bits;
+    u64 x = 0;
+    for (u32 k0 = 0; k0 < arity; k0 += 4) {   // four extension elements = eight base elements per absorption
+        const u32 k = k0 + (l >> 1);
+        if (l < 8 && k < arity) x = a[(size_t)(l & 1) * len + k];
+        x = poseidon_gl_coop::permute(x, l, sh + 16 * row);
+    }
+    if (valid && l < 4) out[4 * leaf + l] = gl::canon(x);
 }
 
 // Level k node t (t < N>>k) sits, in the reference layout, inside subtree s = t >> (layers-k) at
@@ -126,11 +173,29 @@ __global__ __launch_bounds__(256) void k_gl_poseidon_permute(const u64* __restri
 
 static inline u32 blocks_for(u64 n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 
+// Below this many states a lone wave's ~56 us per lane-per-state permutation dominates; the cooperative form does ~3.6x the
+// instructions in total but its dependent chain is ~4x shorter (crossover near 2^14 states on 1024 SIMDs).
+static constexpr u64 COOP_MAX_STATES = 8192;
+
 void gl_merkle_leaves(const u64* cols, size_t col_stride, u32 width, u64 num_leaves, u64* out, hipStream_t stream) {
+    if (width > 4 && num_leaves <= COOP_MAX_STATES) {
+        hipLaunchKernelGGL(k_gl_merkle_leaves_coop, dim3(blocks_for(num_leaves, 4)), dim3(64), 0, stream, cols, col_stride, width,
+                           num_leaves, out);
+        return;
+    }
     hipLaunchKernelGGL(k_gl_merkle_leaves, dim3(blocks_for(num_leaves, 256)), dim3(256), 0, stream, cols, col_stride,
                        width, num_leaves, out);
 }
+bool gl_fri_leaves_coop(const u64* vals, size_t len, u32 arity_bits, u64 num_leaves, u64* out, hipStream_t stream) {
+    if (num_leaves > COOP_MAX_STATES || (2u << arity_bits) <= 4) return false;
+    hipLaunchKernelGGL(k_gl_fri_leaves_coop, dim3(blocks_for(num_leaves, 4)), dim3(64), 0, stream, vals, len, arity_bits, num_leaves, out);
+    return true;
+}
 void gl_merkle_level(const u64* in, u64* out, u64 num_out, hipStream_t stream) {
+    if (num_out <= COOP_MAX_STATES) {
+        hipLaunchKernelGGL(k_gl_merkle_level_coop, dim3(blocks_for(num_out, 4)), dim3(64), 0, stream, in, out, num_out);
+        return;
+    }
     hipLaunchKernelGGL(k_gl_merkle_level, dim3(blocks_for(num_out, 256)), dim3(256), 0, stream, in, out, num_out);
 }
 void gl_digests_to_reference_layout(const u64* levels, u64* out, u32 log_leaves, u32 cap_height, hipStream_t stream) {
