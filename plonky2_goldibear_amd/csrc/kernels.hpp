@@ -49,6 +49,7 @@ void gl_merkle_leaves(const u64* cols, size_t col_stride, u32 width, u64 num_lea
 void gl_merkle_level(const u64* in, u64* out, u64 num_out, hipStream_t stream);
 // one state per 16-lane row for small trees; false = not applicable (caller uses the lane-per-leaf kernel)
 bool gl_fri_leaves_coop(const u64* vals, size_t len, u32 arity_bits, u64 num_leaves, u64* out, hipStream_t stream);
+bool bb_fri_leaves_coop(const u32* vals, size_t len, u32 arity_bits, u64 num_leaves, u32* out, hipStream_t stream);
 // level-major digests -> the reference's interleaved layout (hash/merkle_tree.rs:50-58)
 void gl_digests_to_reference_layout(const u64* levels, u64* out, u32 log_leaves, u32 cap_height, hipStream_t stream);
 // gather one row (width elements at stride col_stride) into dst[0..width)

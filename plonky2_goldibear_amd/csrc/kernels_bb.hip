@@ -7,6 +7,7 @@
 // Device-resident element data is in Montgomery form; digests are canonical.
 #include "kernels.hpp"
 #include "poseidon2_bb.hpp"
+#include "poseidon2_bb_coop.hpp"
 
 namespace gbk {
 
@@ -240,6 +241,46 @@ __global__ __launch_bounds__(256) void k_bb_merkle_level(const u32* __restrict__
     o[0] = make_uint4(canonical_out(s[0]), canonical_out(s[1]), canonical_out(s[2]), canonical_out(s[3]));
     o[1] = make_uint4(canonical_out(s[4]), canonical_out(s[5]), canonical_out(s[6]), canonical_out(s[7]));
 }
+// The same two kernels (and the FRI layer leaves) with one state per 16-lane row (poseidon2_bb_coop.hpp) for small trees.
+__global__ __launch_bounds__(64) void k_bb_merkle_level_coop(const u32* __restrict__ in, u32* __restrict__ out, u64 num_out) {
+    const u32 l = threadIdx.x & 15;
+    const u64 node = (u64)blockIdx.x * 4 + (threadIdx.x >> 4);
+    const bool valid = node < num_out;
+    u32 x = bb::to_mont(in[16 * (valid ? node : 0) + l]);
+    x = poseidon2_bb_coop::permute(x, l);
+    if (valid && l < 8) out[8 * node + l] = bb::from_mont(x);
+}
+// width > 8 (narrower leaves are not hashed, plonk/config.rs:70-84); cols in Montgomery form
+__global__ __launch_bounds__(64) void k_bb_merkle_leaves_coop(const u32* __restrict__ cols, size_t col_stride, u32 width,
+                                                              u64 num_leaves, u32* __restrict__ out) {
+    const u32 l = threadIdx.x & 15;
+    const u64 leaf = (u64)blockIdx.x * 4 + (threadIdx.x >> 4);
+    const bool valid = leaf < num_leaves;
+    const u64 j = valid ? leaf : 0;
+    u32 x = 0;
+    for (u32 c0 = 0; c0 < width; c0 += 8) {
+        if (l < 8 && c0 + l < width) x = cols[(size_t)(c0 + l) * col_stride + j];  // overwrite-mode absorption
+        x = poseidon2_bb_coop::permute(x, l);
+    }
+    if (valid && l < 8) out[8 * leaf + l] = bb::from_mont(x);
+}
+// FRI layer leaves (fri/prover.rs:101-107), D = 4: vals = [4][len] coordinate columns (Montgomery), 4 * arity > 8 only
+__global__ __launch_bounds__(64) void k_bb_fri_leaves_coop(const u32* __restrict__ vals, size_t len, u32 arity_bits, u64 num_leaves,
+                                                           u32* __restrict__ out) {
+    const u32 l = threadIdx.x & 15;
+    const u64 leaf = (u64)blockIdx.x * 4 + (threadIdx.x >> 4);
+    const bool valid = leaf < num_leaves;
+    const u32* a = vals + ((valid ? leaf : 0) << arity_bits);
+    const u32 arity = 1u << arity_bits;
+    u32 x = 0;
+    for (u32 k0 = 0; k0 < arity; k0 += 2) {   // two extension elements = eight base elements per absorption
+        const u32 k = k0 + (l >> 2);
+        if (l < 8 && k < arity) x = a[(size_t)(l & 3) * len + k];
+        x = poseidon2_bb_coop::permute(x, l);
+    }
+    if (valid && l < 8) out[8 * leaf + l] = bb::from_mont(x);
+}
+
 __global__ __launch_bounds__(256) void k_bb_permute(const u32* __restrict__ in, u32* __restrict__ out, u64 count) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -320,10 +361,26 @@ void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables
                            t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
     bb_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
 }
+// as for Goldilocks (kernels_merkle.hip): below this many states the lane-per-state kernels are latency-bound
+static constexpr u64 BB_COOP_MAX_STATES = 16384;
+
 void bb_merkle_leaves(const u32* cols, size_t col_stride, u32 width, u64 num_leaves, u32* out, hipStream_t stream) {
+    if (width > 8 && num_leaves <= BB_COOP_MAX_STATES) {
+        hipLaunchKernelGGL(k_bb_merkle_leaves_coop, dim3(nblk(num_leaves, 4)), dim3(64), 0, stream, cols, col_stride, width, num_leaves, out);
+        return;
+    }
     hipLaunchKernelGGL(k_bb_merkle_leaves, dim3(nblk(num_leaves, 256)), dim3(256), 0, stream, cols, col_stride, width, num_leaves, out);
 }
+bool bb_fri_leaves_coop(const u32* vals, size_t len, u32 arity_bits, u64 num_leaves, u32* out, hipStream_t stream) {
+    if (num_leaves > BB_COOP_MAX_STATES || (4u << arity_bits) <= 8) return false;
+    hipLaunchKernelGGL(k_bb_fri_leaves_coop, dim3(nblk(num_leaves, 4)), dim3(64), 0, stream, vals, len, arity_bits, num_leaves, out);
+    return true;
+}
 void bb_merkle_level(const u32* in, u32* out, u64 num_out, hipStream_t stream) {
+    if (num_out <= BB_COOP_MAX_STATES) {
+        hipLaunchKernelGGL(k_bb_merkle_level_coop, dim3(nblk(num_out, 4)), dim3(64), 0, stream, in, out, num_out);
+        return;
+    }
     hipLaunchKernelGGL(k_bb_merkle_level, dim3(nblk(num_out, 256)), dim3(256), 0, stream, in, out, num_out);
 }
 void bb_poseidon2_permute(const u32* in, u32* out, u64 count, hipStream_t stream) {

@@ -726,6 +726,8 @@ template <class F>
 void fri_leaves(const typename F::T* vals, size_t len, u32 arity_bits, u64 num_leaves, typename F::T* out, hipStream_t st) {
     if constexpr (F::TAG == 0)   // small trees: one state per 16-lane row (poseidon_gl_coop.hpp)
         if (gl_fri_leaves_coop(vals, len, arity_bits, num_leaves, out, st)) return;
+    if constexpr (F::TAG == 1)
+        if (bb_fri_leaves_coop(vals, len, arity_bits, num_leaves, out, st)) return;
     hipLaunchKernelGGL(k_fri_leaves<F>, dim3(nblk(num_leaves, 256)), dim3(256), 0, st, vals, len, arity_bits, num_leaves, out);
 }
 
