@@ -263,9 +263,10 @@ def main():
         achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
         # physical HBM bytes per column, measured with rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/*.json)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01d_ntt_traffic_pmc_%s.json" % args.field)
-        if log_n == 20 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ntt_traffic_pmc_%s.json" % args.field)))  # newest round last
+        if log_n == 20 and tpaths:
+            tj = json.load(open(tpaths[-1]))
             if args.workload == "prove":
                 traffic = tj["ifft_bytes_per_column"] * (nwires + nzs) + tj["lde_bytes_per_column"] * (nwires + nzs + nq + ext_d)
             else:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates profiles/r01d_* on an MI355X box (this is the command sequence that produced the committed files):
+# Regenerates profiles/r01e_* on an MI355X box (this is the command sequence that produced the committed files):
 #   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/make_profiles.sh'      then, locally:  bash tools/make_profiles.sh --summarise
 # rocprofv3 writes rocpd SQLite databases on this image; tools/rocpd_kernel_stats.py, tools/pmc_traffic.py and
 # tools/pmc_sq_summary.py turn them into the CSV / JSON summaries.  PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE
@@ -21,9 +21,9 @@ fi
 for F in goldilocks babybear; do
     COLS=$([ $F = babybear ] && echo 167 || echo 135)
     ES=$([ $F = babybear ] && echo 4 || echo 8)
-    python tools/rocpd_kernel_stats.py $OUT/prof_$F/p_results.db profiles/r01d_prove_${F}_2p20_kernel_stats.csv
-    python tools/pmc_traffic.py $OUT/pmc_${F}_f/f_results.db $OUT/pmc_${F}_w/w_results.db $COLS 20 $ES profiles/r01d_ntt_traffic_pmc_$F.json > /dev/null
-    python tools/pmc_sq_summary.py $OUT/pmc_${F}_sq/s_results.db profiles/r01d_commit_${F}_2p20_sq_counters.csv
-    grep '"metric"' $OUT/prof_$F.log > profiles/r01d_bench_prove_${F}_2p20.json
+    python tools/rocpd_kernel_stats.py $OUT/prof_$F/p_results.db profiles/r01e_prove_${F}_2p20_kernel_stats.csv
+    python tools/pmc_traffic.py $OUT/pmc_${F}_f/f_results.db $OUT/pmc_${F}_w/w_results.db $COLS 20 $ES profiles/r01e_ntt_traffic_pmc_$F.json > /dev/null
+    python tools/pmc_sq_summary.py $OUT/pmc_${F}_sq/s_results.db profiles/r01e_commit_${F}_2p20_sq_counters.csv
+    grep '"metric"' $OUT/prof_$F.log > profiles/r01e_bench_prove_${F}_2p20.json
 done
 ls -la profiles
