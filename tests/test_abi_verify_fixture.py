@@ -70,3 +70,17 @@ def test_wrong_salt_setting_is_malformed(golden_dir):
     circ, cd, raw = _fixture_circuit(golden_dir, zero_knowledge=False)
     with pytest.raises((N.ShapeError, VerifyError)):
         circ.verify(raw)
+
+
+def test_malformed_path_lengths_are_rejected_not_read(golden_dir):
+    """A Merkle path shorter than its tree's depth would leave an index beyond the cap (hash/merkle_proofs.rs:62-75 indexes the
+    cap with the remaining bits): the library refuses the bytes instead of reading past the cap."""
+    circ, cd, raw = _fixture_circuit(golden_dir)
+    proof, pis = V.read_proof_with_pis(raw, cd)
+    vals, path = proof["opening_proof"]["query_round_proofs"][3]["initial_trees_proof"][2]
+    proof["opening_proof"]["query_round_proofs"][3]["initial_trees_proof"][2] = (vals, path[:-2])
+    bad = V.write_proof_with_pis(proof, pis)
+    with pytest.raises(N.ShapeError, match="wrong length"):
+        circ.verify(bad)
+    with pytest.raises(N.ShapeError, match="wrong length"):
+        circ.compress(bad)
