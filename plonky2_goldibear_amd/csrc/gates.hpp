@@ -104,6 +104,7 @@ template <class F>
 struct BaseAlg {
     typedef typename F::T V;
     typedef typename F::T T;
+    static constexpr bool IS_GL_BASE = F::TAG == 0;  // base-field Goldilocks values: the device fast paths apply
     static GB_HD V add(V a, V b) { return F::add(a, b); }
     static GB_HD V sub(V a, V b) { return F::sub(a, b); }
     static GB_HD V mul(V a, V b) { return F::mul(a, b); }
@@ -115,6 +116,7 @@ template <class F>
 struct ExtAlg {
     typedef typename F::E V;
     typedef typename F::T T;
+    static constexpr bool IS_GL_BASE = false;
     static GB_HD V add(V a, V b) { return F::eadd(a, b); }
     static GB_HD V sub(V a, V b) { return F::esub(a, b); }
     static GB_HD V mul(V a, V b) { return F::emul(a, b); }
@@ -156,9 +158,46 @@ GB_HD typename A::V sbox7(typename A::V x) {  // sbox_monomial (hash/poseidon_go
     typename A::V x2 = A::mul(x, x), x4 = A::mul(x2, x2), x3 = A::mul(x, x2);
     return A::mul(x3, x4);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The MDS layer on base-field values in the quotient kernel: entries < 2^6, so each output is two 64-bit sums over the 32-bit
+// halves of the inputs and ONE reduction (the decomposition of the reference's mds_layer, hash/poseidon_goldilocks.rs:497-528) -
+// 24 v_mad_u64_u32 per output where twelve modular multiplications by small constants would be ~350 instructions.  Half of
+// PoseidonGate's multiplications are these.
+__device__ __forceinline__ void mds_layer_gl_base(u64 (&s)[12]) {
+    const PoseidonTab& t = poseidon_tab();
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (u32 i = 0; i < 12; i++) {
+        lo[i] = (u32)s[i];
+        hi[i] = (u32)(s[i] >> 32);
+    }
+#pragma unroll
+    for (u32 r = 0; r < 12; r++) {
+        u64 sl = (u64)lo[r] * (u32)t.diag[r], sh = (u64)hi[r] * (u32)t.diag[r];
+#pragma unroll
+        for (u32 i = 0; i < 12; i++) {
+            sl += (u64)lo[(i + r) % 12] * (u32)t.circ[i];
+            sh += (u64)hi[(i + r) % 12] * (u32)t.circ[i];
+        }
+        // sl + 2^32 sh with sh < 2^42: the bits of sh above 32 are worth EPS each (2^64 = EPS); one carry fix, then canonical
+        const u64 tt = sl + (sh >> 32) * gl::EPS;
+        u64 r2;
+        const bool cy = __builtin_uaddll_overflow(tt, sh << 32, &r2);
+        r2 += cy ? gl::EPS : 0;
+        s[r] = gl::canon(r2);
+    }
+}
+#endif
+
 template <class A>
 GB_HD void mds_layer(typename A::V (&s)[12]) {  // mds_layer_field (:584-592)
     typedef typename A::V V;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (A::IS_GL_BASE) {
+        mds_layer_gl_base(s);
+        return;
+    }
+#endif
     const PoseidonTab& t = poseidon_tab();
     V out[12];
 #pragma unroll
@@ -514,13 +553,15 @@ GB_HD void eval_poseidon_mds(W&& wire, Emit&& emit) {
     typedef Tup<F, A> X;
     constexpr u32 D = F::D;
     const PoseidonTab& t = poseidon_tab();
-    X in[12];
-#pragma unroll
-    for (u32 i = 0; i < 12; i++) in[i] = X::load(wire, i * D);
+    // the inputs are read where they are used (a degree-1 gate: twelve live D-tuples would only cost registers)
 #pragma unroll 1
     for (u32 r = 0; r < 12; r++) {
-        X res = in[r].scalar_c(F::enc(t.circ[0] + t.diag[r]));
-        for (u32 i = 1; i < 12; i++) res = res + in[(i + r) % 12].scalar_c(F::enc(t.circ[i]));
+        X res = X::load(wire, r * D).scalar_c(F::enc(t.circ[0] + t.diag[r]));
+#pragma unroll 1
+        for (u32 i = 1; i < 12; i++) {
+            const u32 j = r + i >= 12 ? r + i - 12 : r + i;
+            res = res + X::load(wire, j * D).scalar_c(F::enc(t.circ[i]));
+        }
         (X::load(wire, (12 + r) * D) - res).emit_all(emit);
     }
 }
@@ -618,9 +659,23 @@ GB_HD void eval_poseidon2_internal_permutation(W&& wire, Emit&& emit) {
 }
 
 // wire(col) / konst(i) give the opened (or LDE) value of a wire / of the i-th constant after the selectors
-template <class F, class A, class W, class K, class Emit>
+// The in-circuit hash gates carry the permutation's whole state through ~120 constraints (200+ VGPRs in the quotient kernel); the
+// other gates are short.  The kernel evaluates the two families in separate launches (SUBSET) so that the light ones are not
+// compiled - and run - at the heavy ones' register budget.
+enum GateSubset { ALL_GATES = 0, HEAVY_GATES = 1, LIGHT_GATES = 2 };
+GB_HD bool is_heavy(const gb_gate& g) { return g.kind == GB_GATE_POSEIDON || g.kind == GB_GATE_POSEIDON2_BABYBEAR; }
+
+template <class F, class A, int SUBSET = ALL_GATES, class W, class K, class Emit>
 GB_HD void eval_gate(const GateSet& gs, const gb_gate& g, W&& wire, K&& konst, const typename F::T* pi_hash, Emit&& emit) {
     typedef typename A::V V;
+    if constexpr (SUBSET == HEAVY_GATES) {
+        if (g.kind == GB_GATE_POSEIDON) {
+            if constexpr (F::TAG == 0) eval_poseidon<A>(wire, emit);
+        } else if (g.kind == GB_GATE_POSEIDON2_BABYBEAR) {
+            if constexpr (F::TAG == 1) eval_poseidon2_bb<F, A>(g.param, wire, emit);
+        }
+        return;
+    }
     switch (g.kind) {
         case GB_GATE_CONSTANT:
             for (u32 i = 0; i < g.param; i++) emit(A::sub(konst(i), wire(i)));
@@ -637,10 +692,10 @@ GB_HD void eval_gate(const GateSet& gs, const gb_gate& g, W&& wire, K&& konst, c
             break;
         }
         case GB_GATE_POSEIDON:
-            if constexpr (F::TAG == 0) eval_poseidon<A>(wire, emit);
+            if constexpr (F::TAG == 0 && SUBSET != LIGHT_GATES) eval_poseidon<A>(wire, emit);
             break;
         case GB_GATE_POSEIDON2_BABYBEAR:
-            if constexpr (F::TAG == 1) eval_poseidon2_bb<F, A>(g.param, wire, emit);
+            if constexpr (F::TAG == 1 && SUBSET != LIGHT_GATES) eval_poseidon2_bb<F, A>(g.param, wire, emit);
             break;
         case GB_GATE_ARITHMETIC_EXTENSION: eval_arithmetic_extension<F, A>(g.param, true, wire, konst, emit); break;
         case GB_GATE_MUL_EXTENSION: eval_arithmetic_extension<F, A>(g.param, false, wire, konst, emit); break;

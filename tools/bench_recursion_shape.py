@@ -1,6 +1,6 @@
 """Timing of prove() on a recursion-SHAPED circuit: the gate set of the reference's recursion circuits (the twelve gates of its
-RECURSIVE_VERIFIER_GL fixture plus Constant, Exponentiation and a second BaseSum) at 2^12..2^14 rows, standard_recursion_config_gl
-(num_challenges 2).  One row of every gate carries a valid witness, the rest is NoopGate padding: the gate-constraint kernel
+RECURSIVE_VERIFIER_GL fixture plus Constant, Exponentiation, AddMany, ApplyMat4 and a second BaseSum) at 2^12..2^14 rows,
+standard_recursion_config_gl (num_challenges 2; 3 above 2^14 rows).  One row of every gate carries a valid witness, the rest is NoopGate padding: the gate-constraint kernel
 evaluates every gate of the set at every LDE point whatever sits in the rows, so the time is that of a full recursion circuit of
 the same size; the proof is verified.  The reference's one published number is for this shape: "about 170 ms" for a recursion
 proof (~2^12 rows) on a MacBook Pro (plonky2/README.md:5).
@@ -23,7 +23,8 @@ def main():
     ctx = GpuContext(0)
     ctx.set_profiling(True)
     for log_n in [int(a) for a in sys.argv[1:]] or [12, 13, 14]:
-        b, pw, _ = recursion_gates_circuit(seed=log_n)
+        # circuit_builder.rs:1190-1192: (64 - degree_bits) * num_challenges >= 100 needs a third challenge above 2^14 rows
+        b, pw, _ = recursion_gates_circuit(seed=log_n, num_challenges=2 if log_n <= 14 else 3)
         while b.num_gates() < (1 << log_n) - 8:
             b.add_gate(NoopGate())
         c = b.build(ctx)
