@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--cols", type=int, default=135)
     ap.add_argument("--cpu-sample-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-witness", action="store_true",
+                    help="prove workload: hand the witness over as a HOST array every step (the drop-in boundary's case: 1.05 GiB "
+                         "across PCIe per Goldilocks proof); the default keeps it resident in HBM, which is what `value` is quoted on")
     args = ap.parse_args()
 
     import torch
@@ -159,7 +162,11 @@ def main():
             else:
                 circuit = CircuitData(lctx, log_n, cs_dev, k_is, num_challenges=args.challenges)
                 wit = DC.dummy_witness(log_n, pi_row, seed=rank * inflight + li)
-            lanes.append((lctx, circuit, torch.from_numpy(wit.view(idt)).to("cuda:%d" % local_rank)))
+            if args.host_witness:   # page-locked, as a host that wants the PCIe rate would allocate it (hipHostMalloc)
+                wit_in = torch.from_numpy(wit.view(idt)).pin_memory().numpy().view(wit.dtype)
+            else:
+                wit_in = torch.from_numpy(wit.view(idt)).to("cuda:%d" % local_rank)
+            lanes.append((lctx, circuit, wit_in))
         # prove_with_partition_witness's retry loop (plonk/prover.rs:183-226): on InvZeroPermArg the random wire - last
         # wire of the PublicInputGate row - is re-drawn and the proof redone; failed attempts stay inside the timed region
         random_wire = (nwires - 1, pi_row)
@@ -277,6 +284,7 @@ def main():
             "vs_baseline": None, "dtype": "u32" if args.field == "babybear" else "u64", "data": "synthetic",
             "config": {"workload": workload, "field": args.field, "log_n": log_n, "rate_bits": rate_bits,
                        "cap_height": cap_height, "proofs_in_flight_per_gpu": inflight,
+                       "witness": "page-locked host memory, copied in every step" if getattr(args, "host_witness", False) else "resident in HBM",
                        "sharding": "one independent circuit per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": "NTT pass = %s (IFFT) + %s (FFT + blinding), all commitments of the step" % (
                              ("k_bb_intt_p1+p2+p3", "k_bb_lde_pa+pb") if bb else ("k_gl_intt16_p1+p2+p3", "k_gl_lde_pa16+pb16")),
