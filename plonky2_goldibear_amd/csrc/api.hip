@@ -59,6 +59,7 @@ struct BbCosetSet {
 struct gb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // host -> device uploads that overlap kernels on `stream` (commit() of host input)
     std::string err;
     bool profiling = false;
     std::map<std::string, ScopeAcc> scopes;
@@ -317,8 +318,23 @@ inline size_t hout(u32 field) { return field == GB_GOLDILOCKS ? 4 : 8; }
 inline size_t esize(u32 field) { return field == GB_GOLDILOCKS ? 8 : 4; }
 inline size_t level_offset(u64 N, u32 k) { return (size_t)(2 * N - ((2 * N) >> k)); }
 
+struct EventList {  // events of one enqueue sequence, destroyed together (destruction is deferred until they have completed)
+    std::vector<hipEvent_t> v;
+    hipEvent_t make(bool& ok) {
+        hipEvent_t e = nullptr;
+        if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) v.push_back(e);
+        else ok = false;
+        return e;
+    }
+    ~EventList() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
+};
+
+// values_dev (optional, from_values of HOST input only): a device buffer [ncols][n] that receives the input values in the field's
+// device form.  The upload then runs in column chunks on the context's copy stream while the inverse NTT and LDE of the chunk
+// before it run on the main stream, and the caller gets the values on the device without a second transfer (prove() needs the
+// routed wires there for the permutation argument).
 gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                 uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out) {
+                 uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr) {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     if (!out) return fail(ctx, GB_ERR_INVALID, "null out");
     *out = nullptr;
@@ -370,24 +386,53 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         if ((s = ensure(ctx, ctx->scratch, 2 * scr_bytes))) return cleanup(s);
         u32* scr = (u32*)ctx->scratch.p;
         const u32* in_dev = static_cast<const u32*>(cols);
-        if (!dev_in) {
+        const bool staged = !dev_in && !is_coeffs && values_dev && log_n >= 12 && ncols >= 4;
+        if (staged) {
+            // column chunks: H2D into one of two staging halves (copy stream) -> Montgomery form into values_dev -> inverse NTT -> LDE
+            const size_t half = scr_bytes / 4 / 2;                 // words per staging half; the NTT scratch is scr's second region
+            const size_t per = std::min<size_t>(16, half / n);     // >= 2 columns because ncols >= 4
+            u32* vals = static_cast<u32*>(values_dev);
+            u32* ntt_scr = scr + scr_bytes / 4;
+            EventList evs;
+            bool ok = true;
+            hipEvent_t e0 = evs.make(ok);                           // the staging area and values_dev may still be in use on `st`
+            ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
+            std::vector<hipEvent_t> converted;
+            size_t k = 0;
+            for (size_t c0 = 0; c0 < ncols && ok; c0 += per, k++) {
+                const size_t cc = std::min(per, ncols - c0);
+                u32* stage = scr + (k & 1) * half;
+                if (k >= 2) ok = ok && hipStreamWaitEvent(ctx->copy_stream, converted[k - 2], 0) == hipSuccess;  // half free again
+                hipEvent_t copied = evs.make(ok), conv = evs.make(ok);
+                ok = ok && hipMemcpyAsync(stage, static_cast<const u32*>(cols) + c0 * n, cc * n * 4, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
+                     hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
+                if (!ok) break;
+                gbk::bb_to_mont(stage, vals + c0 * n, cc * n, st);
+                ok = hipEventRecord(conv, st) == hipSuccess;
+                converted.push_back(conv);
+                { Scope sc(ctx, "IFFT"); gbk::bb_intt_columns(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, *bt, st); }
+                { Scope sc(ctx, "FFT + blinding"); gbk::bb_lde_columns(coeffs + c0 * n, lde + c0 * N, cc, *bt, *bc, st); }
+            }
+            if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
+        } else if (!dev_in) {
             if (hipMemcpyAsync(scr, cols, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
             in_dev = scr;
         }
-        if (flags & GB_INPUT_DEVICE_FORM) {  // prover-internal: already Montgomery words on the device
+        if (staged) {
+        } else if (flags & GB_INPUT_DEVICE_FORM) {  // prover-internal: already Montgomery words on the device
             if (hipMemcpyAsync(coeffs, in_dev, in_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
         } else {
             gbk::bb_to_mont(in_dev, coeffs, ncols * n, st);
         }
-        if (!is_coeffs) {
+        if (!is_coeffs && !staged) {
             Scope sc(ctx, "IFFT");
             gbk::bb_intt_columns(coeffs, coeffs, scr + scr_bytes / 4, ncols, *bt, st);
         }
         {
             Scope sc(ctx, "FFT + blinding");
-            gbk::bb_lde_columns(coeffs, lde, ncols, *bt, *bc, st);
+            if (!staged) gbk::bb_lde_columns(coeffs, lde, ncols, *bt, *bc, st);
             if (nsalt) {
                 const u32* sdev = static_cast<const u32*>(salts);
                 if (!dev_in) {
@@ -415,21 +460,41 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     if ((s = gl_cosets_for(ctx, log_n, rate_bits, gl::GENERATOR, false, &cos))) return cleanup(s);
 
     const u64* src = static_cast<const u64*>(cols);
-    if (!dev_in || is_coeffs) {
+    const bool staged = !dev_in && !is_coeffs && values_dev && log_n >= 12;
+    if (staged) {
+        // column chunks: H2D into values_dev on the copy stream, then (main stream, behind an event) inverse NTT and LDE of the chunk
+        const size_t CH = 16;
+        u64* vals = static_cast<u64*>(values_dev);
+        if ((s = ensure(ctx, ctx->scratch, CH * n * sizeof(u64)))) return cleanup(s);
+        EventList evs;
+        bool ok = true;
+        hipEvent_t e0 = evs.make(ok);                               // values_dev may be a pool block still in use on `st`
+        ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
+        for (size_t c0 = 0; c0 < ncols && ok; c0 += CH) {
+            const size_t cc = std::min(CH, ncols - c0);
+            hipEvent_t copied = evs.make(ok);
+            ok = ok && hipMemcpyAsync(vals + c0 * n, src + c0 * n, cc * n * sizeof(u64), hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
+                 hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
+            if (!ok) break;
+            { Scope sc(ctx, "IFFT"); gbk::gl_intt_columns(vals + c0 * n, b->coeffs + c0 * n, (u64*)ctx->scratch.p, cc, *tabs, st); }
+            { Scope sc(ctx, "FFT + blinding"); gbk::gl_lde_columns(b->coeffs + c0 * n, b->lde + c0 * N, cc, *tabs, *cos, st); }
+        }
+        if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
+    } else if (!dev_in || is_coeffs) {
         // host input, or coefficients the batch must own a copy of
         if (hipMemcpyAsync(b->coeffs, cols, ncols * n * sizeof(u64), dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            st) != hipSuccess)
             return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
         src = b->coeffs;
     }
-    if (!is_coeffs) {
+    if (!is_coeffs && !staged) {
         if ((s = ensure(ctx, ctx->scratch, ncols * n * sizeof(u64)))) return cleanup(s);
         Scope sc(ctx, "IFFT");
         gbk::gl_intt_columns(src, b->coeffs, (u64*)ctx->scratch.p, ncols, *tabs, st);
     }
     {
         Scope sc(ctx, "FFT + blinding");
-        gbk::gl_lde_columns(b->coeffs, b->lde, ncols, *tabs, *cos, st);
+        if (!staged) gbk::gl_lde_columns(b->coeffs, b->lde, ncols, *tabs, *cos, st);
         if (nsalt) {
             // salt columns arrive in LDE-point order (like lde_values' extra columns, oracle.rs:144-148)
             // and are stored, like everything else, in leaf order: leaf j <- point bitrev(j)
@@ -468,7 +533,8 @@ gb_status gb_ctx_create(int device, gb_ctx** out) {
     gb_ctx* ctx = new (std::nothrow) gb_ctx();
     if (!ctx) return fail(nullptr, GB_ERR_OOM, "host allocation failed");
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, GB_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
     }
@@ -493,6 +559,7 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     if (ctx->small.p) hipFree(ctx->small.p);
     for (auto& kv : ctx->pool) hipFree(kv.second);
     hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
     return GB_OK;
 }
