@@ -329,9 +329,9 @@ struct EventList {  // events of one enqueue sequence, destroyed together (destr
     ~EventList() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
 };
 
-// values_dev (optional, from_values of HOST input only): a device buffer [ncols][n] that receives the input values in the field's
-// device form.  The upload then runs in column chunks on the context's copy stream while the inverse NTT and LDE of the chunk
-// before it run on the main stream, and the caller gets the values on the device without a second transfer (prove() needs the
+// from_values of HOST input (2^12 rows and up): the upload runs in column chunks on the context's copy stream while the inverse NTT
+// and LDE of the chunk before it run on the main stream.  values_dev (optional): a device buffer [ncols][n] that receives the input
+// values in the field's device form, so that the caller gets them on the device without a second transfer (prove() needs the
 // routed wires there for the permutation argument).
 gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                  uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr) {
@@ -386,12 +386,12 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         if ((s = ensure(ctx, ctx->scratch, 2 * scr_bytes))) return cleanup(s);
         u32* scr = (u32*)ctx->scratch.p;
         const u32* in_dev = static_cast<const u32*>(cols);
-        const bool staged = !dev_in && !is_coeffs && values_dev && log_n >= 12 && ncols >= 4;
+        const bool staged = !dev_in && !is_coeffs && log_n >= 12 && ncols >= 4;
         if (staged) {
             // column chunks: H2D into one of two staging halves (copy stream) -> Montgomery form into values_dev -> inverse NTT -> LDE
             const size_t half = scr_bytes / 4 / 2;                 // words per staging half; the NTT scratch is scr's second region
             const size_t per = std::min<size_t>(16, half / n);     // >= 2 columns because ncols >= 4
-            u32* vals = static_cast<u32*>(values_dev);
+            u32* vals = values_dev ? static_cast<u32*>(values_dev) : coeffs;  // without a taker the values are transformed in place
             u32* ntt_scr = scr + scr_bytes / 4;
             EventList evs;
             bool ok = true;
@@ -460,11 +460,11 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     if ((s = gl_cosets_for(ctx, log_n, rate_bits, gl::GENERATOR, false, &cos))) return cleanup(s);
 
     const u64* src = static_cast<const u64*>(cols);
-    const bool staged = !dev_in && !is_coeffs && values_dev && log_n >= 12;
+    const bool staged = !dev_in && !is_coeffs && log_n >= 12;
     if (staged) {
         // column chunks: H2D into values_dev on the copy stream, then (main stream, behind an event) inverse NTT and LDE of the chunk
         const size_t CH = 16;
-        u64* vals = static_cast<u64*>(values_dev);
+        u64* vals = values_dev ? static_cast<u64*>(values_dev) : b->coeffs;  // without a taker the values are transformed in place
         if ((s = ensure(ctx, ctx->scratch, CH * n * sizeof(u64)))) return cleanup(s);
         EventList evs;
         bool ok = true;
