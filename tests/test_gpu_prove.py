@@ -104,6 +104,11 @@ def test_full_size_2pow20_proof_verifies(ctx):
     assert stats["merkle_paths"] == 28 * (4 + 4)
     assert gpu.verify(proof)  # the product's own host-side verifier (gb_verify)
     assert gpu.prove(w) == proof
+    # compressed form (plonk/proof.rs:96-140, 221-265): round trip and direct verification, checked against the oracle
+    from oracle import compression as Z
+    small = gpu.compress(proof)
+    assert len(small) < len(proof) and small == Z.compress_bytes(proof, circ.circuit_digest, circ.common_data())
+    assert gpu.decompress(small) == proof and gpu.verify_compressed(small)
     gpu.free()
     ctx.trim()
 

@@ -83,6 +83,10 @@ def test_bb_config4_2p20_rows(ctx):
     assert D.verify(circ, proof, stats)
     assert stats["merkle_paths"] == 28 * (4 + 5)
     assert gpu.verify(proof)  # the product's own host-side verifier (gb_verify)
+    from oracle import compression as Z
+    small = gpu.compress(proof)
+    assert small == Z.compress_bytes(proof, circ.circuit_digest, circ.common_data(), BB)
+    assert gpu.decompress(small) == proof and gpu.verify_compressed(small)
 
 
 def test_bb_error_behaviour(ctx):

@@ -4,7 +4,9 @@ standard_recursion_config_gl (num_challenges 2; 3 above 2^14 rows).  One row of 
 evaluates every gate of the set at every LDE point whatever sits in the rows, so the time is that of a full recursion circuit of
 the same size; the proof is verified.  The reference's one published number is for this shape: "about 170 ms" for a recursion
 proof (~2^12 rows) on a MacBook Pro (plonky2/README.md:5).
-usage: python tools/bench_recursion_shape.py [log_n ...]"""
+usage: python tools/bench_recursion_shape.py [--inflight K] [log_n ...]
+--inflight K: K independent circuits proved concurrently, one context (= one HIP stream) and one host thread each - what an
+aggregation layer with many recursion proofs to make does; a proof of this size cannot fill the GPU on its own."""
 import json
 import os
 import sys
@@ -19,10 +21,54 @@ from plonky2_goldibear_amd.circuit_builder import NoopGate  # noqa: E402
 from circuits import recursion_gates_circuit  # noqa: E402
 
 
+def many_in_flight(log_n, k):
+    import threading
+    import torch
+    lanes = []
+    for i in range(k):
+        ctx = GpuContext(0)
+        b, pw, _ = recursion_gates_circuit(seed=100 + i, num_challenges=2 if log_n <= 14 else 3)
+        while b.num_gates() < (1 << log_n) - 8:
+            b.add_gate(NoopGate())
+        c = b.build(ctx)
+        w, pis = c.generate_witness(pw)
+        assert c.data.verify(c.data.prove(w, pis))
+        lanes.append((ctx, c, torch.from_numpy(w.view(np.int64)).to("cuda:0"), pis))
+    per_thread = 40
+
+    def run(i):
+        _, c, wd, pis = lanes[i]
+        for _ in range(per_thread):
+            c.data.prove(wd, pis)
+    for i in range(k):
+        run_warm = lanes[i][1].data.prove(lanes[i][2], lanes[i][3])
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(k)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for ctx, _, _, _ in lanes:
+        ctx.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": "recursion-shaped circuits, %d in flight (one stream + one host thread each)" % k, "log_n": log_n,
+                      "proofs": k * per_thread, "seconds": round(dt, 4), "proofs_per_s": round(k * per_thread / dt, 1)}), flush=True)
+    for ctx, c, _, _ in lanes:
+        c.data.free()
+        ctx.close()
+
+
 def main():
+    args = sys.argv[1:]
+    if args and args[0] == "--inflight":
+        k = int(args[1])
+        for log_n in [int(a) for a in args[2:]] or [12]:
+            many_in_flight(log_n, k)
+        return
     ctx = GpuContext(0)
     ctx.set_profiling(True)
-    for log_n in [int(a) for a in sys.argv[1:]] or [12, 13, 14]:
+    for log_n in [int(a) for a in args] or [12, 13, 14]:
         # circuit_builder.rs:1190-1192: (64 - degree_bits) * num_challenges >= 100 needs a third challenge above 2^14 rows
         b, pw, _ = recursion_gates_circuit(seed=log_n, num_challenges=2 if log_n <= 14 else 3)
         while b.num_gates() < (1 << log_n) - 8:
