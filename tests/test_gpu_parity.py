@@ -51,7 +51,7 @@ def _check_batch(gpu, cpu, full=True):
 @pytest.mark.parametrize("log_n,ncols,rate_bits,cap_height", [
     (0, 1, 0, 0), (0, 3, 3, 2), (1, 2, 1, 0), (2, 5, 3, 4), (4, 1, 3, 4), (5, 4, 3, 0), (6, 9, 3, 4),
     (8, 17, 3, 4), (10, 8, 3, 4), (10, 135, 3, 4), (11, 3, 2, 13), (12, 5, 3, 4), (12, 2, 0, 1),
-    (13, 3, 3, 4), (14, 2, 1, 4), (15, 2, 3, 4), (16, 3, 3, 4), (17, 2, 3, 4), (18, 1, 2, 4),
+    (13, 3, 3, 4), (14, 2, 1, 4), (15, 2, 3, 4), (16, 3, 3, 4), (17, 2, 3, 4), (18, 1, 2, 4), (18, 3, 3, 4), (19, 2, 3, 4),
 ])
 def test_from_values_matches_oracle(ctx, log_n, ncols, rate_bits, cap_height):
     vals = _cols(ncols, log_n)
