@@ -67,6 +67,30 @@ __device__ __forceinline__ void dft16(u32 (&x)[16]) {
 #undef B1
 }
 
+// 2-, 4- and 8-point DFTs of the same family (the tail stages of dft16 on the first 2^K registers): natural input order,
+// output X[k] in slot brevK(k) - for the sizes between the multiples of four bits (2^17..2^19 rows)
+template <bool INV, int K>
+__device__ __forceinline__ void dft_small(u32 (&x)[16]) {
+    static_assert(K >= 1 && K <= 3, "radix 2, 4 or 8");
+    if constexpr (K == 3) {
+        bfly<INV, 4, 0>(x[0], x[4]); bfly<INV, 4, 1>(x[1], x[5]); bfly<INV, 4, 2>(x[2], x[6]); bfly<INV, 4, 3>(x[3], x[7]);
+    }
+    if constexpr (K >= 2) {
+#pragma unroll
+        for (int o = 0; o < (1 << K); o += 4) {
+            bfly<INV, 2, 0>(x[o], x[o + 2]);
+            bfly<INV, 2, 1>(x[o + 1], x[o + 3]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < (1 << K); o += 2) bfly<INV, 1, 0>(x[o], x[o + 1]);
+}
+__device__ __forceinline__ constexpr u32 brevk(u32 x, int k) {
+    u32 r = 0;
+    for (int i = 0; i < k; i++) r |= ((x >> i) & 1) << (k - 1 - i);
+    return r;
+}
+
 __device__ __forceinline__ u32 bb_tw_split16(const u32* __restrict__ hi, const u32* __restrict__ lo, u32 e) {
     u32 eh = e >> 10, el = e & 1023;
     u32 w = lo[el];
@@ -193,6 +217,64 @@ __global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict
     }
 }
 
+// LA = 4 + K (L = 16 + K, K = 1..3): a = a1 2^K + a0.  grid = ncols * 2^(4+K); a block holds all 2^LA rows of 2^(8-K) consecutive
+// columns l (row segments of 128 bytes and more): stage 1 (thread = (a0, jl), radix 16 over a1), LDS, stage 2 (radix 2^K over a0;
+// a thread takes 2^(4-K) columns so that it still moves 16 values).
+template <int K>
+__global__ __launch_bounds__(THREADS) void k_bb_lde_pa16xs(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 rate_bits,
+                                                           const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                           const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
+                                                           const u32* __restrict__ pow_hi) {
+    constexpr u32 L = 16 + K, LA = 4 + K, R = 1u << K, M = 256u >> K;  // M columns per block
+    __shared__ u32 sh[16 * 256];                                          // [k_a1 slot][a0][jl]
+    const u32 blocks_per_col = 4096 / M;
+    const size_t col = blockIdx.x / blocks_per_col;
+    const u32 l0 = (blockIdx.x % blocks_per_col) * M;
+    const u32 tid = threadIdx.x, a0 = tid / M, jl = tid % M;
+    const size_t n = (size_t)1 << L;
+    u32 orig[16];
+    {
+        const u32* cin = coeffs + col * n + l0 + jl;
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)((a1 << K) + a0) << 12];
+    }
+    u32 tw[16];
+#pragma unroll
+    for (u32 s = 1; s < 16; s++) tw[s] = tw4096[((brev4(s) * a0) << (12 - LA)) & 4095];  // w_{2^LA}^(k_a1 a0): the same for every coset
+    const u32 s2 = tid >> 4, q = tid & 15;  // stage-2 role: slot s2, columns q + 16 u
+    const u32 ka1 = brev4(s2);
+    const u32 ncosets = 1u << rate_bits;
+    for (u32 c = 0; c < ncosets; c++) {
+        const u32* ph = pow_hi + ((size_t)c << LA) + a0;
+        u32 x[16];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = ph[a1 << K];  // s_c^(4096 a)
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = bb::mul(orig[a1], x[a1]);
+        dft16<false>(x);
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) sh[s * 256 + tid] = s ? bb::mul(x[s], tw[s]) : x[s];
+        __syncthreads();
+#pragma unroll
+        for (u32 u = 0; u < M / 16; u++) {
+            const u32 jj = q + 16 * u, l = l0 + jj;
+            u32 y[16];
+#pragma unroll
+            for (u32 b = 0; b < R; b++) y[b] = sh[s2 * 256 + b * M + jj];
+            dft_small<false, K>(y);
+            u32 f = bb::mul(pow_lo[(size_t)c * 4096 + l], bb_tw_split16(tw_hi, tw_lo, ka1 * l));
+            const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 16 * l);
+            u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+#pragma unroll
+            for (u32 k = 0; k < R; k++) {  // row position = brev_LA(k_a) = slot * 2^K + brevK(k')
+                out[(size_t)(s2 * R + brevk(k, K)) << 12] = bb::mul(y[brevk(k, K)], f);
+                if (k + 1 < R) f = bb::mul(f, ratio);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // LA = 4 (L = 16): grid = ncols * 16, block = 16 rows x 256 contiguous columns, one radix-16 stage, no LDS.
 __global__ __launch_bounds__(THREADS) void k_bb_lde_pa16x1(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 rate_bits,
                                                            const u32* __restrict__ tw_hi, const u32* __restrict__ tw_lo,
@@ -282,6 +364,26 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p2(const u32* __restrict_
         dst[cbase + ((size_t)brev4(s) << 16) + ((size_t)ka << 8) + c] = s ? bb::mul(x[s], tw[s]) : x[s];
 }
 
+// P2 for LB = K in 1..3 (L = 16 + K): the same pass with a radix-2^K DFT over b; src [k_a][b][c] -> dst [k_b][k_a][c]
+template <int K>
+__global__ __launch_bounds__(THREADS) void k_bb_intt16_p2s(const u32* __restrict__ src, u32* __restrict__ dst, const u32* __restrict__ tw4096) {
+    constexpr u32 L = 16 + K, R = 1u << K;
+    const size_t col = blockIdx.x >> 8;
+    const u32 ga = (blockIdx.x >> 4) & 15, gc = blockIdx.x & 15;
+    const size_t cbase = col << L;
+    const u32 ka = 16 * ga + (threadIdx.x >> 4), c = 16 * gc + (threadIdx.x & 15);
+    u32 x[16];
+#pragma unroll
+    for (u32 b = 0; b < R; b++) x[b] = src[cbase + ((size_t)ka << (8 + K)) + ((size_t)b << 8) + c];
+    u32 tw[R];
+#pragma unroll
+    for (u32 s = 1; s < R; s++) tw[s] = tw4096[(brevk(s, K) * c) << (4 - K)];  // w_{2^(8+K)}^-(c k_b)
+    dft_small<true, K>(x);
+#pragma unroll
+    for (u32 s = 0; s < R; s++)
+        dst[cbase + ((size_t)brevk(s, K) << 16) + ((size_t)ka << 8) + c] = s ? bb::mul(x[s], tw[s]) : x[s];
+}
+
 // P3: grid = ncols * 2^LB * 16; tile 16 k_a x 256 c (c = 16 c1 + c0); src [k_b][k_a][c];
 // dst natural k = k_a + 256 k_b + 2^(8+LB) k_c, scaled by n^-1
 __global__ __launch_bounds__(THREADS) void k_bb_intt16_p3(const u32* __restrict__ src, u32* __restrict__ dst, BbInv16Geom g,
@@ -320,14 +422,17 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p3(const u32* __restrict_
 
 bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
     const u32 L = t.log_n;
-    if (L != 16 && L != 20) return false;
+    if (L < 16 || L > 20) return false;
     BbInv16Geom g{L, L - 16};
     const u32 LL = g.LB + 8;
     u32* p1_dst = g.LB ? coeffs : scratch;
     hipLaunchKernelGGL(k_bb_intt16_p1, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv,
                        t.tw_hi_inv, t.tw_lo_inv);
-    if (g.LB)
-        hipLaunchKernelGGL(k_bb_intt16_p2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv);
+    const dim3 g2((u32)(ncols << 8));
+    if (g.LB == 4) hipLaunchKernelGGL(k_bb_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv);
+    else if (g.LB == 3) hipLaunchKernelGGL(k_bb_intt16_p2s<3>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
+    else if (g.LB == 2) hipLaunchKernelGGL(k_bb_intt16_p2s<2>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
+    else if (g.LB == 1) hipLaunchKernelGGL(k_bb_intt16_p2s<1>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
     hipLaunchKernelGGL(k_bb_intt16_p3, dim3((u32)(ncols << (g.LB + 4))), dim3(THREADS), 0, stream, scratch, coeffs, g,
                        t.tw4096_inv, t.n_inv);
     return true;
@@ -340,6 +445,13 @@ bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables&
                            t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
         return true;
     }
+#define GB_PAS(KK)                                                                                                        \
+    hipLaunchKernelGGL(k_bb_lde_pa16xs<KK>, dim3((u32)(ncols << (4 + KK))), dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, \
+                       t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi)
+    if (L == 17) { GB_PAS(1); return true; }
+    if (L == 18) { GB_PAS(2); return true; }
+    if (L == 19) { GB_PAS(3); return true; }
+#undef GB_PAS
     if (L == 16) {
         hipLaunchKernelGGL(k_bb_lde_pa16x1, dim3((u32)(ncols << 4)), dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits,
                            t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);

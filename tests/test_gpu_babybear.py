@@ -47,7 +47,7 @@ def _check(gpu, cpu):
 
 @pytest.mark.parametrize("log_n,ncols,rate_bits,cap_height", [
     (0, 1, 0, 0), (1, 3, 1, 0), (3, 8, 3, 2), (4, 9, 3, 4), (6, 5, 3, 4), (8, 17, 3, 4), (10, 167, 3, 4),
-    (12, 3, 3, 4), (13, 4, 3, 4), (14, 2, 1, 4), (16, 3, 3, 4), (17, 2, 3, 4), (18, 1, 2, 4),
+    (12, 3, 3, 4), (13, 4, 3, 4), (14, 2, 1, 4), (16, 3, 3, 4), (17, 2, 3, 4), (18, 1, 2, 4), (18, 3, 3, 4), (19, 2, 3, 4),
 ])
 def test_from_values_matches_oracle(ctx, log_n, ncols, rate_bits, cap_height):
     vals = _cols(ncols, log_n)
