@@ -260,6 +260,37 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16xs(const u64* __restr
     }
 }
 
+// LA = K in 1..3 (L = 12 + K): one radix-2^K stage over the 2^K rows, a thread per column l, no LDS.  grid = ncols * 16.
+template <int K>
+__global__ __launch_bounds__(THREADS) void k_gl_lde_pa_small(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 rate_bits,
+                                                             const u64* __restrict__ tw_hi, const u64* __restrict__ tw_lo,
+                                                             const u64* __restrict__ pow_lo, const u64* __restrict__ pow_hi) {
+    constexpr u32 L = 12 + K, R = 1u << K;
+    const size_t col = blockIdx.x >> 4;
+    const u32 l = ((blockIdx.x & 15) << 8) + threadIdx.x;
+    const size_t n = (size_t)1 << L;
+    const u64* cin = coeffs + col * n + l;
+    u64 orig[R];
+#pragma unroll
+    for (u32 a = 0; a < R; a++) orig[a] = cin[(size_t)a << 12];
+    const u32 ncosets = 1u << rate_bits;
+    const u64 ratio = tw_split16(tw_hi, tw_lo, l);  // w_n^l
+    for (u32 c = 0; c < ncosets; c++) {
+        const u64* ph = pow_hi + ((size_t)c << K);
+        u64 x[16];
+#pragma unroll
+        for (u32 a = 0; a < R; a++) x[a] = a ? gl::mul(orig[a], ph[a]) : orig[a];  // s_c^(4096 a)
+        dft_small<false, K>(x);
+        u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+        u64 f = pow_lo[(size_t)c * 4096 + l];  // s^l w_n^(k l), k = 0..R-1
+#pragma unroll
+        for (u32 k = 0; k < R; k++) {
+            out[(size_t)brevk(k, K) << 12] = gl::mul(x[brevk(k, K)], f);
+            if (k + 1 < R) f = gl::mul(f, ratio);
+        }
+    }
+}
+
 // LA = 4 (L = 16): grid = ncols * 16, block = 16 rows x 256 contiguous columns, one radix-16 stage, no LDS.
 __global__ __launch_bounds__(THREADS) void k_gl_lde_pa16x1(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 rate_bits,
                                                            const u64* __restrict__ tw_hi, const u64* __restrict__ tw_lo,
@@ -433,6 +464,13 @@ bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables&
 #define GB_PAS(KK)                                                                                                        \
     hipLaunchKernelGGL(k_gl_lde_pa16xs<KK>, dim3((u32)(ncols << (4 + KK))), dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, \
                        t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi)
+    if (L >= 13 && L <= 15) {
+        const dim3 grid((u32)(ncols << 4));
+        if (L == 13) hipLaunchKernelGGL(k_gl_lde_pa_small<1>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        if (L == 14) hipLaunchKernelGGL(k_gl_lde_pa_small<2>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        if (L == 15) hipLaunchKernelGGL(k_gl_lde_pa_small<3>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        return true;
+    }
     if (L == 17) { GB_PAS(1); return true; }
     if (L == 18) { GB_PAS(2); return true; }
     if (L == 19) { GB_PAS(3); return true; }
