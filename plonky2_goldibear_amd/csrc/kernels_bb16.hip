@@ -5,7 +5,7 @@
 // DFT are Montgomery multiplications by compile-time constants w_16^k.  The multiplication count per element
 // and layer is therefore the same as radix-2 (1/2); what the register form buys is one LDS round trip per four
 // layers instead of one per layer (v1, kernels_bb.hip: 34.8 ms of LDE per 2^20 proof, ~5x the VALU bound).
-// kernels_bb.hip's v1 passes remain the fallback for sizes other than 2^16 and 2^20.
+// kernels_bb.hip's v1 passes remain for the inverse transform of 2^13..2^15 rows and for single-tile sizes.
 #include <algorithm>
 
 #include "bb_field.hpp"

@@ -7,8 +7,8 @@
 // A thread keeps 16 points in registers for four layers; general twiddles (tables) appear only between
 // radix-16 stages, and LDS is touched once per stage instead of once per layer.
 //
-// Same passes, tiles and memory layouts as kernels_ntt.hip (which remains the fallback for shapes
-// that are not multiples of four bits):
+// Same passes, tiles and memory layouts as kernels_ntt.hip (whose LDS radix-2 passes remain for the inverse transform of
+// 2^13..2^15 rows and for single-tile sizes):
 //   inverse:  P1 (8 bits strided)  P2 (0..4 bits)  P3 (8 bits, transposed write)            2^16..2^20 rows
 //   LDE:      PA (4..8 bits strided, per-coset loop)  PB (12 bits contiguous, natural -> leaf order)
 #include "kernels.hpp"
