@@ -55,7 +55,8 @@ def build_library(force=False, verbose=False):
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr):
             return obj
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        extra = os.environ.get("GB_EXTRA_FLAGS_" + os.path.basename(src).split(".")[0].upper(), "").split()  # tuning experiments
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
