@@ -138,3 +138,25 @@ def test_bb_odd_sizes_verify(ctx, degree_bits, num_challenges):
     assert stats["merkle_paths"] == 28 * (4 + len(circ.reduction_arity_bits))
     gpu.free()
     ctx.trim()
+
+
+@pytest.mark.parametrize("field,kw", [("bb", dict(num_wires=334, num_routed_wires=160)),      # recursion_config_bb_wide
+                                      ("gl", dict(num_wires=234)), ("gl", dict(num_wires=136))])   # wide_ecc / standard_ecc
+def test_other_reference_configs_bytes_match_oracle(ctx, field, kw):
+    """The reference's remaining CircuitConfigs (plonk/circuit_data.rs:122-173): same prover, other wire counts (the wide BabyBear
+    config has 20 partial-product chunks per challenge)."""
+    from oracle.fields import GL
+    if field == "bb":
+        cfg = D.CircuitConfig.babybear(6, **kw)
+        circ = D.DummyCircuit(7, cfg, F=BB)
+        gpu = CircuitData.babybear(ctx, 7, circ.constants_sigmas, circ.k_is, num_challenges=6, **kw)
+    else:
+        cfg = D.CircuitConfig(**kw)
+        circ = D.DummyCircuit(7, cfg, F=GL)
+        gpu = CircuitData(ctx, 7, circ.constants_sigmas, circ.k_is, **kw)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    w = circ.witness(seed=5)
+    want, _ = D.prove_cpu(circ, w)
+    got = gpu.prove(w)
+    assert got == want and gpu.verify(got) and D.verify(circ, got)
+    gpu.free()
