@@ -8,6 +8,7 @@
 #include <cstring>
 #include <exception>
 #include <map>
+#include <memory>
 #include <new>
 #include <algorithm>
 #include <string>
