@@ -3,6 +3,7 @@ compressed proof, so the pin is the round trip on ITS regression proof: compress
 bytes exactly (every Merkle path, every inferred FRI element).  No GPU: the oracle (python) and the product (C ABI,
 gb_proof_compress / gb_proof_decompress / gb_verify_compressed run on the host) are compared byte for byte."""
 import os
+import struct
 
 import numpy as np
 import pytest
@@ -58,15 +59,10 @@ def test_oracle_proofs_round_trip(F):
     bad[len(bad) // 2] ^= 1
     try:
         out = Z.decompress_bytes(bytes(bad), circ.circuit_digest, cd, F)
-    except (AssertionError, KeyError, StopIteration, ValueError, struct_error()):
+    except (AssertionError, KeyError, StopIteration, ValueError, struct.error):
         return
     with pytest.raises(AssertionError):
         D.verify(circ, out)
-
-
-def struct_error():
-    import struct
-    return struct.error
 
 
 # ------------------------------------------------------------------------------------------------ the product (C ABI, host)
