@@ -175,7 +175,8 @@ static inline u32 blocks_for(u64 n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 
 // Below this many states a lone wave's ~56 us per lane-per-state permutation dominates; the cooperative form does ~3.6x the
 // instructions in total but its dependent chain is ~4x shorter (crossover between 2^14 and 2^15 states on 1024 SIMDs).
-static constexpr u64 COOP_MAX_STATES = 16384;  // measured: 2048 / 8192 / 16384 / 32768 -> 5.41 / 5.14 / 5.00 / 5.50 ms per 2^12-row proof
+static constexpr u64 COOP_MAX_STATES = 16384;  // measured: 2048 / 8192 / 16384 / 32768 -> 5.41 / 5.14 / 5.00 / 5.50 ms per 2^12-row proof;
+                                               // separate thresholds for levels and leaves (same-box sweeps, both fields) are within noise of this
 
 void gl_merkle_leaves(const u64* cols, size_t col_stride, u32 width, u64 num_leaves, u64* out, hipStream_t stream) {
     if (width > 4 && num_leaves <= COOP_MAX_STATES) {
