@@ -69,6 +69,31 @@ int main(int argc, char** argv) {
     if (gb_verify(circuit, proof.data(), len) != GB_ERR_VERIFY) { std::fprintf(stderr, "tampered proof was not rejected\n"); return 1; }
     proof[100] ^= 1;
 
+    // the verifier's side without the prover's circuit object: CommonCircuitData (config + gate table) and VerifierOnlyCircuitData
+    // (cap, digest) only - no device involved (ctx = NULL) - and the compressed form of the proof
+    {
+        const gb_gate gates[3] = {{GB_GATE_NOOP, 0, 0, 0, 3, 0, 0}, {GB_GATE_CONSTANT, nconst, 0, 0, 3, 0, 0}, {GB_GATE_PUBLIC_INPUT, 4, 0, 0, 3, 0, 0}};
+        gb_circuit* verifier = nullptr;
+        if (gb_verifier_create(nullptr, &cfg, gates, 3, k_is.data(), cap, digest, &verifier) != GB_OK) {
+            std::fprintf(stderr, "gb_verifier_create: %s\n", gb_last_error(nullptr));
+            return 1;
+        }
+        CHECK(gb_verify(verifier, proof.data(), len));
+        std::vector<uint8_t> small(len), back(len + 64);
+        size_t slen = 0, blen = 0;
+        CHECK(gb_proof_compress(verifier, proof.data(), len, small.data(), small.size(), &slen));
+        if (slen >= len) { std::fprintf(stderr, "compressed proof is not smaller\n"); return 1; }
+        CHECK(gb_verify_compressed(verifier, small.data(), slen));
+        CHECK(gb_proof_decompress(verifier, small.data(), slen, back.data(), back.size(), &blen));
+        if (blen != len || std::memcmp(back.data(), proof.data(), len) != 0) { std::fprintf(stderr, "decompress(compress(proof)) != proof\n"); return 1; }
+        size_t need = 0;
+        if (gb_proof_compress(verifier, proof.data(), len, small.data(), 16, &need) != GB_ERR_BUFFER_TOO_SMALL || need != slen) {
+            std::fprintf(stderr, "short output buffer was not reported\n");
+            return 1;
+        }
+        CHECK(gb_circuit_free(verifier));
+    }
+
     // the PolynomialBatch boundary on its own: commit the witness, read the cap (must equal the proof's first cap), a leaf + path
     gb_batch* batch = nullptr;
     CHECK(gb_commit_values(ctx, GB_GOLDILOCKS, wit.data(), wires, k, 3, 4, nullptr, GB_INPUT_HOST, &batch));
