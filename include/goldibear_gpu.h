@@ -133,6 +133,11 @@ typedef struct gb_circuit_config {
     uint32_t gate_constant, gate_pi;/* selector values of ConstantGate / PublicInputGate (NoopGate is the third) */
     uint32_t zero_knowledge;        /* CircuitConfig.zero_knowledge (= FriParams.hiding): the wires / Zs / quotient leaves carry
                                        SALT_SIZE salt elements (fri/oracle.rs:133-148): gb_prove_salted, gb_verify */
+    uint32_t num_public_inputs;     /* CommonCircuitData.num_public_inputs (plonk/circuit_data.rs:590): gb_prove takes exactly
+                                       this many; gb_verify / gb_verify_compressed / gb_proof_decompress reject a proof carrying
+                                       any other count with GB_ERR_INVALID, as validate_proof_with_pis_shape does
+                                       (plonk/validate_shape.rs:22-25) - hash_no_pad does not pad, so [a,b,c] and [a,b,c,0]
+                                       have the same public-inputs hash and only this check tells them apart */
 } gb_circuit_config;
 
 /* constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits] VALUES on H_n

@@ -42,6 +42,8 @@ pub struct gb_circuit_config {
     pub gate_pi: u32,
     /// CircuitConfig.zero_knowledge (= FriParams.hiding): salted wires / Zs / quotient leaves
     pub zero_knowledge: u32,
+    /// CommonCircuitData.num_public_inputs: proofs carrying any other count are rejected (plonk/validate_shape.rs:22-25)
+    pub num_public_inputs: u32,
 }
 
 /// One entry of CommonCircuitData.gates with selectors_info flattened in (include/goldibear_gpu.h: gb_gate, GB_GATE_*).

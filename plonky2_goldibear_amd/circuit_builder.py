@@ -726,7 +726,7 @@ class BuiltCircuit:
                                     rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, proof_of_work_bits=cfg.proof_of_work_bits,
                                     num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits,
                                     final_poly_bits=cfg.final_poly_bits, num_selectors=num_selectors, field=cfg.field,
-                                    gates=gate_table)
+                                    gates=gate_table, num_public_inputs=len(public_inputs))
 
     def generate_witness(self, pw, rng=None):
         """generate_partial_witness + full_witness (iop/generator.rs:25-117, iop/witness.rs:359-371)

@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void k_gate_constraints(GateParams<F> p, const
 // per-challenge sums meet in LDS (in the staging area, once every wave is done with it) and wave 0 writes them.  Two such
 // workgroups fit a CU's 160 KiB: 4 waves per SIMD, as before.  Same arithmetic, same order inside a gate; sums of field elements.
 struct TiledPlan {
-    u32 nw, ncs;                         // wire columns / selector + constant columns staged
+    u32 nw, ncs;                         // wire columns / selector + constant columns staged (nw: what the gates read, never
+                                         // more than the wires block holds)
+    u32 area;                            // columns of the wire area in LDS: max(nw, room for the partial sums)
     unsigned char wave_of[gates::MAX_GATES];
 };
 static constexpr u32 TILED_WAVES = 8;
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(64 * TILED_WAVES) void k_gate_constraints_tiled(Gat
     typedef gates::BaseAlg<F> A;
     extern __shared__ unsigned char smem_raw[];
     T* shw = reinterpret_cast<T*>(smem_raw);          // [nw][64]
-    T* shc = shw + (size_t)plan.nw * 64;              // [ncs][64]
+    T* shc = shw + (size_t)plan.area * 64;            // [ncs][64]
     T* red = shw;                                     // [TILED_WAVES - 1][C][64] partial sums, over the wires once they are dead
     const u32 lgn = p.log_n, r = p.rate_bits;
     const size_t n = (size_t)1 << lgn, N = n << r;
@@ -206,9 +208,10 @@ static bool make_tiled_plan(const GateParams<F>& p, TiledPlan* plan, size_t* sme
         plan->wave_of[cost[i].second] = (unsigned char)w;
         load[w] += cost[i].first;
     }
-    plan->nw = std::max(nw, (TILED_WAVES - 1) * p.num_challenges);   // the partial sums reuse the wire area
+    plan->nw = nw;                                                     // staged from `wires`: only columns a gate reads
+    plan->area = std::max(nw, (TILED_WAVES - 1) * p.num_challenges);   // the partial sums reuse the wire area
     plan->ncs = p.gs.num_selectors + nconst;
-    *smem_bytes = ((size_t)plan->nw + plan->ncs) * 64 * sizeof(typename F::T);
+    *smem_bytes = ((size_t)plan->area + plan->ncs) * 64 * sizeof(typename F::T);
     return *smem_bytes <= 150 * 1024;   // 160 KiB of LDS per CU
 }
 

@@ -22,7 +22,7 @@ class gb_circuit_config(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in (
         "field", "degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges",
         "max_quotient_degree_factor", "rate_bits", "cap_height", "proof_of_work_bits", "num_query_rounds",
-        "arity_bits", "final_poly_bits", "num_selectors", "gate_constant", "gate_pi", "zero_knowledge")]
+        "arity_bits", "final_poly_bits", "num_selectors", "gate_constant", "gate_pi", "zero_knowledge", "num_public_inputs")]
 
 
 class gb_gate(C.Structure):
@@ -68,7 +68,7 @@ class CircuitData(_ProofBytesOps):
     def __init__(self, ctx, degree_bits, constants_sigmas, k_is, *, num_wires=135, num_routed_wires=80, num_constants=2,
                  num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16,
                  num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1, gate_constant=1, gate_pi=2,
-                 field=N.GB_GOLDILOCKS, gates=None, zero_knowledge=False):
+                 field=N.GB_GOLDILOCKS, gates=None, zero_knowledge=False, num_public_inputs=0):
         """`gates` = None: the dummy circuit's gate set, given by the selector values gate_constant / gate_pi
         (gb_circuit_create).  Otherwise CommonCircuitData.gates with selectors_info, one tuple
         (kind, param, selector_index, group_start, group_end) per gate in sorted order (gb_circuit_create_gates; what
@@ -79,7 +79,7 @@ class CircuitData(_ProofBytesOps):
         self.cfg = gb_circuit_config(field, degree_bits, num_wires, num_routed_wires, num_constants, num_challenges,
                                      max_quotient_degree_factor, rate_bits, cap_height, proof_of_work_bits,
                                      num_query_rounds, arity_bits, final_poly_bits, num_selectors, gate_constant, gate_pi,
-                                     1 if zero_knowledge else 0)
+                                     1 if zero_knowledge else 0, num_public_inputs)
         ptr, shape, flags, keep = _as_input(constants_sigmas, field)
         want = (num_selectors + num_constants + num_routed_wires, 1 << degree_bits)
         if tuple(shape) != want:
@@ -190,7 +190,7 @@ class VerifierCircuitData(_ProofBytesOps):
     def __init__(self, degree_bits, gates, k_is, constants_sigmas_cap, circuit_digest, *, num_wires=135, num_routed_wires=80,
                  num_constants=2, num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4,
                  proof_of_work_bits=16, num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1,
-                 zero_knowledge=False, field=N.GB_GOLDILOCKS):
+                 zero_knowledge=False, field=N.GB_GOLDILOCKS, num_public_inputs=0):
         """`gates`: (kind, param, selector_index, group_start, group_end[, param2, param3]) per gate, sorted as in
         CommonCircuitData.gates; num_constants counts the constant columns after the selectors."""
         self._lib = N.load()
@@ -198,7 +198,8 @@ class VerifierCircuitData(_ProofBytesOps):
         hout = 4 if field == N.GB_GOLDILOCKS else 8
         self.cfg = gb_circuit_config(field, degree_bits, num_wires, num_routed_wires, num_constants, num_challenges,
                                      max_quotient_degree_factor, rate_bits, cap_height, proof_of_work_bits, num_query_rounds,
-                                     arity_bits, final_poly_bits, num_selectors, 0, 0, 1 if zero_knowledge else 0)
+                                     arity_bits, final_poly_bits, num_selectors, 0, 0, 1 if zero_knowledge else 0,
+                                     num_public_inputs)
         k = np.ascontiguousarray(k_is, dtype=self._dt)
         cap = np.ascontiguousarray(constants_sigmas_cap, dtype=self._dt)
         dig = np.ascontiguousarray(circuit_digest, dtype=self._dt)

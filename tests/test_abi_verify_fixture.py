@@ -28,7 +28,7 @@ def _fixture_circuit(golden_dir, **override):
               num_challenges=cfg["num_challenges"], max_quotient_degree_factor=cd["quotient_degree_factor"],
               rate_bits=fc["rate_bits"], cap_height=fc["cap_height"], proof_of_work_bits=fc["proof_of_work_bits"],
               num_query_rounds=fc["num_query_rounds"], arity_bits=4, final_poly_bits=5, num_selectors=nsel,
-              zero_knowledge=cd["fri_params"]["hiding"])
+              zero_knowledge=cd["fri_params"]["hiding"], num_public_inputs=cd["num_public_inputs"])
     kw.update(override)
     circ = VerifierCircuitData(cd["fri_params"]["degree_bits"], kw.pop("gates", gates), np.array(cd["k_is"], dtype=np.uint64),
                                np.array(vd["constants_sigmas_cap"], dtype=np.uint64),
@@ -84,3 +84,28 @@ def test_malformed_path_lengths_are_rejected_not_read(golden_dir):
         circ.verify(bad)
     with pytest.raises(N.ShapeError, match="wrong length"):
         circ.compress(bad)
+
+
+def test_public_input_count_is_checked(golden_dir):
+    """plonk/validate_shape.rs:22-25: hash_no_pad does not pad, so the reference's proof re-serialised with a zero public
+    input appended (or, for a circuit whose last public input is zero, stripped) keeps its transcript and its PublicInputGate
+    constraint - only the count check rejects it.  Same for the compressed form, which carries no count at all."""
+    circ, cd, raw = _fixture_circuit(golden_dir)
+    proof, pis = V.read_proof_with_pis(raw, cd)
+    assert len(pis) == cd["num_public_inputs"]
+    padded = V.write_proof_with_pis(proof, list(pis) + [0])
+    with pytest.raises(N.ShapeError, match="public inputs"):
+        circ.verify(padded)
+    two, _, _ = _fixture_circuit(golden_dir, num_public_inputs=2)   # the stripped direction: [0, 0] -> [0] -> []
+    with pytest.raises(N.ShapeError, match="public inputs"):
+        two.verify(V.write_proof_with_pis(proof, [0]))
+    small = circ.compress(raw)
+    assert circ.verify_compressed(small)
+    with pytest.raises(N.ShapeError, match="public inputs"):
+        circ.verify_compressed(small + bytes(8))
+    with pytest.raises(N.ShapeError, match="public inputs"):
+        circ.decompress(small + bytes(8))
+    # a verifier told the wrong count refuses the honest proof
+    other, _, _ = _fixture_circuit(golden_dir, num_public_inputs=cd["num_public_inputs"] + 1)
+    with pytest.raises(N.ShapeError, match="public inputs"):
+        other.verify(raw)

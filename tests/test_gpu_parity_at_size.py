@@ -1,0 +1,94 @@
+"""Parity AT THE BASELINE SIZES, bit for bit, through the C ABI.  -m gpu only.
+
+* prove(): GPU proof BYTES == the CPU oracle prover's at 2^16 rows (BASELINE configs[1] size), 2^18 rows and
+  2^20 rows (configs[2] Goldilocks num_challenges 3; configs[3] BabyBear num_challenges 10) - the claim
+  north_star makes ("bit-exact against the reference CPU prover's Proof bytes", plonk/prover.rs:228-447).
+* PolynomialBatch::from_values (fri/oracle.rs:68-123) at n = 2^20, N = 2^23: EVERY coefficient, EVERY leaf of every
+  column, EVERY digest and the cap against the oracle's batch - this is the only size that runs the 2^20-row NTT kernels
+  (k_gl_lde_pa16x2 / k_bb_lde_pa16x2), so a sampled check is not enough there.
+The oracle needs about a minute per 2^20-row proof on the GPU box's 16 host cores."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import oracle_bb as B
+from oracle import plonk_dummy as D
+from oracle.fields import BB, GL
+from plonky2_goldibear_amd import GB_BABYBEAR, CircuitData, GpuContext, PolynomialBatch
+from plonky2_goldibear_amd import native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    O.use_host_cpu_share()
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _gpu_circuit(ctx, circ, tag):
+    cfg = circ.cfg
+    return CircuitData(ctx, circ.degree_bits, circ.constants_sigmas, circ.k_is, num_wires=cfg.num_wires,
+                       num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
+                       num_challenges=cfg.num_challenges, max_quotient_degree_factor=cfg.max_quotient_degree_factor,
+                       rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, proof_of_work_bits=cfg.proof_of_work_bits,
+                       num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits,
+                       gate_constant=circ.GATE_CONSTANT, gate_pi=circ.GATE_PI, field=tag)
+
+
+@pytest.mark.parametrize("field_name,degree_bits,num_challenges", [
+    ("goldilocks", 16, 3), ("babybear", 16, 7), ("goldilocks", 18, 3), ("babybear", 18, 8),
+    ("goldilocks", 20, 3), ("babybear", 20, 10),
+])
+def test_proof_bytes_match_oracle_at_size(ctx, field_name, degree_bits, num_challenges):
+    if field_name == "goldilocks":
+        F, tag, cfg = GL, N.GB_GOLDILOCKS, D.CircuitConfig(num_challenges=num_challenges)
+    else:
+        F, tag, cfg = BB, N.GB_BABYBEAR, D.CircuitConfig.babybear(num_challenges)
+    circ = D.DummyCircuit(degree_bits, cfg, F=F)
+    gpu = _gpu_circuit(ctx, circ, tag)
+    # the oracle prover commits constants||sigmas itself (the build() share); only the digest is taken from the GPU cap here,
+    # and the proof bytes below depend on the oracle's own commitment through the openings and the query rounds
+    circ.set_cap(gpu.constants_sigmas_cap)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    w = circ.witness(seed=degree_bits)
+    got = gpu.prove(w)
+    want, _ = D.prove_cpu(circ, w)
+    assert len(got) == len(want)
+    assert got == want, "first differing byte at %d" % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    assert gpu.verify(got)
+    gpu.free()
+    ctx.trim()
+
+
+@pytest.mark.parametrize("field_name", ["goldilocks", "babybear"])
+def test_full_batch_2pow20_every_leaf_and_digest(ctx, field_name):
+    """n = 2^20, rate 3, cap 4, 9 columns (two sponge absorptions per leaf for Goldilocks, a ragged second one for both):
+    the whole batch against the oracle."""
+    log_n, ncols = 20, 9
+    seed = 0xC0FFEE ^ (ncols << 32) ^ log_n
+    if field_name == "goldilocks":
+        vals = O.splitmix64_fill(seed, ncols << log_n).reshape(ncols, 1 << log_n)
+        cpu = O.PolynomialBatch.from_values(vals, 3, 4)
+        gpu = PolynomialBatch.from_values(ctx, vals, 3, 4)
+    else:
+        vals = B.fill(seed, ncols << log_n).reshape(ncols, 1 << log_n)
+        cpu = B.PolynomialBatch.from_values(vals, 3, 4)
+        gpu = PolynomialBatch.from_values(ctx, vals, 3, 4, field=GB_BABYBEAR)
+    assert (gpu.merkle_tree.cap == cpu.cap).all()
+    assert (gpu.polynomials == cpu.polynomials).all()
+    leaves = gpu.merkle_tree.leaves
+    assert leaves.shape == cpu.leaves.shape == (1 << 23, ncols)
+    bad = np.flatnonzero((leaves != cpu.leaves).any(axis=1))
+    assert bad.size == 0, "%d leaves differ, first %d" % (bad.size, bad[0])
+    del leaves
+    dig = gpu.merkle_tree.digests
+    assert dig.shape == cpu.digests.shape
+    assert (dig == cpu.digests).all()
+    # the prover's view of the same data (plonk/prover.rs:822-831)
+    for i in (0, 1, (1 << 20) - 1, 777777):
+        assert (gpu.get_lde_values(i, 8) == cpu.get_lde_values(i, 8)).all()
+    gpu.free()
+    ctx.trim()
