@@ -3,22 +3,32 @@
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident
-in HBM.  Workload `prove` (default, BASELINE.json configs[2]): one full prove() of the 2^20-row
-Goldilocks dummy circuit (num_challenges = 3) from a device-resident
-MatrixWitness to ProofWithPublicInputs bytes, constants/sigmas commitment pre-resident
-(plonk/prover.rs:228-447).  Workload `commit` = PolynomialBatch::from_values on the wires matrix
-only (135 columns, rate 3, cap 4 - fri/oracle.rs:68-123 as called at plonk/prover.rs:261-272).
-Independent circuits shard one per GPU: every rank runs the same workload on its own device,
-no data-path collective ("scaling": "weak").  The roofline object prices the NTT pass (the IFFT
-+ LDE kernels) against the 8 TB/s HBM peak with SURVEY.md 8(d)'s algorithmic bytes; the
-cpu_baseline object times the CPU oracle (a restatement of the reference algorithm, "port") on
-a bounded sample on rank 0's host cores.
+A "step" is one full prove() (plonk/prover.rs:228-447) of the 2^20-row dummy circuit (BASELINE.json configs[2]:
+Goldilocks, standard_recursion_config_gl with num_challenges = 3) from a MatrixWitness to ProofWithPublicInputs
+bytes, constants/sigmas commitment pre-resident as after build().
+
+`value` is the proofs/s SURVEY.md 8(d) and BASELINE.md define: the witness is a (page-locked) HOST array handed over
+every step, as the drop-in boundary hands it over.  `value_hbm_resident` is the same circuit proved from a witness that
+is already resident in HBM when the timed region starts (the other boundary the task statement names); both are
+timed the same way (W warm-up steps, barrier, exactly K steps, barrier, max over ranks) in the same run.
+
+Objects in the line:
+  roofline      NTT pass (IFFT + LDE kernels of every commitment of a step) against the 8 TB/s HBM peak with
+                SURVEY.md 8(d)'s algorithmic bytes; durations from HIP events on the context's stream.
+  roofline_alu  the dominant kernel, k_gl_merkle_leaves (Poseidon-12 leaf sponges): VALU wave-instructions per second
+                (instructions per permutation from SQ_INSTS_VALU, profiles/r*_poseidon_valu_*.json) against the SIMD
+                issue peak of /opt/skills/guides/MI355X_MICROARCH.md (one wave64 VALU instruction per 2 cycles per SIMD).
+  babybear      BASELINE configs[3] (2^20 rows, BabyBear + Poseidon2-16, num_challenges 10), same measurements, N = 1 only.
+  cpu_baseline  the CPU oracle prover (a restatement of the reference algorithm, "port") on a bounded sample, rank 0, N = 1.
+Independent circuits shard one per GPU: every rank proves its own circuit, no data-path collective ("scaling": "weak").
+`--workload commit` = PolynomialBatch::from_values on the wires matrix only (fri/oracle.rs:68-123).
 """
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -28,7 +38,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32; a wave64 VALU op issues over 2 cycles (same guide)
 GL_P = 0xFFFFFFFF00000001
+SCOPES = ("IFFT", "FFT + blinding", "build Merkle tree", "hash leaves", "compute wires commitment", "compute partial products",
+          "compute quotient polys", "construct the opening set", "compute opening proofs", "find proof-of-work witness",
+          "fri query rounds")
 
 
 def splitmix64_matrix(seed, rows, cols):
@@ -88,6 +102,190 @@ def cpu_baseline_prove(log_n, num_challenges, sample_log_n, field="goldilocks"):
     }
 
 
+def _num(x):
+    """JSON has no NaN: unavailable figures are null."""
+    return None if x is None or x != x or x in (float("inf"), float("-inf")) else x
+
+
+def _latest_profile(pattern):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))  # r01e_..., r02_...: newest round last
+    return json.load(open(paths[-1])) if paths else None
+
+
+class ProveLeg:
+    """One field's circuit on this rank's GPU: build() once, then timed prove() steps from a host or an HBM-resident witness."""
+
+    def __init__(self, field, log_n, challenges, local_rank, rank, inflight, ctx):
+        import torch
+        from plonky2_goldibear_amd import CircuitData, GpuContext
+        from plonky2_goldibear_amd import dummy_circuit as DC
+        self.torch, self.field, self.log_n, self.rank, self.inflight = torch, field, log_n, rank, inflight
+        self.bb = bb = field == "babybear"
+        if challenges is None:  # the minimum the reference's security assert allows (circuit_builder.rs:1190-1192)
+            challenges = max(6 if bb else 2, -(-100 // ((31 if bb else 64) - log_n)))
+        self.challenges = challenges
+        # per-field circuit shape: standard_recursion_config_gl / recursion_config_bb_narrow (circuit_data.rs:102-139)
+        self.nwires, self.nrouted, self.arity_bits, self.ext_d, self.esz = (167, 41, 3, 4, 4) if bb else (135, 80, 4, 2, 8)
+        self.idt = np.int32 if bb else np.int64
+        self.dev = "cuda:%d" % local_rank
+        cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(log_n) if bb else DC.build_dummy_circuit(log_n)
+        cs_dev = torch.from_numpy(cs.view(self.idt)).to(self.dev)
+        self.lanes = []  # one (context, circuit, host witness) per proof in flight: independent circuits, as across GPUs
+        self.extra_ctx = []
+        for li in range(inflight):
+            lctx = ctx if li == 0 else GpuContext(local_rank)
+            if li:
+                self.extra_ctx.append(lctx)
+            if bb:  # build(): once per circuit
+                circuit = CircuitData.babybear(lctx, log_n, cs_dev, k_is, num_challenges=challenges)
+                wit = DC.dummy_witness_bb(log_n, pi_row, seed=rank * inflight + li)
+            else:
+                circuit = CircuitData(lctx, log_n, cs_dev, k_is, num_challenges=challenges)
+                wit = DC.dummy_witness(log_n, pi_row, seed=rank * inflight + li)
+            self.lanes.append([lctx, circuit, wit, None])
+        # prove_with_partition_witness's retry loop (plonk/prover.rs:183-226): on InvZeroPermArg the random wire - last
+        # wire of the PublicInputGate row - is re-drawn and the proof redone; failed attempts stay inside the timed region
+        self.random_wire = (self.nwires - 1, pi_row)
+        self.ctx = ctx
+        self.proof, self.proof_len, self.retries = None, 0, 0
+        del cs, cs_dev
+        torch.cuda.synchronize()
+
+    def set_witness(self, host):
+        """host=True: page-locked host memory, as a host that wants the PCIe rate allocates it (hipHostMalloc); False: HBM."""
+        for lane in self.lanes:
+            t = self.torch.from_numpy(lane[2].view(self.idt))
+            lane[3] = t.pin_memory().numpy().view(lane[2].dtype) if host else t.to(self.dev)
+        self.torch.cuda.synchronize()
+
+    def step(self):
+        if self.inflight == 1:
+            lctx, circuit, _, wit = self.lanes[0]
+            self.proof = circuit.prove(wit, random_wire=self.random_wire, rng=self.rng[0])
+            self.retries += circuit.perm_arg_retries
+        else:
+            out, ret = [None] * self.inflight, [0] * self.inflight
+
+            def run(i):
+                out[i] = self.lanes[i][1].prove(self.lanes[i][3], random_wire=self.random_wire, rng=self.rng[i])
+                ret[i] = self.lanes[i][1].perm_arg_retries
+            ts = [threading.Thread(target=run, args=(i,)) for i in range(self.inflight)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            self.proof = out[0]
+            self.retries += sum(ret)
+        self.proof_len = len(self.proof)
+
+    def barrier(self):
+        from plonky2_goldibear_amd import sharding
+        self.ctx.synchronize()
+        for c in self.extra_ctx:
+            c.synchronize()
+        self.torch.cuda.synchronize()
+        sharding.barrier()
+
+    def timed(self, steps, warmup, host):
+        """W untimed steps, then exactly K steps between barriers; returns (seconds = max over ranks, scopes, retries)."""
+        from plonky2_goldibear_amd import sharding
+        self.set_witness(host)
+        self.rng = [np.random.default_rng(1234 + self.rank * self.inflight + i) for i in range(self.inflight)]
+        for _ in range(warmup):
+            self.step()
+        self.retries = 0
+        if self.inflight == 1:
+            self.ctx.set_profiling(True)  # per-scope HIP events; with several proofs in flight scopes overlap, so only wall time
+        self.ctx.scope_reset()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        dt = sharding.max_over_ranks(time.perf_counter() - t0)  # whole job = the slowest rank
+        scopes = {s: self.ctx.scope_ms(s) for s in SCOPES}
+        self.ctx.set_profiling(False)
+        return dt, scopes, self.retries
+
+    def verify_last(self):
+        """outside the timed region: the library's own host-side verifier (gb_verify) on lane 0's last proof"""
+        return bool(self.lanes[0][1].verify(self.proof)) if self.proof is not None else None
+
+    def counts(self, rate_bits=3, cap_height=4):
+        """algorithmic NTT bytes and Poseidon permutations of one proof"""
+        n, N, c = 1 << self.log_n, (1 << self.log_n) << rate_bits, self.challenges
+        nzs, nq = c * (-(-self.nrouted // 8)), c * 8  # Z + partial products, quotient chunks
+        # from_values (2 + 2^r) n s per column (wires, zs/pp), from_coeffs (1 + 2^r) n s (quotient chunks), + the final
+        # polynomial's D coordinate columns; the quotient's per-coset inverse NTTs and the small FRI layers are not counted
+        alg_bytes = ((2 + 8) * (self.nwires + nzs) + (1 + 8) * (nq + self.ext_d)) * n * self.esz
+        nlayers, db = 0, self.log_n
+        while db > 5 and db + rate_bits - self.arity_bits >= cap_height:  # fri/reduction_strategies.rs:44-56
+            nlayers, db = nlayers + 1, db - self.arity_bits
+        leaf_perms = sum(N * (-(-w // 8)) for w in (self.nwires, nzs, nq))   # the three big trees' leaf sponges ("hash leaves")
+        perms = leaf_perms + 3 * (N - 16) + sum(
+            (N >> (self.arity_bits * (l + 1))) * ((self.ext_d << self.arity_bits) // 8) + ((N >> (self.arity_bits * (l + 1))) - 16)
+            for l in range(nlayers))
+        return alg_bytes, perms, leaf_perms, nzs, nq
+
+    def report(self, steps, scopes, inflight):
+        """roofline / roofline_alu / merkle objects of one timed region"""
+        bb, fname = self.bb, self.field
+        alg_bytes, perms, leaf_perms, nzs, nq = self.counts()
+        live = inflight == 1
+        ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps if live else None
+        merkle_ms = scopes["build Merkle tree"][0] / steps if live else None
+        leaves_ms = scopes["hash leaves"][0] / steps if live else None
+        achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None
+        traffic = None  # physical HBM bytes per column from rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/*.json)
+        tj = _latest_profile("r*_ntt_traffic_pmc_%s.json" % fname)
+        if self.log_n == 20 and tj:
+            traffic = tj["ifft_bytes_per_column"] * (self.nwires + nzs) + tj["lde_bytes_per_column"] * (self.nwires + nzs + nq + self.ext_d)
+        out = {
+            "roofline": {"bound": "hbm", "kernel": "NTT pass = %s (IFFT) + %s (FFT + blinding), all commitments of the step" % (
+                             ("k_bb_intt16_*", "k_bb_lde_pa16*+pb16") if bb else ("k_gl_intt16_*", "k_gl_lde_pa16*+pb16")),
+                         "achieved": _num(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": _num(achieved / HBM_PEAK_GBS if achieved else None), "traffic": traffic,
+                         "algorithmic_bytes": alg_bytes, "ms": _num(ntt_ms)},
+            "merkle": {"permutations": perms, "Gperm_per_s": _num(perms / (merkle_ms * 1e-3) / 1e9 if merkle_ms else None),
+                       "ms": _num(merkle_ms)},
+        }
+        # ALU roofline of the dominant kernel: leaf sponges.  VALU instructions per permutation come from SQ_INSTS_VALU / grid
+        # (PMC pass, tools/pmc_poseidon.py); the peak is the SIMD issue rate (one wave64 VALU instruction per 2 cycles per SIMD).
+        pj = _latest_profile("r*_poseidon_valu_%s.json" % fname)
+        peak = SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9   # G wave-instructions / s
+        alu = {"bound": "valu-issue", "kernel": "k_bb_merkle_leaves" if bb else "k_gl_merkle_leaves",
+               "unit": "G wave-instr/s", "peak": peak, "leaf_permutations": leaf_perms, "ms": _num(leaves_ms),
+               "Gperm_per_s": _num(leaf_perms / (leaves_ms * 1e-3) / 1e9 if leaves_ms else None),
+               "achieved": None, "frac": None, "valu_instr_per_permutation": None}
+        if pj and leaves_ms:
+            ipp = pj["valu_instr_per_permutation"]
+            ach = ipp * leaf_perms / 64.0 / (leaves_ms * 1e-3) / 1e9
+            alu.update({"valu_instr_per_permutation": ipp, "achieved": ach, "frac": ach / peak,
+                        "issue_cost_floor_frac": pj.get("issue_cost_floor_frac"), "source": pj.get("source_file")})
+        out["roofline_alu"] = alu
+        return out
+
+    def free(self):
+        for lane in self.lanes:
+            lane[1].free()
+            lane[3] = None
+        for c in self.extra_ctx:
+            c.close()
+        self.lanes, self.extra_ctx = [], []
+        self.ctx.trim()
+        self.torch.cuda.empty_cache()
+
+
+def workload_name(leg, witness):
+    return ("prove(): 2^%d-row %s dummy circuit (2^%d+1 NoopGates), %s with num_challenges=%d, %s, witness %s -> proof bytes "
+            "(%d B)" % (leg.log_n, "BabyBear" if leg.bb else "Goldilocks", leg.log_n - 1,
+                        "recursion_config_bb_narrow" if leg.bb else "standard_recursion_config_gl", leg.challenges,
+                        "Poseidon2-16" if leg.bb else "Poseidon-12", witness, leg.proof_len))
+
+
+HOST_W = "in page-locked host memory, handed over every step"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,9 +303,9 @@ def main():
     ap.add_argument("--cols", type=int, default=135)
     ap.add_argument("--cpu-sample-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-witness", action="store_true",
-                    help="prove workload: hand the witness over as a HOST array every step (the drop-in boundary's case: 1.05 GiB "
-                         "across PCIe per Goldilocks proof); the default keeps it resident in HBM, which is what `value` is quoted on")
+    ap.add_argument("--no-babybear", action="store_true", help="skip the BASELINE configs[3] leg of the default run")
+    ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident-witness leg (value_hbm_resident)")
+    ap.add_argument("--host-witness", action="store_true", help="(default since round 2; kept for old command lines)")
     args = ap.parse_args()
 
     import torch
@@ -130,74 +328,67 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from plonky2_goldibear_amd import CircuitData, GpuContext, PolynomialBatch, sharding
-    from plonky2_goldibear_amd import dummy_circuit as DC
+    from plonky2_goldibear_amd import GpuContext, PolynomialBatch, sharding
 
-    ncols, log_n, rate_bits, cap_height = args.cols, args.log_n, 3, 4
-    n = 1 << log_n
-    bb = args.field == "babybear"
-    if args.challenges is None:
-        bits = 31 if bb else 64
-        args.challenges = max(6 if bb else 2, -(-100 // (bits - log_n)))
-    # per-field circuit shape: standard_recursion_config_gl / recursion_config_bb_narrow (circuit_data.rs:102-139)
-    nwires, nrouted, arity_bits, ext_d, esz = (167, 41, 3, 4, 4) if bb else (135, 80, 4, 2, 8)
+    log_n, rate_bits, cap_height = args.log_n, 3, 4
     ctx = GpuContext(local_rank)
-    proof_len = 0
-    inflight = max(1, args.inflight) if args.workload == "prove" else 1
-    extra_ctx = []
+    out = None
     if args.workload == "prove":
-        import threading
-        ncols = nwires
-        idt = np.int32 if bb else np.int64
-        cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(log_n) if bb else DC.build_dummy_circuit(log_n)
-        cs_dev = torch.from_numpy(cs.view(idt)).to("cuda:%d" % local_rank)
-        lanes = []  # one (context, circuit, witness) per proof in flight: independent circuits, as across GPUs
-        for li in range(inflight):
-            lctx = ctx if li == 0 else GpuContext(local_rank)
-            if li:
-                extra_ctx.append(lctx)
-            if bb:  # build(): once per circuit
-                circuit = CircuitData.babybear(lctx, log_n, cs_dev, k_is, num_challenges=args.challenges)
-                wit = DC.dummy_witness_bb(log_n, pi_row, seed=rank * inflight + li)
-            else:
-                circuit = CircuitData(lctx, log_n, cs_dev, k_is, num_challenges=args.challenges)
-                wit = DC.dummy_witness(log_n, pi_row, seed=rank * inflight + li)
-            if args.host_witness:   # page-locked, as a host that wants the PCIe rate would allocate it (hipHostMalloc)
-                wit_in = torch.from_numpy(wit.view(idt)).pin_memory().numpy().view(wit.dtype)
-            else:
-                wit_in = torch.from_numpy(wit.view(idt)).to("cuda:%d" % local_rank)
-            lanes.append((lctx, circuit, wit_in))
-        # prove_with_partition_witness's retry loop (plonk/prover.rs:183-226): on InvZeroPermArg the random wire - last
-        # wire of the PublicInputGate row - is re-drawn and the proof redone; failed attempts stay inside the timed region
-        random_wire = (nwires - 1, pi_row)
-        rng = np.random.default_rng(1234 + rank)
-        retries = [0]
-        last_proof = [None]
-        del cs, cs_dev, wit
-        torch.cuda.synchronize()
-
-        def step():
-            nonlocal proof_len
-            if inflight == 1:
-                last_proof[0] = lanes[0][1].prove(lanes[0][2], random_wire=random_wire, rng=rng)
-                proof_len = len(last_proof[0])
-                retries[0] += lanes[0][1].perm_arg_retries
-                return
-            out = [0] * inflight
-
-            def run(i):
-                out[i] = len(lanes[i][1].prove(lanes[i][2], random_wire=random_wire, rng=np.random.default_rng(99 + i)))
-            ts = [threading.Thread(target=run, args=(i,)) for i in range(inflight)]
-            for t in ts:
-                t.start()
-            for t in ts:
-                t.join()
-            proof_len = out[0]
+        inflight = max(1, args.inflight)
+        steps = args.steps
+        leg = ProveLeg(args.field, log_n, args.challenges, local_rank, rank, inflight, ctx)
+        dt, scopes, retries = leg.timed(steps, args.warmup, host=True)
+        if rank == 0:
+            out = {
+                "metric": "proofs/s", "value": world * steps * inflight / dt, "unit": "proofs/s", "n_gpus": world, "steps": steps,
+                "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u32" if leg.bb else "u64", "data": "synthetic",
+                "config": {"workload": workload_name(leg, HOST_W), "field": args.field, "log_n": log_n, "rate_bits": rate_bits,
+                           "cap_height": cap_height, "proofs_in_flight_per_gpu": inflight, "witness": HOST_W,
+                           "sharding": "one independent circuit per GPU, no collective"},
+            }
+            out.update(leg.report(steps, scopes, inflight))
+            out["scopes_ms_per_step"] = {k: v[0] / steps for k, v in scopes.items() if v[1]}
+            out["verified"] = leg.verify_last()
+            out["perm_arg_retries"] = retries  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
+        if not args.no_resident:
+            dt2, scopes2, _ = leg.timed(steps, args.warmup, host=False)
+            if rank == 0:
+                out["value_hbm_resident"] = world * steps * inflight / dt2
+                out["ms_per_step_hbm_resident"] = dt2 / steps * 1e3
+        leg.free()
+        del leg
+        if args.field == "goldilocks" and world == 1 and not args.no_babybear and log_n == 20:
+            # BASELINE configs[3]: the same measurements for BabyBear + Poseidon2-16 (a 31-bit field needs num_challenges = 10)
+            bleg = ProveLeg("babybear", log_n, None, local_rank, rank, inflight, ctx)
+            bdt, bscopes, bret = bleg.timed(steps, args.warmup, host=True)
+            bb = {"metric": "proofs/s", "value": steps * inflight / bdt, "ms_per_step": bdt / steps * 1e3, "dtype": "u32",
+                  "config": {"workload": workload_name(bleg, HOST_W), "witness": HOST_W}}
+            bb.update(bleg.report(steps, bscopes, inflight))
+            bb["scopes_ms_per_step"] = {k: v[0] / steps for k, v in bscopes.items() if v[1]}
+            bb["verified"] = bleg.verify_last()
+            bb["perm_arg_retries"] = bret
+            if not args.no_resident:
+                bdt2, _, _ = bleg.timed(steps, args.warmup, host=False)
+                bb["value_hbm_resident"] = steps * inflight / bdt2
+                bb["ms_per_step_hbm_resident"] = bdt2 / steps * 1e3
+            bleg.free()
+            out["babybear"] = bb
+        if rank == 0 and not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the driver's contract)
+            from oracle import oracle as _O
+            cores = _O.host_cpu_share()
+            bbf = args.field == "babybear"
+            sample = args.cpu_sample_log_n
+            if sample is None:
+                sample = max(8, min(log_n, 19 if bbf else 18, (15 if bbf else 14) + (cores.bit_length() - 1)))  # ~10-30 s of CPU work
+            ch = args.challenges or max(6 if bbf else 2, -(-100 // ((31 if bbf else 64) - log_n)))
+            out["cpu_baseline"] = cpu_baseline_prove(log_n, ch, sample, args.field)
     else:
+        ncols, n = args.cols, 1 << log_n
         host = splitmix64_matrix((0xC0FFEE ^ (ncols << 32) ^ log_n) + rank, ncols, n)
-        ftag = 0
+        ftag, esz = 0, 8
         if args.field == "babybear":
-            ftag = 1
+            ftag, esz = 1, 4
             host = (host % np.uint64(2013265921)).astype(np.uint32)
             dev = torch.from_numpy(host.view(np.int32)).to("cuda:%d" % local_rank)
         else:
@@ -209,107 +400,56 @@ def main():
             b = PolynomialBatch.from_values(ctx, dev, rate_bits, cap_height, field=ftag)
             b.free()
 
-    def barrier():
-        ctx.synchronize()
-        for c in extra_ctx:
-            c.synchronize()
-        torch.cuda.synchronize()
-        sharding.barrier()
+        def barrier():
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            sharding.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    if args.workload == "prove":
-        retries[0] = 0
-    if inflight == 1:
-        ctx.set_profiling(True)  # per-scope HIP events; with several proofs in flight scopes overlap, so only wall time
-    ctx.scope_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0)  # whole job = the slowest rank
-
-    scope_names = ("IFFT", "FFT + blinding", "build Merkle tree", "compute wires commitment", "compute partial products",
-                   "compute quotient polys", "construct the opening set", "compute opening proofs",
-                   "find proof-of-work witness", "fri query rounds")
-    scopes = {s: ctx.scope_ms(s) for s in scope_names}
-    ctx.set_profiling(False)
-    units_per_step = inflight
-
-    if rank == 0:
-        steps = args.steps
-        ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps or float("nan")
-        merkle_ms = scopes["build Merkle tree"][0] / steps or float("nan")
-        N = n << rate_bits
-        if args.workload == "prove":
-            c = args.challenges
-            nzs, nq = c * (-(-nrouted // 8)), c * 8  # Z + partial products, quotient chunks
-            # from_values (2 + 2^r) n s per column (wires, zs/pp), from_coeffs (1 + 2^r) n s (quotient
-            # chunks), + the final polynomial's D coordinate columns; the quotient's per-coset inverse NTTs and the
-            # small FRI layers are not counted (conservative)
-            alg_bytes = ((2 + 8) * (nwires + nzs) + (1 + 8) * (nq + ext_d)) * n * esz
-            nlayers, db = 0, log_n
-            while db > 5 and db + rate_bits - arity_bits >= cap_height:  # fri/reduction_strategies.rs:44-56
-                nlayers, db = nlayers + 1, db - arity_bits
-            perms = sum(N * (-(-w // 8)) + (N - 16) for w in (nwires, nzs, nq)) + sum(
-                (N >> (arity_bits * (l + 1))) * ((ext_d << arity_bits) // 8) + ((N >> (arity_bits * (l + 1))) - 16)
-                for l in range(nlayers))
-            metric = "proofs/s"
-            workload = ("prove(): 2^%d-row %s dummy circuit (2^%d+1 NoopGates), %s with num_challenges=%d, %s, witness "
-                        "resident in HBM -> proof bytes (%d B)" % (
-                            log_n, "BabyBear" if bb else "Goldilocks", log_n - 1,
-                            "recursion_config_bb_narrow" if bb else "standard_recursion_config_gl", c,
-                            "Poseidon2-16" if bb else "Poseidon-12", proof_len))
-        else:
+        for _ in range(args.warmup):
+            step()
+        ctx.set_profiling(True)
+        ctx.scope_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = sharding.max_over_ranks(time.perf_counter() - t0)
+        scopes = {s: ctx.scope_ms(s) for s in SCOPES}
+        ctx.set_profiling(False)
+        if rank == 0:
+            steps, N = args.steps, n << rate_bits
+            ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps
+            merkle_ms = scopes["build Merkle tree"][0] / steps
             alg_bytes = (2 + (1 << rate_bits)) * n * esz * ncols  # (2 + 2^r) n s per column
             perms = N * (-(-ncols // 8)) + (N - (1 << cap_height))  # leaf sponge + internal nodes
+            achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None
+            tj = _latest_profile("r*_ntt_traffic_pmc_%s.json" % args.field)
+            traffic = (tj["ifft_bytes_per_column"] + tj["lde_bytes_per_column"]) * ncols if (tj and log_n == 20) else None
             metric = "commits/s (PolynomialBatch::from_values, wires oracle of the 2^%d-row circuit)" % log_n
-            workload = "from_values: %d cols x 2^%d rows %s, rate_bits 3, cap_height 4, %s" % (
-                ncols, log_n, args.field, "Poseidon2-16" if args.field == "babybear" else "Poseidon-12")
-        achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
-        # physical HBM bytes per column, measured with rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/*.json)
-        traffic = None
-        import glob
-        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ntt_traffic_pmc_%s.json" % args.field)))  # newest round last
-        if log_n == 20 and tpaths:
-            tj = json.load(open(tpaths[-1]))
-            if args.workload == "prove":
-                traffic = tj["ifft_bytes_per_column"] * (nwires + nzs) + tj["lde_bytes_per_column"] * (nwires + nzs + nq + ext_d)
-            else:
-                traffic = (tj["ifft_bytes_per_column"] + tj["lde_bytes_per_column"]) * ncols
-        out = {
-            "metric": metric, "value": world * steps * units_per_step / dt, "unit": metric.split(" ")[0], "n_gpus": world, "steps": steps,
-            "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32" if args.field == "babybear" else "u64", "data": "synthetic",
-            "config": {"workload": workload, "field": args.field, "log_n": log_n, "rate_bits": rate_bits,
-                       "cap_height": cap_height, "proofs_in_flight_per_gpu": inflight,
-                       "witness": "page-locked host memory, copied in every step" if getattr(args, "host_witness", False) else "resident in HBM",
-                       "sharding": "one independent circuit per GPU, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "NTT pass = %s (IFFT) + %s (FFT + blinding), all commitments of the step" % (
-                             ("k_bb_intt_p1+p2+p3", "k_bb_lde_pa+pb") if bb else ("k_gl_intt16_p1+p2+p3", "k_gl_lde_pa16+pb16")),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "ms": ntt_ms},
-            "scopes_ms_per_step": {k: v[0] / steps for k, v in scopes.items() if v[1]},
-            "merkle": {"permutations": perms, "Gperm_per_s": perms / (merkle_ms * 1e-3) / 1e9},
-        }
-        if args.workload == "prove":
-            if last_proof[0] is not None:  # outside the timed region: the library's own host-side verifier (gb_verify)
-                out["verified"] = bool(lanes[0][1].verify(last_proof[0]))
-            out["perm_arg_retries"] = retries[0]  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the driver's contract)
-            sample = args.cpu_sample_log_n
-            from oracle import oracle as _O
-            cores = _O.host_cpu_share()
-            if args.workload == "prove":
-                if sample is None:
-                    sample = max(8, min(log_n, 19 if bb else 18, (15 if bb else 14) + (cores.bit_length() - 1)))  # ~10-30 s of CPU work
-                out["cpu_baseline"] = cpu_baseline_prove(log_n, args.challenges, sample, args.field)
-            else:
+            out = {
+                "metric": metric, "value": world * steps / dt, "unit": "commits/s", "n_gpus": world, "steps": steps,
+                "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u32" if ftag else "u64", "data": "synthetic",
+                "config": {"workload": "from_values: %d cols x 2^%d rows %s, rate_bits 3, cap_height 4, %s, input resident in HBM" % (
+                               ncols, log_n, args.field, "Poseidon2-16" if ftag else "Poseidon-12"),
+                           "field": args.field, "log_n": log_n, "rate_bits": rate_bits, "cap_height": cap_height,
+                           "sharding": "one independent batch per GPU, no collective"},
+                "roofline": {"bound": "hbm", "kernel": "NTT pass (IFFT + FFT + blinding scopes)", "achieved": _num(achieved),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _num(achieved / HBM_PEAK_GBS if achieved else None),
+                             "traffic": traffic, "algorithmic_bytes": alg_bytes, "ms": _num(ntt_ms)},
+                "scopes_ms_per_step": {k: v[0] / steps for k, v in scopes.items() if v[1]},
+                "merkle": {"permutations": perms, "Gperm_per_s": _num(perms / (merkle_ms * 1e-3) / 1e9 if merkle_ms else None)},
+            }
+            if not args.no_cpu_baseline and world == 1:
+                from oracle import oracle as _O
+                cores = _O.host_cpu_share()
+                sample = args.cpu_sample_log_n
                 if sample is None:
                     sample = max(10, min(log_n, 19, 13 + (cores.bit_length() - 1)))
                 out["cpu_baseline"] = cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample)
-        print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out, allow_nan=False))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

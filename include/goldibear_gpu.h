@@ -16,7 +16,11 @@
  *  - field elements are canonical little-endian u64 (Goldilocks) / u32 (BabyBear);
  *  - matrices are COLUMN-MAJOR [ncols][n]: the layout of Vec<PolynomialValues<F>>
  *    (iop/witness.rs:277-284) with the per-column Vecs laid end to end;
- *  - gb_batch is an opaque device-resident handle; nothing large is copied back unless asked.
+ *  - gb_batch is an opaque device-resident handle; nothing large is copied back unless asked;
+ *  - host input buffers (`cols`, `salts`, `witness`, `constants_sigmas`, ...) belong to the caller again as soon as the call
+ *    returns (the reference moves its Vecs in): gb_commit_* wait for their uploads - not for the kernels behind them - before
+ *    returning, gb_prove / gb_circuit_create end on a synchronised read-back.  Device inputs (GB_INPUT_DEVICE) are read by
+ *    kernels enqueued on the context's stream and must stay valid until gb_ctx_synchronize or any read-back on that context.
  */
 #ifndef GOLDIBEAR_GPU_H
 #define GOLDIBEAR_GPU_H
@@ -186,6 +190,10 @@ typedef struct gb_gate {
 } gb_gate;
 gb_status gb_circuit_create_gates(gb_ctx* ctx, const gb_circuit_config* cfg, const gb_gate* gates, uint32_t num_gates,
                                   const void* constants_sigmas, const void* k_is, uint32_t flags, gb_circuit** out);
+/* ProverOnlyCircuitData.constants_sigmas_commitment (plonk/circuit_data.rs:532-534), the PolynomialBatch built by
+ * gb_circuit_create*: a BORROWED handle - owned by the circuit, valid until gb_circuit_free, never passed to gb_batch_free.  The
+ * reference's prover reads it for the opening set (plonk/proof.rs:359-377) and the query rounds. */
+gb_status gb_circuit_constants_sigmas_commitment(gb_circuit* c, gb_batch** out);
 /* VerifierOnlyCircuitData: constants_sigmas_cap [2^cap_height][H] and circuit_digest [H], field elements */
 gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_out);
 /* prove_with_partition_witness -> internal_prove_with_partition_witness (plonk/prover.rs:160-447):
@@ -234,6 +242,44 @@ gb_status gb_verify_compressed(gb_circuit* c, const void* compressed, size_t com
  * RECURSIVE_VERIFIER_GL regression proof (recursion/regression_test_data.rs) through it.  Free with gb_circuit_free. */
 gb_status gb_verifier_create(gb_ctx* ctx, const gb_circuit_config* cfg, const gb_gate* gates, uint32_t num_gates, const void* k_is,
                              const void* constants_sigmas_cap, const void* circuit_digest, gb_circuit** out);
+
+/* ---- the stages of prove(), one at a time ---------------------------------------------------------------------------------
+ * For a host that keeps the reference's prover loop (plonk/prover.rs:228-447) and its Challenger and swaps in the heavy calls
+ * one by one: wires / Zs / quotient commitments through gb_commit_values / gb_commit_coeffs, the opening set through
+ * gb_batch_eval_ext, and the three functions below.  gb_prove is exactly this sequence with the transcript kept inside the
+ * library (tests/test_gpu_stage_abi.py drives the stages from Python with the oracle's Challenger and gets gb_prove's bytes).
+ * Challenges are canonical field elements, host pointers.  Results are canonical; `flags` (GB_INPUT_HOST / GB_INPUT_DEVICE) names
+ * the memory space of the large operand AND of the result buffer. */
+
+/* wires_permutation_partial_products_and_zs + all_wires_permutation_partial_products (plonk/prover.rs:449-546): witness =
+ * wire_values [num_wires][n] (only the routed columns are read); betas, gammas: [num_challenges].  values_out:
+ * [num_challenges * (1 + num_partial_products)][n] VALUES on H_n in the order prover.rs:318-329 hands them to from_values - every
+ * challenge's Z first, then each challenge's partial products.  GB_ERR_PERM_ARG_ZERO = ProverError::InvZeroPermArg (:512-514). */
+gb_status gb_zs_partial_products(gb_circuit* c, const void* witness, uint32_t flags, const void* betas, const void* gammas,
+                                 void* values_out);
+/* compute_quotient_polys (plonk/prover.rs:712-926) followed by the split into degree-n chunks (:345-376).  wires and
+ * zs_partial_products are the commitments of the same proof (gb_commit_values of the witness / of gb_zs_partial_products' output),
+ * made on this circuit's context; public_inputs_hash: [H]; betas, gammas, alphas: [num_challenges].  chunks_out:
+ * [num_challenges * quotient_degree_factor][n] COEFFICIENTS, ready for gb_commit_coeffs (:376-387). */
+gb_status gb_quotient_polys(gb_circuit* c, gb_batch* wires, gb_batch* zs_partial_products, const void* public_inputs_hash,
+                            const void* betas, const void* gammas, const void* alphas, uint32_t flags, void* chunks_out);
+/* Challenger<F, H> (iop/challenger.rs:18-31) by value: sponge_state (SPONGE_WIDTH = 12 / 16 words used), input_buffer and
+ * output_buffer (at most SPONGE_RATE = 8 each; challenges pop from the END of output_buffer, :84-94).  Canonical values as u64 for
+ * either field. */
+typedef struct gb_challenger_state {
+    uint64_t sponge_state[16];
+    uint64_t input_buffer[8];
+    uint64_t output_buffer[8];
+    uint32_t input_len, output_len;
+} gb_challenger_state;
+/* PolynomialBatch::prove_openings (fri/oracle.rs:187-246) on the PLONK instance of this circuit (get_fri_instance(zeta),
+ * plonk/circuit_data.rs:438-520: constants/sigmas, wires, Zs / partial products, quotient - the Zs also at g * zeta) followed by
+ * fri_proof (fri/prover.rs:29-81): commit phase, proof of work (the MINIMUM nonce), query rounds.  zeta: [D]; `challenger` is the
+ * transcript after observe_openings (plonk/prover.rs:418) and is left as the reference leaves it.  fri_proof_out receives the
+ * FriProof bytes (util/serialization/mod.rs:1679-1695): commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness -
+ * the part of ProofWithPublicInputs between the opening set and the public inputs; *fri_proof_len is the size needed. */
+gb_status gb_prove_openings(gb_circuit* c, gb_batch* wires, gb_batch* zs_partial_products, gb_batch* quotient, const void* zeta,
+                            gb_challenger_state* challenger, void* fri_proof_out, size_t fri_proof_cap, size_t* fri_proof_len);
 
 /* fri_proof_of_work (fri/prover.rs:136-188) on its own, for a host that keeps the Challenger: sponge_state is the
  * duplex state with the pending input buffer already written over lanes 0..witness_pos-1 (`duplex_intermediate_state`,

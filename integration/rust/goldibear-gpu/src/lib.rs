@@ -59,6 +59,18 @@ pub struct gb_gate {
     pub param3: u32,
 }
 
+/// Challenger<F, H> by value (iop/challenger.rs:18-31) for `gb_prove_openings`: canonical values as u64 for either field;
+/// challenges pop from the END of `output_buffer`.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct gb_challenger_state {
+    pub sponge_state: [u64; 16],
+    pub input_buffer: [u64; 8],
+    pub output_buffer: [u64; 8],
+    pub input_len: u32,
+    pub output_len: u32,
+}
+
 extern "C" {
     fn gb_ctx_create(device: i32, out: *mut *mut gb_ctx) -> i32;
     fn gb_ctx_destroy(ctx: *mut gb_ctx) -> i32;
@@ -80,6 +92,15 @@ extern "C" {
     fn gb_prove(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
                 proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
     fn gb_verify(c: *mut gb_circuit, proof: *const c_void, proof_len: usize) -> i32;
+    fn gb_circuit_constants_sigmas_commitment(c: *mut gb_circuit, out: *mut *mut gb_batch) -> i32;
+    fn gb_zs_partial_products(c: *mut gb_circuit, witness: *const c_void, flags: u32, betas: *const c_void, gammas: *const c_void,
+                              values_out: *mut c_void) -> i32;
+    fn gb_quotient_polys(c: *mut gb_circuit, wires: *mut gb_batch, zs_partial_products: *mut gb_batch,
+                         public_inputs_hash: *const c_void, betas: *const c_void, gammas: *const c_void, alphas: *const c_void,
+                         flags: u32, chunks_out: *mut c_void) -> i32;
+    fn gb_prove_openings(c: *mut gb_circuit, wires: *mut gb_batch, zs_partial_products: *mut gb_batch, quotient: *mut gb_batch,
+                         zeta: *const c_void, challenger: *mut gb_challenger_state, fri_proof_out: *mut c_void,
+                         fri_proof_cap: usize, fri_proof_len: *mut usize) -> i32;
     fn gb_circuit_create_gates(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, gates: *const gb_gate, num_gates: u32,
                                constants_sigmas: *const c_void, k_is: *const c_void, flags: u32, out: *mut *mut gb_circuit) -> i32;
     fn gb_prove_salted(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
@@ -316,6 +337,54 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         check(self.ctx.0, st)?;
         buf.truncate(len);
         Ok(ProveOutcome::Proof(buf))
+    }
+    /// `wires_permutation_partial_products_and_zs` for every challenge (plonk/prover.rs:305-329, 449-546): the values handed to
+    /// `PolynomialBatch::from_values`, Zs first.  `Ok(None)` = `ProverError::InvZeroPermArg`.
+    pub fn zs_partial_products(&self, witness: &[W], betas: &[W], gammas: &[W]) -> Result<Option<Vec<W>>, GpuError> {
+        let c = &self.config;
+        let chunks = (c.num_routed_wires + c.max_quotient_degree_factor - 1) / c.max_quotient_degree_factor;
+        let mut out = vec![W::default(); (c.num_challenges * chunks) as usize << c.degree_bits];
+        let st = unsafe {
+            gb_zs_partial_products(self.handle, witness.as_ptr() as *const c_void, GB_INPUT_HOST, betas.as_ptr() as *const c_void,
+                                   gammas.as_ptr() as *const c_void, out.as_mut_ptr() as *mut c_void)
+        };
+        if st == GB_ERR_PERM_ARG_ZERO {
+            return Ok(None);
+        }
+        check(self.ctx.0, st)?;
+        Ok(Some(out))
+    }
+    /// `compute_quotient_polys` + the split into chunks (plonk/prover.rs:345-376): coefficients for `from_coeffs`
+    pub fn quotient_polys(&self, wires: &GpuPolynomialBatch<'c, W>, zs_partial_products: &GpuPolynomialBatch<'c, W>,
+                          public_inputs_hash: &[W], betas: &[W], gammas: &[W], alphas: &[W]) -> Result<Vec<W>, GpuError> {
+        let c = &self.config;
+        let mut out = vec![W::default(); (c.num_challenges * c.max_quotient_degree_factor) as usize << c.degree_bits];
+        check(self.ctx.0, unsafe {
+            gb_quotient_polys(self.handle, wires.handle, zs_partial_products.handle, public_inputs_hash.as_ptr() as *const c_void,
+                              betas.as_ptr() as *const c_void, gammas.as_ptr() as *const c_void, alphas.as_ptr() as *const c_void,
+                              GB_INPUT_HOST, out.as_mut_ptr() as *mut c_void)
+        })?;
+        Ok(out)
+    }
+    /// `PolynomialBatch::prove_openings` on this circuit's FRI instance (fri/oracle.rs:187-246): FriProof bytes; `challenger`
+    /// (the transcript after observe_openings) is advanced as the reference's is.
+    pub fn prove_openings(&self, wires: &GpuPolynomialBatch<'c, W>, zs_partial_products: &GpuPolynomialBatch<'c, W>,
+                          quotient: &GpuPolynomialBatch<'c, W>, zeta: &[W], challenger: &mut gb_challenger_state)
+                          -> Result<Vec<u8>, GpuError> {
+        let mut buf = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        check(self.ctx.0, unsafe {
+            gb_prove_openings(self.handle, wires.handle, zs_partial_products.handle, quotient.handle, zeta.as_ptr() as *const c_void,
+                              challenger, buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
+        })?;
+        buf.truncate(len);
+        Ok(buf)
+    }
+    /// `prover_data.constants_sigmas_commitment`: borrowed from the circuit, for `eval_ext` / `get_lde_values`
+    pub fn constants_sigmas_commitment_handle(&self) -> Result<*mut gb_batch, GpuError> {
+        let mut h = ptr::null_mut();
+        check(self.ctx.0, unsafe { gb_circuit_constants_sigmas_commitment(self.handle, &mut h) })?;
+        Ok(h)
     }
     /// `CircuitData::verify` for the gate sets the library evaluates, on the host: Ok(true), Ok(false) when a check fails
     pub fn verify(&self, proof: &[u8]) -> Result<bool, GpuError> {

@@ -211,8 +211,10 @@ class CommonDataCircuit(DummyCircuit):
         return self._cd
 
 
-def prove_cpu(circ, witness, public_inputs=(), salts=None):
-    """Run the CPU oracle prover; returns (proof_bytes, debug challenges).  `salts`: None, or for a zero-knowledge circuit
+def prove_cpu(circ, witness, public_inputs=(), salts=None, dump=None):
+    """Run the CPU oracle prover; returns (proof_bytes, debug challenges).  `dump`: a dict that receives the prover's own
+    intermediates - "zs_partial_products" [c * (1 + num_partial_products)][n] values as handed to from_values (prover.rs:318-329)
+    and "quotient_chunks" [c * quotient_degree_factor][n] coefficients as handed to from_coeffs (:361-376).  `salts`: None, or for a zero-knowledge circuit
     (circ.zero_knowledge) the [3][4][N] salt columns of the wires / Zs / quotient commitments in LDE-point order - the values
     the reference draws with F::rand_vec (fri/oracle.rs:144-148), a host input here."""
     L = O.lib()
@@ -228,6 +230,11 @@ def prove_cpu(circ, witness, public_inputs=(), salts=None):
     if salts is not None:
         salts = np.ascontiguousarray(salts, dtype=F.dtype)
         assert salts.shape == (3, 4, circ.n << circ.cfg.rate_bits)
+    if dump is not None:
+        dump["zs_partial_products"] = np.zeros((c * (1 + circ.num_partial_products), circ.n), dtype=F.dtype)
+        dump["quotient_chunks"] = np.zeros((c * circ.cfg.max_quotient_degree_factor, circ.n), dtype=F.dtype)
+        getattr(L, F.prove_symbol + "_set_dump")(dump["zs_partial_products"].ctypes.data_as(C.c_void_p),
+                                                 dump["quotient_chunks"].ctypes.data_as(C.c_void_p))
     cap = 64 << 20
     out = np.zeros(cap, dtype=np.uint8)
     out_len = C.c_size_t()
@@ -236,6 +243,8 @@ def prove_cpu(circ, witness, public_inputs=(), salts=None):
             wit.ctypes.data_as(C.c_void_p), pis.ctypes.data_as(C.c_void_p), C.c_size_t(len(public_inputs)),
             out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p),
             salts.ctypes.data_as(C.c_void_p) if salts is not None else None)
+    if dump is not None:
+        getattr(L, F.prove_symbol + "_set_dump")(None, None)
     if rc != 0:
         raise RuntimeError("oracle prover failed: rc=%d" % rc)
     prove_cpu.last_cs_commit_seconds = C.c_double.in_dll(L, "gbo_last_cs_commit_seconds").value  # build() share of the call

@@ -104,6 +104,14 @@ static E_T eval_base_poly_ext(const F_T *c, size_t n, E_T z) {
     return acc;
 }
 
+/* Test hook: when set, the next proofs copy their intermediate values out - the Z / partial-product VALUES handed to
+ * from_values (prover.rs:318-329) and the quotient chunk COEFFICIENTS handed to from_coeffs (:361-376) - so that the GPU's
+ * stage-level entry points can be compared with the oracle prover's own intermediates (tests/test_gpu_stage_abi.py). */
+static F_T *dump_zs_values = NULL, *dump_quotient_chunks = NULL;
+#define X_CAT2(a, b) a##b
+#define X_CAT(a, b) X_CAT2(a, b)
+void X_CAT(X_PROVE_DUMMY, _set_dump)(F_T *zs_values, F_T *quotient_chunks) { dump_zs_values = zs_values; dump_quotient_chunks = quotient_chunks; }
+
 /* Status: 0 ok, 1 = InvZeroPermArg (plonk/prover.rs:512-514), 2 = opening point in subgroup, <0 internal */
 int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs][n] values*/,
                        const F_T *circuit_digest, const F_T *k_is, const F_T *witness /*[num_wires][n]*/,
@@ -198,6 +206,7 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
     }
     if (rc) goto done_early;
     GBO_SCOPE("Z and partial products");
+    if (dump_zs_values) memcpy(dump_zs_values, zs_vals, nzs * n * sizeof(F_T));
     if ((rc = batch_commit(&zs, zs_vals, nzs, lg, r, capH, 0, salts ? salts + 4 * N : NULL))) goto done_early;    /* prover.rs:328-339 */
     X_CH_OBSERVE(&ch, zs.cap, (size_t)HOUT << capH);
     for (unsigned i = 0; i < c; i++) alphas[i] = X_CH_GET(&ch);
@@ -296,6 +305,7 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
         memcpy(qchunks + (size_t)k * qdf * n, qvals + (size_t)k * N, (size_t)qdf * n * sizeof(F_T));
     }
     GBO_SCOPE("quotient values + coset_ifft");
+    if (dump_quotient_chunks) memcpy(dump_quotient_chunks, qchunks, (size_t)c * qdf * n * sizeof(F_T));
     if ((rc = batch_commit(&quot, qchunks, (size_t)c * qdf, lg, r, capH, 1, salts ? salts + 8 * N : NULL))) goto done;   /* prover.rs:376-387 */
     X_CH_OBSERVE(&ch, quot.cap, (size_t)HOUT << capH);
     E_T zeta = challenger_ext(&ch);

@@ -74,6 +74,8 @@ struct gb_ctx {
     std::multimap<size_t, void*> pool;                      // freed batch blocks by size (stream-ordered reuse)
     DeviceBuf scratch;                                      // grow-only workspace
     DeviceBuf small;                                        // small gather staging (rows, siblings)
+    hipEvent_t upload_mark = nullptr;                       // recorded on `stream` after the last host -> device copy of a commit
+    bool upload_marked = false;
 };
 
 struct gb_batch {
@@ -116,6 +118,25 @@ struct Scope {
         ctx->scopes[name].spans.emplace_back(a, b);
     }
 };
+
+// Host inputs of the public commit entry points stay the caller's only until the call returns (the reference moves its Vecs in):
+// commit() marks the last host -> device copy it enqueues on the main stream, and gb_commit_* wait for that mark and for the copy
+// stream before returning - the kernels behind the copies keep running asynchronously.
+void mark_upload(gb_ctx* ctx) {
+    if (!ctx->upload_mark && hipEventCreateWithFlags(&ctx->upload_mark, hipEventDisableTiming) != hipSuccess) {
+        ctx->upload_mark = nullptr;
+        (void)hipStreamSynchronize(ctx->stream);   // no event to wait on later: wait here
+        return;
+    }
+    if (hipEventRecord(ctx->upload_mark, ctx->stream) == hipSuccess) ctx->upload_marked = true;
+    else (void)hipStreamSynchronize(ctx->stream);
+}
+gb_status wait_uploads(gb_ctx* ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->copy_stream);
+    if (e == hipSuccess && ctx->upload_marked) e = hipEventSynchronize(ctx->upload_mark);
+    ctx->upload_marked = false;
+    return e == hipSuccess ? GB_OK : fail(ctx, GB_ERR_HIP, "waiting for the upload of the host input failed");
+}
 
 gb_status ensure(gb_ctx* ctx, DeviceBuf& buf, size_t bytes) {
     if (buf.bytes >= bytes) return GB_OK;
@@ -418,6 +439,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         } else if (!dev_in) {
             if (hipMemcpyAsync(scr, cols, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+            mark_upload(ctx);
             in_dev = scr;
         }
         if (staged) {
@@ -439,6 +461,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
                 if (!dev_in) {
                     if (hipMemcpyAsync(scr, salts, (size_t)nsalt * N * 4, hipMemcpyHostToDevice, st) != hipSuccess)
                         return cleanup(fail(ctx, GB_ERR_HIP, "copy of salts failed"));
+                    mark_upload(ctx);
                     sdev = scr;
                 }
                 gbk::bb_bitrev_copy_to_mont(sdev, lde + ncols * N, log_N, nsalt, st);
@@ -447,7 +470,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         {
             Scope sc(ctx, "build Merkle tree");
             u32* lv = (u32*)b->levels;
-            gbk::bb_merkle_leaves(lde, N, (u32)width, N, lv, st);
+            { Scope sl(ctx, "hash leaves"); gbk::bb_merkle_leaves(lde, N, (u32)width, N, lv, st); }
             for (u32 k = 0; k < log_N - cap_height; k++)
                 gbk::bb_merkle_level(lv + 8 * level_offset(N, k), lv + 8 * level_offset(N, k + 1), N >> (k + 1), st);
         }
@@ -486,6 +509,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         if (hipMemcpyAsync(b->coeffs, cols, ncols * n * sizeof(u64), dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            st) != hipSuccess)
             return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+        if (!dev_in) mark_upload(ctx);
         src = b->coeffs;
     }
     if (!is_coeffs && !staged) {
@@ -504,6 +528,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
                 if ((s = ensure(ctx, ctx->scratch, nsalt * N * sizeof(u64)))) return cleanup(s);
                 if (hipMemcpyAsync(ctx->scratch.p, salts, nsalt * N * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess)
                     return cleanup(fail(ctx, GB_ERR_HIP, "copy of salts failed"));
+                mark_upload(ctx);
                 sdev = (const u64*)ctx->scratch.p;
             }
             gbk::u64_bitrev_copy(sdev, b->lde + ncols * N, log_N, nsalt, st);
@@ -511,7 +536,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     }
     {
         Scope sc(ctx, "build Merkle tree");
-        gbk::gl_merkle_leaves(b->lde, N, (u32)width, N, b->levels, st);
+        { Scope sl(ctx, "hash leaves"); gbk::gl_merkle_leaves(b->lde, N, (u32)width, N, b->levels, st); }
         for (u32 k = 0; k < log_N - cap_height; k++)
             gbk::gl_merkle_level(b->levels + 4 * level_offset(N, k), b->levels + 4 * level_offset(N, k + 1), N >> (k + 1), st);
     }
@@ -558,6 +583,7 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     if (ctx->tw4096_inv) hipFree(ctx->tw4096_inv);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->small.p) hipFree(ctx->small.p);
+    if (ctx->upload_mark) hipEventDestroy(ctx->upload_mark);
     for (auto& kv : ctx->pool) hipFree(kv.second);
     hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
@@ -627,12 +653,16 @@ gb_status gb_ctx_scope_reset(gb_ctx* ctx) {
 
 gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                            uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
-    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, false, out);
+    gb_status s = commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, false, out);
+    if (s == GB_OK && !(flags & GB_INPUT_DEVICE)) s = wait_uploads(ctx);   // `cols` / `salts` are the caller's again on return
+    return s;
 }
 
 gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                            uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
-    return commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, true, out);
+    gb_status s = commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, true, out);
+    if (s == GB_OK && !(flags & GB_INPUT_DEVICE)) s = wait_uploads(ctx);
+    return s;
 }
 
 gb_status gb_batch_free(gb_batch* b) {

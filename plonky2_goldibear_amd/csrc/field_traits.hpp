@@ -21,6 +21,7 @@ struct GlF {
     typedef u64 T;
     typedef gl::ext2 E;
     static constexpr u32 D = 2, H = 4, SPONGE_W = 12, ORDER_BITS = 64, TWO_ADICITY = 32, TAG = 0;
+    static constexpr u64 ORDER = gl::P;
     static GB_HD T zero() { return 0; }
     static GB_HD T one() { return 1; }
     static GB_HD T enc(u64 canonical) { return canonical; }
@@ -65,6 +66,7 @@ struct BbF {
     typedef u32 T;
     typedef bb_ext4 E;
     static constexpr u32 D = 4, H = 8, SPONGE_W = 16, ORDER_BITS = 31, TWO_ADICITY = 27, TAG = 1;
+    static constexpr u64 ORDER = bb::P;
     static constexpr u32 W_MONT = (u32)((11ull << 32) % bb::P);  // the non-residue 11 in Montgomery form
     static GB_HD T zero() { return 0; }
     static GB_HD T one() { return bb::R1; }

@@ -51,6 +51,10 @@ SIGNATURES = {
     "gb_circuit_create_gates": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _pvp]),
     "gb_circuit_free": (_i32, [_vp]),
     "gb_circuit_verifier_data": (_i32, [_vp, _vp, _vp]),
+    "gb_circuit_constants_sigmas_commitment": (_i32, [_vp, _pvp]),
+    "gb_zs_partial_products": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "gb_quotient_polys": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "gb_prove_openings": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "gb_prove": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "gb_prove_salted": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
 }

@@ -150,8 +150,9 @@ class MerkleTree:
 class PolynomialBatch:
     """fri/oracle.rs:29-158 with the data resident on the GPU."""
 
-    def __init__(self, ctx, handle):
+    def __init__(self, ctx, handle, borrowed=False):
         self.ctx, self.handle, self._lib = ctx, handle, ctx._lib
+        self._borrowed = borrowed   # owned by a circuit object (its constants_sigmas_commitment): never freed here
         f, nc, dl, rb, ch, bl = C.c_uint32(), C.c_size_t(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         N.check(self._lib.gb_batch_info(handle, C.byref(f), C.byref(nc), C.byref(dl), C.byref(rb), C.byref(ch), C.byref(bl)))
         self.field, self.num_polys, self.degree_log = f.value, nc.value, dl.value
@@ -193,7 +194,7 @@ class PolynomialBatch:
         return cls._commit("gb_commit_coeffs", ctx, coeffs, rate_bits, cap_height, salts, field)
 
     def free(self):
-        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None) and not self._borrowed:
             self._lib.gb_batch_free(self.handle)
         self.handle = None
 

@@ -25,6 +25,12 @@ class gb_circuit_config(C.Structure):
         "arity_bits", "final_poly_bits", "num_selectors", "gate_constant", "gate_pi", "zero_knowledge", "num_public_inputs")]
 
 
+class gb_challenger_state(C.Structure):
+    """Challenger<F, H> by value (iop/challenger.rs:18-31); include/goldibear_gpu.h"""
+    _fields_ = [("sponge_state", C.c_uint64 * 16), ("input_buffer", C.c_uint64 * 8), ("output_buffer", C.c_uint64 * 8),
+                ("input_len", C.c_uint32), ("output_len", C.c_uint32)]
+
+
 class gb_gate(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("kind", "param", "selector_index", "group_start", "group_end", "param2", "param3")]
 
@@ -165,6 +171,88 @@ class CircuitData(_ProofBytesOps):
         N.check(st, self.ctx.handle)
         del keep
         return self._proof_buf[: n.value].tobytes()
+
+    @property
+    def constants_sigmas_commitment(self):
+        """ProverOnlyCircuitData.constants_sigmas_commitment (plonk/circuit_data.rs:532-534): a PolynomialBatch view that the
+        circuit keeps owning."""
+        from .polynomial_batch import PolynomialBatch
+        h = C.c_void_p()
+        N.check(self._lib.gb_circuit_constants_sigmas_commitment(self.handle, C.byref(h)), self.ctx.handle)
+        return PolynomialBatch(self.ctx, h, borrowed=True)
+
+    # ---- the stages of prove() one at a time, for a host that keeps the reference's prover loop and Challenger
+    def _nzs(self):
+        c = self.cfg
+        return c.num_challenges * (-(-c.num_routed_wires // c.max_quotient_degree_factor))
+
+    def _challenges(self, xs):
+        a = np.ascontiguousarray(xs, dtype=self._dt)
+        if a.shape != (self.cfg.num_challenges,):
+            raise N.ShapeError(N.GB_ERR_INVALID, "expected num_challenges field elements")
+        return a
+
+    def zs_partial_products(self, witness, betas, gammas):
+        """wires_permutation_partial_products_and_zs for every challenge (plonk/prover.rs:305-329, 449-546) ->
+        [num_challenges * (1 + num_partial_products)][n] values, Zs first; host array for a host witness, device tensor for a
+        device one.  Raises PermArgZeroError (InvZeroPermArg)."""
+        ptr, shape, flags, keep = _as_input(witness, self.field)
+        n = 1 << self.cfg.degree_bits
+        if tuple(shape) != (self.cfg.num_wires, n):
+            raise N.ShapeError(N.GB_ERR_INVALID, "witness must be [num_wires][n]")
+        b, g = self._challenges(betas), self._challenges(gammas)
+        if flags == N.GB_INPUT_DEVICE:
+            import torch
+            out = torch.empty((self._nzs(), n), dtype=witness.dtype, device=witness.device)
+            optr = out.data_ptr()
+        else:
+            out = np.empty((self._nzs(), n), dtype=self._dt)
+            optr = out.ctypes.data
+        N.check(self._lib.gb_zs_partial_products(self.handle, ptr, flags, b.ctypes.data, g.ctypes.data, optr), self.ctx.handle)
+        del keep
+        return out
+
+    def quotient_polys(self, wires, zs_partial_products, public_inputs_hash, betas, gammas, alphas):
+        """compute_quotient_polys + the split into chunks (plonk/prover.rs:345-376, 712-926): `wires` / `zs_partial_products` are
+        the PolynomialBatch commitments of this proof -> [num_challenges * quotient_degree_factor][n] coefficients (host)."""
+        hout = 4 if self.field == N.GB_GOLDILOCKS else 8
+        ph = np.ascontiguousarray(public_inputs_hash, dtype=self._dt)
+        if ph.shape != (hout,):
+            raise N.ShapeError(N.GB_ERR_INVALID, "public_inputs_hash must have NUM_HASH_OUT_ELTS elements")
+        b, g, a = self._challenges(betas), self._challenges(gammas), self._challenges(alphas)
+        out = np.empty((self.cfg.num_challenges * self.cfg.max_quotient_degree_factor, 1 << self.cfg.degree_bits), dtype=self._dt)
+        N.check(self._lib.gb_quotient_polys(self.handle, wires.handle, zs_partial_products.handle, ph.ctypes.data, b.ctypes.data,
+                                            g.ctypes.data, a.ctypes.data, N.GB_INPUT_HOST, out.ctypes.data), self.ctx.handle)
+        return out
+
+    def prove_openings(self, wires, zs_partial_products, quotient, zeta, challenger):
+        """PolynomialBatch::prove_openings on this circuit's FRI instance (fri/oracle.rs:187-246, plonk/prover.rs:422-437).
+        `challenger` = (sponge_state, input_buffer, output_buffer) after observe_openings, canonical ints.
+        -> (FriProof bytes, challenger afterwards in the same form)"""
+        d = 2 if self.field == N.GB_GOLDILOCKS else 4
+        z = np.ascontiguousarray(zeta, dtype=self._dt)
+        if z.shape != (d,):
+            raise N.ShapeError(N.GB_ERR_INVALID, "zeta must have %d coordinates" % d)
+        st, inp, outb = challenger
+        w = 12 if self.field == N.GB_GOLDILOCKS else 16
+        if len(st) != w or len(inp) > 8 or len(outb) > 8:
+            raise N.ShapeError(N.GB_ERR_INVALID, "challenger state has the wrong shape")
+        cs = gb_challenger_state()
+        for i, v in enumerate(st):
+            cs.sponge_state[i] = int(v)
+        for i, v in enumerate(inp):
+            cs.input_buffer[i] = int(v)
+        for i, v in enumerate(outb):
+            cs.output_buffer[i] = int(v)
+        cs.input_len, cs.output_len = len(inp), len(outb)
+        if self._proof_buf is None:
+            self._proof_buf = np.empty(8 << 20, dtype=np.uint8)
+        n = C.c_size_t()
+        N.check(self._lib.gb_prove_openings(self.handle, wires.handle, zs_partial_products.handle, quotient.handle, z.ctypes.data,
+                                            C.byref(cs), self._proof_buf.ctypes.data, self._proof_buf.size, C.byref(n)), self.ctx.handle)
+        after = ([int(cs.sponge_state[i]) for i in range(w)], [int(cs.input_buffer[i]) for i in range(cs.input_len)],
+                 [int(cs.output_buffer[i]) for i in range(cs.output_len)])
+        return self._proof_buf[: n.value].tobytes(), after
 
     def verify(self, proof_bytes):
         """CircuitData::verify (plonk/circuit_data.rs:290-300 -> plonk/verifier.rs:17-128): True, or raises VerifyError naming
