@@ -396,6 +396,33 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
 
     gb_status s;
     hipStream_t st = ctx->stream;
+    // Host input of a big batch: the leaf sponges run in segments of SEG columns as the columns arrive (chunked upload below), so
+    // that the hashing - most of a commitment's time - overlaps the PCIe transfer instead of waiting for its end; the sponge state
+    // waits in `seg_state` between segments (kernels_merkle.hip / kernels_bb.hip: k_*_merkle_leaves).
+    constexpr u32 SEG = 32;
+    const bool segmented = !dev_in && !is_coeffs && log_N >= 19 && ncols > SEG;
+    u32 seg_done = 0;
+    void* seg_state = nullptr;
+    const size_t seg_state_bytes = field == GB_GOLDILOCKS ? 12 * N * sizeof(u64) : 16 * N * sizeof(u32);
+    struct SegGuard {
+        gb_ctx* ctx; void** p; size_t bytes;
+        ~SegGuard() { if (*p) pool_free(ctx, *p, bytes); }
+    } seg_guard{ctx, &seg_state, seg_state_bytes};
+    auto hash_ready_segments = [&](size_t cols_ready) -> bool {   // every full segment that is not the last one
+        while (segmented && seg_done + SEG < ncols && seg_done + SEG <= cols_ready) {
+            if (!seg_state && pool_alloc(ctx, seg_state_bytes, &seg_state) != hipSuccess) { seg_state = nullptr; return false; }
+            Scope sm(ctx, "build Merkle tree");
+            Scope sl(ctx, "hash leaves");
+            const u32 next_cols = (u32)(width - (seg_done + SEG));
+            if (field == GB_GOLDILOCKS)
+                gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, seg_done + SEG, N, (u64*)seg_state, false, next_cols, b->levels, st);
+            else
+                gbk::bb_merkle_leaves_segment((const u32*)b->lde, N, seg_done, seg_done + SEG, N, (u32*)seg_state, false, next_cols,
+                                              (u32*)b->levels, st);
+            seg_done += SEG;
+        }
+        return true;
+    };
     if (field == GB_BABYBEAR) {
         // same flow over u32 Montgomery words; inputs are converted on the way in
         const gbk::BbNttTables* bt;
@@ -410,30 +437,25 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         const u32* in_dev = static_cast<const u32*>(cols);
         const bool staged = !dev_in && !is_coeffs && log_n >= 12 && ncols >= 4;
         if (staged) {
-            // column chunks: H2D into one of two staging halves (copy stream) -> Montgomery form into values_dev -> inverse NTT -> LDE
-            const size_t half = scr_bytes / 4 / 2;                 // words per staging half; the NTT scratch is scr's second region
-            const size_t per = std::min<size_t>(16, half / n);     // >= 2 columns because ncols >= 4
+            // column chunks: H2D straight into values_dev / the coefficient block (copy stream) -> Montgomery form in place ->
+            // inverse NTT -> LDE -> the leaf-sponge segments that have all their columns
+            const size_t per = 16;
             u32* vals = values_dev ? static_cast<u32*>(values_dev) : coeffs;  // without a taker the values are transformed in place
             u32* ntt_scr = scr + scr_bytes / 4;
             EventList evs;
             bool ok = true;
-            hipEvent_t e0 = evs.make(ok);                           // the staging area and values_dev may still be in use on `st`
+            hipEvent_t e0 = evs.make(ok);                           // values_dev / coeffs may be a pool block still in use on `st`
             ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
-            std::vector<hipEvent_t> converted;
-            size_t k = 0;
-            for (size_t c0 = 0; c0 < ncols && ok; c0 += per, k++) {
+            for (size_t c0 = 0; c0 < ncols && ok; c0 += per) {
                 const size_t cc = std::min(per, ncols - c0);
-                u32* stage = scr + (k & 1) * half;
-                if (k >= 2) ok = ok && hipStreamWaitEvent(ctx->copy_stream, converted[k - 2], 0) == hipSuccess;  // half free again
-                hipEvent_t copied = evs.make(ok), conv = evs.make(ok);
-                ok = ok && hipMemcpyAsync(stage, static_cast<const u32*>(cols) + c0 * n, cc * n * 4, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
+                hipEvent_t copied = evs.make(ok);
+                ok = ok && hipMemcpyAsync(vals + c0 * n, static_cast<const u32*>(cols) + c0 * n, cc * n * 4, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
                      hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
                 if (!ok) break;
-                gbk::bb_to_mont(stage, vals + c0 * n, cc * n, st);
-                ok = hipEventRecord(conv, st) == hipSuccess;
-                converted.push_back(conv);
+                gbk::bb_to_mont(vals + c0 * n, vals + c0 * n, cc * n, st);
                 { Scope sc(ctx, "IFFT"); gbk::bb_intt_columns(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, *bt, st); }
                 { Scope sc(ctx, "FFT + blinding"); gbk::bb_lde_columns(coeffs + c0 * n, lde + c0 * N, cc, *bt, *bc, st); }
+                if (!hash_ready_segments(c0 + cc)) return cleanup(fail(ctx, GB_ERR_OOM, "sponge state"));
             }
             if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
         } else if (!dev_in) {
@@ -470,7 +492,11 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         {
             Scope sc(ctx, "build Merkle tree");
             u32* lv = (u32*)b->levels;
-            { Scope sl(ctx, "hash leaves"); gbk::bb_merkle_leaves(lde, N, (u32)width, N, lv, st); }
+            {
+                Scope sl(ctx, "hash leaves");
+                if (seg_done) gbk::bb_merkle_leaves_segment(lde, N, seg_done, (u32)width, N, (u32*)seg_state, true, 0, lv, st);
+                else gbk::bb_merkle_leaves(lde, N, (u32)width, N, lv, st);
+            }
             for (u32 k = 0; k < log_N - cap_height; k++)
                 gbk::bb_merkle_level(lv + 8 * level_offset(N, k), lv + 8 * level_offset(N, k + 1), N >> (k + 1), st);
         }
@@ -502,6 +528,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             if (!ok) break;
             { Scope sc(ctx, "IFFT"); gbk::gl_intt_columns(vals + c0 * n, b->coeffs + c0 * n, (u64*)ctx->scratch.p, cc, *tabs, st); }
             { Scope sc(ctx, "FFT + blinding"); gbk::gl_lde_columns(b->coeffs + c0 * n, b->lde + c0 * N, cc, *tabs, *cos, st); }
+            if (!hash_ready_segments(c0 + cc)) return cleanup(fail(ctx, GB_ERR_OOM, "sponge state"));
         }
         if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
     } else if (!dev_in || is_coeffs) {
@@ -536,7 +563,11 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     }
     {
         Scope sc(ctx, "build Merkle tree");
-        { Scope sl(ctx, "hash leaves"); gbk::gl_merkle_leaves(b->lde, N, (u32)width, N, b->levels, st); }
+        {
+            Scope sl(ctx, "hash leaves");
+            if (seg_done) gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, (u32)width, N, (u64*)seg_state, true, 0, b->levels, st);
+            else gbk::gl_merkle_leaves(b->lde, N, (u32)width, N, b->levels, st);
+        }
         for (u32 k = 0; k < log_N - cap_height; k++)
             gbk::gl_merkle_level(b->levels + 4 * level_offset(N, k), b->levels + 4 * level_offset(N, k + 1), N >> (k + 1), st);
     }

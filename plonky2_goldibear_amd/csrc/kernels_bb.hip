@@ -227,6 +227,59 @@ __global__ __launch_bounds__(256) void k_bb_merkle_leaves(const u32* __restrict_
     o[0] = make_uint4(canonical_out(s[0]), canonical_out(s[1]), canonical_out(s[2]), canonical_out(s[3]));
     o[1] = make_uint4(canonical_out(s[4]), canonical_out(s[5]), canonical_out(s[6]), canonical_out(s[7]));
 }
+// The leaf sponge in column SEGMENTS [c_begin, c_end) (see k_gl_merkle_leaves_seg): between segments the capacity words 8..15 - as
+// the permutation left them: the next absorption's renorm brings them back to scale 1 - and, in front of a ragged last
+// absorption, the rate words it leaves alone (`keep_from`..7) wait in `state` [16][num_leaves].
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256, 7) void k_bb_merkle_leaves_seg(const u32* __restrict__ cols, size_t col_stride, u32 c_begin, u32 c_end,
+                                                                 u64 num_leaves, u32* __restrict__ state, u32 keep_from,
+                                                                 u32* __restrict__ out) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u32 s[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = 0;
+#pragma unroll
+    for (int i = 8; i < 16; i++) s[i] = FIRST ? 0 : state[(size_t)i * num_leaves + j];
+    if (LAST && !FIRST && c_end - c_begin < 8) {
+#pragma unroll
+        for (int i = 1; i < 8; i++)
+            if ((u32)i >= c_end - c_begin) s[i] = state[(size_t)i * num_leaves + j];
+    }
+    for (u32 c0 = c_begin; c0 < c_end; c0 += 8) {
+        if (c0) {  // the capacity words go on at scale 1; the rate words are overwritten (partially in the last absorption)
+#pragma unroll
+            for (int i = 8; i < 16; i++) s[i] = poseidon2_bb::renorm(s[i]);
+            if (LAST && c0 + 8 > c_end) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) s[i] = poseidon2_bb::renorm(s[i]);
+            }
+        }
+        if (!LAST || c0 + 8 <= c_end) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c0 + i < c_end) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+        }
+        poseidon2_bb::permute_scaled(s);
+    }
+    if (!LAST) {
+#pragma unroll
+        for (int i = 8; i < 16; i++) state[(size_t)i * num_leaves + j] = s[i];
+        if (keep_from < 8) {
+#pragma unroll
+            for (int i = 1; i < 8; i++)
+                if ((u32)i >= keep_from) state[(size_t)i * num_leaves + j] = s[i];
+        }
+        return;
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + 8 * j);
+    using poseidon2_bb::canonical_out;
+    o[0] = make_uint4(canonical_out(s[0]), canonical_out(s[1]), canonical_out(s[2]), canonical_out(s[3]));
+    o[1] = make_uint4(canonical_out(s[4]), canonical_out(s[5]), canonical_out(s[6]), canonical_out(s[7]));
+}
 __global__ __launch_bounds__(256) void k_bb_merkle_level(const u32* __restrict__ in, u32* __restrict__ out, u64 num_out) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_out) return;
@@ -370,6 +423,17 @@ void bb_merkle_leaves(const u32* cols, size_t col_stride, u32 width, u64 num_lea
         return;
     }
     hipLaunchKernelGGL(k_bb_merkle_leaves, dim3(nblk(num_leaves, 256)), dim3(256), 0, stream, cols, col_stride, width, num_leaves, out);
+}
+void bb_merkle_leaves_segment(const u32* cols, size_t col_stride, u32 c_begin, u32 c_end, u64 num_leaves, u32* state, bool last,
+                              u32 next_cols, u32* out, hipStream_t stream) {
+    const dim3 grid(nblk(num_leaves, 256)), block(256);
+    const u32 keep_from = next_cols < 8u ? next_cols : 8u;
+    if (c_begin == 0 && !last)
+        hipLaunchKernelGGL((k_bb_merkle_leaves_seg<true, false>), grid, block, 0, stream, cols, col_stride, c_begin, c_end, num_leaves, state, keep_from, out);
+    else if (!last)
+        hipLaunchKernelGGL((k_bb_merkle_leaves_seg<false, false>), grid, block, 0, stream, cols, col_stride, c_begin, c_end, num_leaves, state, keep_from, out);
+    else
+        hipLaunchKernelGGL((k_bb_merkle_leaves_seg<false, true>), grid, block, 0, stream, cols, col_stride, c_begin, c_end, num_leaves, state, keep_from, out);
 }
 bool bb_fri_leaves_coop(const u32* vals, size_t len, u32 arity_bits, u64 num_leaves, u32* out, hipStream_t stream) {
     if (num_leaves > BB_COOP_MAX_STATES || (4u << arity_bits) <= 8) return false;

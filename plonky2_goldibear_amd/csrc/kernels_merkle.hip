@@ -44,6 +44,53 @@ __global__ __launch_bounds__(256) void k_gl_merkle_leaves(const u64* __restrict_
     o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
 }
 
+// The sponge of a leaf run in SEGMENTS of columns [c_begin, c_end): a commitment whose columns arrive over PCIe hashes the columns
+// it already has while the rest is still in flight (api.hip commit()).  Between segments the words that the next absorption does
+// not overwrite wait in `state` ([12][num_leaves], lazy residues): the capacity words 8..11 always, and the rate words the ragged
+// last absorption leaves alone (`keep_from` .. 7) when the following segment starts with it.  FIRST: fresh sponge; LAST: the
+// digest goes to `out`.  Every segment but the last absorbs whole groups of 8 columns.
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves_seg(const u64* __restrict__ cols, size_t col_stride, u32 c_begin, u32 c_end,
+                                                              u64 num_leaves, u64* __restrict__ state, u32 keep_from,
+                                                              u64* __restrict__ out) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = 0;
+#pragma unroll
+    for (int i = 8; i < 12; i++) s[i] = FIRST ? 0 : state[(size_t)i * num_leaves + j];
+    if (LAST && !FIRST && c_end - c_begin < 8) {  // this segment is the ragged absorption alone: the rate words it leaves alone
+#pragma unroll
+        for (int i = 1; i < 8; i++)
+            if ((u32)i >= c_end - c_begin) s[i] = state[(size_t)i * num_leaves + j];
+    }
+    for (u32 c0 = c_begin; c0 < c_end; c0 += 8) {
+        if (!LAST || c0 + 8 <= c_end) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c0 + i < c_end) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+        }
+        permute_lazy(s);
+    }
+    if (!LAST) {
+#pragma unroll
+        for (int i = 8; i < 12; i++) state[(size_t)i * num_leaves + j] = s[i];
+        if (keep_from < 8) {
+#pragma unroll
+            for (int i = 1; i < 8; i++)
+                if ((u32)i >= keep_from) state[(size_t)i * num_leaves + j] = s[i];
+        }
+        return;
+    }
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * j);
+    o[0] = make_ulonglong2(to_canonical(s[0]), to_canonical(s[1]));
+    o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
+}
+
 // hash/hashing.rs:76-96 compress / Hasher::two_to_one
 __global__ __launch_bounds__(256) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,6 +233,20 @@ void gl_merkle_leaves(const u64* cols, size_t col_stride, u32 width, u64 num_lea
     }
     hipLaunchKernelGGL(k_gl_merkle_leaves, dim3(blocks_for(num_leaves, 256)), dim3(256), 0, stream, cols, col_stride,
                        width, num_leaves, out);
+}
+// one segment of the leaf sponges (k_gl_merkle_leaves_seg): columns [c_begin, c_end), c_begin a multiple of 8; `last`: c_end is the
+// leaf width and the digests are written; next_cols: how many columns remain after this segment (the following segment's first
+// absorption takes min(8, next_cols) of them)
+void gl_merkle_leaves_segment(const u64* cols, size_t col_stride, u32 c_begin, u32 c_end, u64 num_leaves, u64* state, bool last,
+                              u32 next_cols, u64* out, hipStream_t stream) {
+    const dim3 grid(blocks_for(num_leaves, 256)), block(256);
+    const u32 keep_from = next_cols < 8u ? next_cols : 8u;
+    if (c_begin == 0 && !last)
+        hipLaunchKernelGGL((k_gl_merkle_leaves_seg<true, false>), grid, block, 0, stream, cols, col_stride, c_begin, c_end, num_leaves, state, keep_from, out);
+    else if (!last)
+        hipLaunchKernelGGL((k_gl_merkle_leaves_seg<false, false>), grid, block, 0, stream, cols, col_stride, c_begin, c_end, num_leaves, state, keep_from, out);
+    else
+        hipLaunchKernelGGL((k_gl_merkle_leaves_seg<false, true>), grid, block, 0, stream, cols, col_stride, c_begin, c_end, num_leaves, state, keep_from, out);
 }
 bool gl_fri_leaves_coop(const u64* vals, size_t len, u32 arity_bits, u64 num_leaves, u64* out, hipStream_t stream) {
     if (num_leaves > COOP_MAX_STATES || (2u << arity_bits) <= 4) return false;

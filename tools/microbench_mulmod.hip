@@ -102,8 +102,72 @@ __device__ __forceinline__ u64 mul5(u64 a, u64 b) {
     return fold4((u32)p00, (u32)p10, hl, hh);
 }
 
+// M6: 4 mads; fold = one v_mad_u64_u32 for lo + hl (2^32 - 1) with its carry in an SGPR pair, a 64-bit subtract of hh with
+// its borrow in another, the (carry - borrow) (2^32 - 1) correction selected through scalar mask logic: 7 VALU ops instead of 11.
+// gfx950 needs two wait states between a VALU that writes an SGPR and a VALU that reads it (carry-in / select): s_nop 1 inside.
+template <bool NOPS>
+__device__ __forceinline__ u64 fold6(u32 r0, u32 r1, u32 hl, u32 hh) {
+    const u64 lo = (u64)r0 | ((u64)r1 << 32);
+    u64 t, c, b0, B;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
+    u32 d0, d1;
+    asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(d0), "=s"(b0) : "v"((u32)t), "v"(hh));
+    if (NOPS) asm("s_nop 1\n\tv_subb_co_u32 %0, %1, %2, 0, %3" : "=v"(d1), "=s"(B) : "v"((u32)(t >> 32)), "s"(b0));
+    else asm("v_subb_co_u32 %0, %1, %2, 0, %3" : "=v"(d1), "=s"(B) : "v"((u32)(t >> 32)), "s"(b0));
+    const u64 oc = c & ~B, ob = B & ~c;   // scalar: carry only / borrow only
+    u32 x, cl, ch;
+    if (NOPS) {
+        asm("s_nop 1\n\tv_cndmask_b32 %0, 0, 1, %1" : "=v"(x) : "s"(ob));
+        asm("s_nop 1\n\tv_cndmask_b32 %0, %1, -1, %2" : "=v"(cl) : "v"(x), "s"(oc));
+        asm("s_nop 1\n\tv_cndmask_b32 %0, 0, -1, %1" : "=v"(ch) : "s"(ob));
+    } else {
+        asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(x) : "s"(ob));
+        asm("v_cndmask_b32 %0, %1, -1, %2" : "=v"(cl) : "v"(x), "s"(oc));
+        asm("v_cndmask_b32 %0, 0, -1, %1" : "=v"(ch) : "s"(ob));
+    }
+    const u64 d = (u64)d0 | ((u64)d1 << 32), k = (u64)cl | ((u64)ch << 32);
+    return d + k;   // (cl, ch) = +EPS, -EPS or 0 as a 64-bit two's complement value; no second overflow (see fold4)
+}
+template <bool NOPS>
+__device__ __forceinline__ u64 mul6(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    u64 p11 = (u64)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
+    return fold6<NOPS>((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
+}
+// M8: as M6, the correction applied with a mad (d + cl, zero extended) and a masked subtract on the high word
+__device__ __forceinline__ u64 mul8(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    u64 p11 = (u64)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
+    const u32 r0 = (u32)p00, r1 = (u32)p10, hl = (u32)p11, hh = (u32)(p11 >> 32);
+    const u64 lo = (u64)r0 | ((u64)r1 << 32);
+    u64 t, c, b0m, B, dummy;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
+    u32 d0, d1;
+    asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(d0), "=s"(b0m) : "v"((u32)t), "v"(hh));
+    asm("s_nop 1\n\tv_subb_co_u32 %0, %1, %2, 0, %3" : "=v"(d1), "=s"(B) : "v"((u32)(t >> 32)), "s"(b0m));
+    const u64 oc = c & ~B, ob = B & ~c;
+    u32 x, cl;
+    asm("s_nop 1\n\tv_cndmask_b32 %0, 0, 1, %1" : "=v"(x) : "s"(ob));
+    asm("s_nop 1\n\tv_cndmask_b32 %0, %1, -1, %2" : "=v"(cl) : "v"(x), "s"(oc));
+    const u64 d = (u64)d0 | ((u64)d1 << 32);
+    u64 f;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=&v"(f), "=s"(dummy) : "v"(cl), "v"(d));
+    u32 f1;
+    asm("s_nop 1\n\tv_subb_co_u32 %0, %1, %2, 0, %3" : "=v"(f1), "=s"(dummy) : "v"((u32)(f >> 32)), "s"(ob));
+    return (u64)(u32)f | ((u64)f1 << 32);
+}
+
 template <int V>
 __device__ __forceinline__ u64 mulv(u64 a, u64 b) {
+    if (V == 6) return mul6<true>(a, b);
+    if (V == 7) return mul6<false>(a, b);
+    if (V == 8) return mul8(a, b);
     if (V == 4) return mul4(a, b);
     if (V == 5) return mul5(a, b);
     if (V == 0) return mul0(a, b);
@@ -179,5 +243,8 @@ int main() {
     run<3>("M3 phi");
     run<4>("M4 limb32");
     run<5>("M5 limb32b");
+    run<6>("M6 madfold");
+    run<7>("M7 nonops");
+    run<8>("M8 madfold2");
     return 0;
 }
