@@ -446,8 +446,8 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             bool ok = true;
             hipEvent_t e0 = evs.make(ok);                           // values_dev / coeffs may be a pool block still in use on `st`
             ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
-            for (size_t c0 = 0; c0 < ncols && ok; c0 += per) {
-                const size_t cc = std::min(per, ncols - c0);
+            for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
+                cc = std::min(c0 == 0 ? (size_t)4 : c0 == 4 ? per - 4 : per, ncols - c0);  // a small first chunk: the GPU starts after 1/4 of the wait
                 hipEvent_t copied = evs.make(ok);
                 ok = ok && hipMemcpyAsync(vals + c0 * n, static_cast<const u32*>(cols) + c0 * n, cc * n * 4, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
                      hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
@@ -520,8 +520,8 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         bool ok = true;
         hipEvent_t e0 = evs.make(ok);                               // values_dev may be a pool block still in use on `st`
         ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
-        for (size_t c0 = 0; c0 < ncols && ok; c0 += CH) {
-            const size_t cc = std::min(CH, ncols - c0);
+        for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
+            cc = std::min(c0 == 0 ? (size_t)4 : c0 == 4 ? CH - 4 : CH, ncols - c0);  // a small first chunk: the GPU starts after 1/4 of the wait
             hipEvent_t copied = evs.make(ok);
             ok = ok && hipMemcpyAsync(vals + c0 * n, src + c0 * n, cc * n * sizeof(u64), hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
                  hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;

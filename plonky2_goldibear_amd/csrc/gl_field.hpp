@@ -109,13 +109,22 @@ __device__ __forceinline__ u64 fold160(u32 r0, u32 r1, u32 hl, u32 hh, u32 r4) {
     u32 f1 = d1 + ch + k2;
     return (u64)f0 | ((u64)f1 << 32);
 }
-// a * b as four 32-bit limbs (four v_mad_u64_u32)
+// a * b as four 32-bit limbs: four v_mad_u64_u32 for the partial products and a fifth as an ADDER - the second carry word
+// enters the top product as x * 1 + acc, one instruction on registers that are already in place, where a 64-bit add of two
+// zero-extended halves costs a v_lshl_add_u64 plus two v_mov to build its operand pairs (gfx950 issue costs, measured:
+// v_mad_u64_u32 4.5 cycles per wave, carry / select / 64-bit-add ops ~2.9 in a mixed stream, v_mov 2.4; tools/microbench_*.hip).
 __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& hl, u32& hh) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 p01 = (u64)a0 * b1 + (p00 >> 32);
     u64 p10 = (u64)a1 * b0 + (u32)p01;
-    u64 p11 = (u64)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
+    u64 p11 = (u64)a1 * b1 + (p01 >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 carry_unused;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(p11), "=s"(carry_unused) : "v"((u32)(p10 >> 32)));   // < 2^64: the product is < 2^128
+#else
+    p11 += p10 >> 32;
+#endif
     r0 = (u32)p00; r1 = (u32)p10; hl = (u32)p11; hh = (u32)(p11 >> 32);
 }
 // a * b mod p, any u64 in, canonical out.

@@ -11,12 +11,15 @@
 
 namespace gbk {
 
+using poseidon_gl::from_mont;
 using poseidon_gl::permute;
-using poseidon_gl::permute_lazy;
-using poseidon_gl::to_canonical;
+using poseidon_gl::permute_mont;
+using poseidon_gl::to_mont;
+// The sponge state of these kernels is kept in the permutation's Montgomery form (poseidon_gl.hpp): absorbed words go through
+// to_mont, the digest through from_mont (canonical); the capacity words never leave that form between absorptions.
 
 // hash/hashing.rs:100-123 (overwrite-mode sponge, rate 8) + plonk/config.rs:70-84 (hash_or_noop)
-__global__ __launch_bounds__(256) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
+__global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
                                                           u64 num_leaves, u64* __restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= num_leaves) return;
@@ -30,18 +33,20 @@ __global__ __launch_bounds__(256) void k_gl_merkle_leaves(const u64* __restrict_
         for (u32 c0 = 0; c0 < width; c0 += 8) {
             if (c0 + 8 <= width) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+                for (int i = 0; i < 8; i++) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; i++)
-                    if (c0 + i < width) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+                    if (c0 + i < width) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
             }
-            permute_lazy(s);  // capacity lanes stay lazy residues between absorptions
+            permute_mont(s);  // the state stays a lazy Montgomery-form residue between absorptions
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[i] = from_mont(s[i]);
     }
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * j);
-    o[0] = make_ulonglong2(to_canonical(s[0]), to_canonical(s[1]));
-    o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
 }
 
 // The sponge of a leaf run in SEGMENTS of columns [c_begin, c_end): a commitment whose columns arrive over PCIe hashes the columns
@@ -68,13 +73,13 @@ __global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves_seg(const u64* __re
     for (u32 c0 = c_begin; c0 < c_end; c0 += 8) {
         if (!LAST || c0 + 8 <= c_end) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+            for (int i = 0; i < 8; i++) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; i++)
-                if (c0 + i < c_end) s[i] = cols[(size_t)(c0 + i) * col_stride + j];
+                if (c0 + i < c_end) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
         }
-        permute_lazy(s);
+        permute_mont(s);
     }
     if (!LAST) {
 #pragma unroll
@@ -87,21 +92,22 @@ __global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves_seg(const u64* __re
         return;
     }
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * j);
-    o[0] = make_ulonglong2(to_canonical(s[0]), to_canonical(s[1]));
-    o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
+    o[0] = make_ulonglong2(from_mont(s[0]), from_mont(s[1]));
+    o[1] = make_ulonglong2(from_mont(s[2]), from_mont(s[3]));
 }
 
 // hash/hashing.rs:76-96 compress / Hasher::two_to_one
-__global__ __launch_bounds__(256) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
+__global__ __launch_bounds__(256, 6) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_out) return;
     const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
     ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
-    u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
-    permute_lazy(s);
+    u64 s[12] = {to_mont(a.x), to_mont(a.y), to_mont(b.x), to_mont(b.y), to_mont(c.x), to_mont(c.y), to_mont(d.x), to_mont(d.y),
+                 0, 0, 0, 0};
+    permute_mont(s);
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
-    o[0] = make_ulonglong2(to_canonical(s[0]), to_canonical(s[1]));
-    o[1] = make_ulonglong2(to_canonical(s[2]), to_canonical(s[3]));
+    o[0] = make_ulonglong2(from_mont(s[0]), from_mont(s[1]));
+    o[1] = make_ulonglong2(from_mont(s[2]), from_mont(s[3]));
 }
 
 // The same two kernels with one state per 16-lane row (poseidon_gl_coop.hpp), for trees too small to fill the machine with

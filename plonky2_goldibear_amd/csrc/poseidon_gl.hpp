@@ -49,9 +49,32 @@ constexpr u64 WHATS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_W_HATS_LIST};
 constexpr u64 INIT[11 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX_LIST};
 }  // namespace raw
 
-__device__ static const u64 RC[GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN] = {GL_POSEIDON_ALL_ROUND_CONSTANTS_LIST};
-__device__ static const u64 FP_FIRST[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST};
-__device__ static const u64 FP_RC[22] = {GL_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS_LIST};
+// The state lives in MONTGOMERY form (x R, R = 2^64 mod p) inside the permutation: a state-by-state product (the s-box) is then
+// reduced by the Montgomery fold (8 carry ops, mont_fold) instead of the plain one (11, gl::fold128), while everything linear -
+// small-integer MDS sums, products with the PLAIN constants w_hat / v / M_init (x R times c is (x c) R under the plain fold) -
+// is unchanged.  Only the constants that are ADDED to the state are stored times R.
+template <int N>
+struct U64Table {
+    u64 v[N];
+};
+namespace raw {
+constexpr u64 cmulmod_r(u64 a) { return (u64)(((u128)(a % gl::P) * gl::EPS) % gl::P); }  // a R mod p (R = 2^64 mod p = 2^32 - 1)
+template <int N>
+constexpr U64Table<N> times_r(const u64 (&src)[N]) {
+    U64Table<N> t{};
+    for (int i = 0; i < N; i++) t.v[i] = cmulmod_r(src[i]);
+    return t;
+}
+constexpr u64 ALL_RC[GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN] = {GL_POSEIDON_ALL_ROUND_CONSTANTS_LIST};
+constexpr u64 FIRST_RC[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST};
+constexpr u64 PARTIAL_RC[22] = {GL_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS_LIST};
+}  // namespace raw
+__device__ static const U64Table<GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN> RC_T = raw::times_r(raw::ALL_RC);
+__device__ static const U64Table<12> FP_FIRST_T = raw::times_r(raw::FIRST_RC);
+__device__ static const U64Table<22> FP_RC_T = raw::times_r(raw::PARTIAL_RC);
+#define GB_RC (poseidon_gl::RC_T.v)
+#define GB_FP_FIRST (poseidon_gl::FP_FIRST_T.v)
+#define GB_FP_RC (poseidon_gl::FP_RC_T.v)
 __device__ static const u64 FP_VS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_VS_LIST};
 // Two partial rounds at a time (see partial_rounds): the second round's w_hat row meets the first round's pending update
 // u_k v_k of the state, sum_i v_{k,i} w_hat_{k+1,i} = PAIR_C[k/2], a per-pair constant (compile-time, mod p).
@@ -92,7 +115,7 @@ constexpr MergedInit merged_init() {
         }
         u64 acc = 0;
         for (int r = 1; r < 12; r++) acc = (u64)(((u128)acc + cmulmod(FIRST[r], INIT[(r - 1) * 11 + c])) % gl::P);
-        t.k[c] = acc;
+        t.k[c] = (u64)(((u128)acc * gl::EPS) % gl::P);   // added to the state: times R (Montgomery form)
     }
     return t;
 }
@@ -131,6 +154,43 @@ __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
     gl::mul_limbs(a, b, r0, r1, hl, hh);
     return gl::fold128(r0, r1, hl, hh);
 }
+// (x0 + 2^32 x1 + 2^64 x2 + 2^96 x3) / 2^64 mod p as SOME u64 congruent to it: Montgomery reduction with R = 2^64, for which
+// p = 2^64 - 2^32 + 1 needs no multiplication (-1/p = -(1 + 2^32) mod 2^64):  a = lo + (lo << 32), b = a - (a >> 32) - carry,
+// r = hi - b, minus EPS when that borrows.  b <= p - 1 for every 128-bit input, so the last step cannot borrow twice.
+// 8 carry ops against fold128's 11.
+__device__ __forceinline__ u64 mont_fold(u32 x0, u32 x1, u32 x2, u32 x3) {
+    u32 e, bw, k0, c0, c, k;
+    const u32 a1 = __builtin_addc(x1, x0, 0u, &e);   // a = (x0, a1), carry e
+    const u32 b0 = __builtin_subc(x0, a1, e, &bw);
+    const u32 b1 = __builtin_subc(a1, 0u, bw, &k0);
+    const u32 r0 = __builtin_subc(x2, b0, 0u, &c0);
+    const u32 r1 = __builtin_subc(x3, b1, c0, &c);
+    const u32 m = 0u - c;                            // EPS when hi < b: r + p = r - EPS (mod 2^64)
+    const u32 f0 = __builtin_subc(r0, m, 0u, &k);
+    const u32 f1 = r1 - k;
+    return (u64)f0 | ((u64)f1 << 32);
+}
+// a b / R for two Montgomery-form residues: any u64 in, any u64 out
+__device__ __forceinline__ u64 mul_mont(u64 a, u64 b) {
+    u32 r0, r1, hl, hh;
+    gl::mul_limbs(a, b, r0, r1, hl, hh);
+    return mont_fold(r0, r1, hl, hh);
+}
+// x -> x R = x (2^32 - 1) = (x0 << 32) - (x0 + x1) for x = x0 + 2^32 x1 (2^64 = 2^32 - 1 mod p), any u64 in, any u64 out
+__device__ __forceinline__ u64 to_mont(u64 x) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    u32 tc, b0, B, k;
+    const u32 t0 = __builtin_addc(x0, x1, 0u, &tc);
+    const u32 r0 = __builtin_subc(0u, t0, 0u, &b0);
+    const u32 r1 = __builtin_subc(x0, tc, b0, &B);
+    const u32 m = 0u - B;                            // negative (x0 = 0): + p
+    const u32 f0 = __builtin_subc(r0, m, 0u, &k);
+    const u32 f1 = r1 - k;
+    return (u64)f0 | ((u64)f1 << 32);
+}
+// x R -> x, canonical
+__device__ __forceinline__ u64 from_mont(u64 x) { return gl::canon(mont_fold((u32)x, (u32)(x >> 32), 0u, 0u)); }
+
 // a * b + c
 __device__ __forceinline__ u64 mul_add_lazy(u64 a, u64 b, u64 c) {
     u32 r0, r1, hl, hh, k0, k1, k2;
@@ -150,9 +210,9 @@ __device__ __forceinline__ u64 add_rc(u64 x, u64 rc) {
 }
 __device__ __forceinline__ u64 to_canonical(u64 x) { return gl::canon(x); }
 
-__device__ __forceinline__ u64 sbox(u64 x) {
-    u64 x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);
-    return mul_lazy(x3, x4);
+__device__ __forceinline__ u64 sbox(u64 x) {  // Montgomery form in and out
+    u64 x2 = mul_mont(x, x), x4 = mul_mont(x2, x2), x3 = mul_mont(x, x2);
+    return mul_mont(x3, x4);
 }
 
 // Unreduced dot product sum_i a_i * b_i for up to 16 terms: six carry-free 64-bit sums.
@@ -244,7 +304,7 @@ __device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0, const u64*
     for (int k = 0; k < HALF_FULL; k++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        mds_layer(s, k + 1 < HALF_FULL ? RC + 12 * (round0 + k + 1) : tail_rc);
+        mds_layer(s, k + 1 < HALF_FULL ? GB_RC + 12 * (round0 + k + 1) : tail_rc);
     }
 }
 
@@ -255,13 +315,13 @@ __device__ __forceinline__ void first_half(u64 (&s)[12]) {
     for (int k = 0; k < HALF_FULL - 1; k++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        mds_layer(s, RC + 12 * (k + 1));
+        mds_layer(s, GB_RC + 12 * (k + 1));
     }
     u64 y[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) y[i] = sbox(s[i]);
     {  // row 0 of the MDS + FAST_PARTIAL_FIRST_ROUND_CONSTANT[0]
-        const u64 c = FP_FIRST[0];
+        const u64 c = GB_FP_FIRST[0];
         u64 sl = (u32)c, sh = c >> 32;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -298,12 +358,12 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
         const u64* vs0 = FP_VS + 11 * k;
         const u64* vs1 = vs0 + 11;
         // mds_partial_layer_fast (:718-744): d = s0*(CIRC[0]+DIAG[0]) + sum_i s[i]*w_hat[i-1]
-        const u64 u0 = add_rc(sbox(s[0]), FP_RC[k]);
+        const u64 u0 = add_rc(sbox(s[0]), GB_FP_RC[k]);
         Dot d0;
         d0.acc_small(u0, mds_circ(0) + MDS_DIAG0);
 #pragma unroll
         for (int i = 1; i < 12; i++) d0.acc(s[i], wh0[i - 1]);
-        const u64 u1 = add_rc(sbox(d0.finish()), FP_RC[k + 1]);
+        const u64 u1 = add_rc(sbox(d0.finish()), GB_FP_RC[k + 1]);
         Dot d1;
         d1.acc_small(u1, mds_circ(0) + MDS_DIAG0);
 #pragma unroll
@@ -331,15 +391,24 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
     }
 }
 
-// state in: any u64 residues; state out: any u64 residues (call to_canonical before storing)
-__device__ __forceinline__ void permute_lazy(u64 (&s)[12]) {
+// state in and out: MONTGOMERY-form residues, any u64 (to_mont what is absorbed, from_mont what is squeezed)
+__device__ __forceinline__ void permute_mont(u64 (&s)[12]) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], RC[i]);
+    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
     first_half(s);
     partial_rounds(s);
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], RC[12 * (HALF_FULL + N_PARTIAL) + i]);
+    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[12 * (HALF_FULL + N_PARTIAL) + i]);
     full_rounds(s, HALF_FULL + N_PARTIAL, ZERO_RC);
+}
+
+// state in: any u64 residues; state out: any u64 residues (call to_canonical before storing)
+__device__ __forceinline__ void permute_lazy(u64 (&s)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = to_mont(s[i]);
+    permute_mont(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = mont_fold((u32)s[i], (u32)(s[i] >> 32), 0u, 0u);
 }
 
 __device__ __forceinline__ void permute(u64 (&s)[12]) {

@@ -17,12 +17,9 @@ namespace poseidon_gl_coop {
 
 using gl::u32;
 using gl::u64;
-using poseidon_gl::FP_FIRST;
-using poseidon_gl::FP_RC;
 using poseidon_gl::FP_VS;
 using poseidon_gl::mul_add_lazy;
 using poseidon_gl::mul_lazy;
-using poseidon_gl::RC;
 using poseidon_gl::sbox;
 
 __device__ static const u64 WHATS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_W_HATS_LIST};
@@ -55,6 +52,7 @@ __device__ __forceinline__ u64 row_sum(u64 x) {
 __device__ __forceinline__ u64 permute(u64 x, u32 l, u64* __restrict__ sh) {
     const bool live = l < 12;
     const u32 lc = live ? l : 0;       // a valid table index for the idle lanes
+    x = poseidon_gl::to_mont(x);       // the shared s-box and additive constants work on Montgomery-form residues (poseidon_gl.hpp)
     auto mds = [&](u64 v) {            // res[l] = sum_i v[(l + i) % 12] CIRC[i] + (l == 0) v[0] DIAG[0]   (:547-557)
         __syncthreads();               // the previous reads of sh are done
         sh[l] = v;
@@ -82,11 +80,11 @@ __device__ __forceinline__ u64 permute(u64 x, u32 l, u64* __restrict__ sh) {
     // ---- first half: four full rounds (:889-897)
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
-        x = add_lazy(x, live ? RC[12 * r + lc] : 0);
+        x = add_lazy(x, live ? GB_RC[12 * r + lc] : 0);
         x = mds(sbox(x));
     }
     // ---- partial_first_constant_layer + mds_partial_layer_init (:632-683): s_0 stays, s_c = sum_{r >= 1} s_r INIT[r-1][c-1]
-    x = add_lazy(x, live ? FP_FIRST[lc] : 0);
+    x = add_lazy(x, live ? GB_FP_FIRST[lc] : 0);
     __syncthreads();
     sh[l] = x;
     __syncthreads();
@@ -110,7 +108,7 @@ __device__ __forceinline__ u64 permute(u64 x, u32 l, u64* __restrict__ sh) {
             wh = upper ? WHATS[11 * (k + 1) + t] : c00;
             vs = FP_VS[11 * (k + 1) + t];
         }
-        s0 = add_lazy(sbox(s0), FP_RC[k]);
+        s0 = add_lazy(sbox(s0), GB_FP_RC[k]);
         const u64 term = mul_lazy(upper ? x : s0, wh_k);
         const u64 upd = mul_add_lazy(s0, vs_k, x);
         x = upper ? upd : 0;
@@ -120,10 +118,10 @@ __device__ __forceinline__ u64 permute(u64 x, u32 l, u64* __restrict__ sh) {
     // ---- second half: four full rounds
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
-        x = add_lazy(x, live ? RC[12 * (4 + 22 + r) + lc] : 0);
+        x = add_lazy(x, live ? GB_RC[12 * (4 + 22 + r) + lc] : 0);
         x = mds(sbox(x));
     }
-    return x;
+    return poseidon_gl::mont_fold((u32)x, (u32)(x >> 32), 0u, 0u);   // out of Montgomery form; still a lazy residue
 }
 
 }  // namespace poseidon_gl_coop
