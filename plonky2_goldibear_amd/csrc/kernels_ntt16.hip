@@ -20,19 +20,48 @@ static constexpr int THREADS = 256;
 
 __device__ __forceinline__ constexpr u32 brev4(u32 x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); }
 
-// x * 2^K mod p, canonical in/out
+// x * 2^K mod p, canonical in, canonical out, 0 <= K < 96.  With f = 2^32 (f^2 = f - 1, f^3 = -1 mod p) and
+// y = x 2^(K mod 32) = y0 + y1 f + y2 f^2 (y2 < 2^(K mod 32)), multiplying on by f^(K / 32) only shuffles limbs:
+//   K <  32:  y0 + y1 f + y2 (f - 1)            = lo64 + y2 EPS             one conditional subtraction of p
+//   K <  64:  (y0 + y1) f - (y1 + y2)           = (u0 + cu) f - (y1 + y2 + cu),  u = y0 + y1 = u0 + cu f
+//   K <  96:  (y0 - y2) f - (y0 + y1)
+// In the last two the minuend is a multiple of f below p and the subtrahend is small, so one "+ p on borrow" leaves the
+// canonical value: 10-12 VALU ops where shift + generic fold + canonicalisation took 17 and the K >= 64 cases a full
+// multiplication by a 64-bit constant (four of the seventeen twiddles of a 16-point DFT).
 template <int K>
 __device__ __forceinline__ u64 mul_pow2(u64 x) {
     static_assert(K >= 0 && K < 96, "shift range");
-    if constexpr (K == 0) {
-        return x;
-    } else if constexpr (K < 64) {
-        const u64 lo = x << K, hi = x >> (64 - K);
-        return gl::canon(gl::fold128((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)));
+    if constexpr (K == 0) return x;
+    constexpr int k = K % 32, j = K / 32;
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    const u32 y0 = k ? x0 << k : x0;
+    const u32 y1 = k ? (x1 << k) | (x0 >> ((32 - k) & 31)) : x1;
+    const u32 y2 = k ? x1 >> ((32 - k) & 31) : 0u;
+    if constexpr (j == 0) {
+        const u64 lo = (u64)y0 | ((u64)y1 << 32), he = ((u64)y2 << 32) - y2;  // y2 EPS < 2^63
+        u64 t, t2;
+        const bool c = __builtin_uaddll_overflow(lo, he, &t);
+        const bool d = __builtin_uaddll_overflow(t, gl::EPS, &t2);            // t - p
+        return (c | d) ? t2 : t;
     } else {
-        // 2^K = 2^(K-64) * (2^32 - 1): a 64-bit constant < p
-        constexpr u64 c = ((u64)1 << (K - 32)) - ((u64)1 << (K - 64));
-        return gl::mul(x, c);
+        u32 cu, cw, b0, B1, B2, kk;
+        u32 hi, s0;   // minuend hi f, subtrahend s0 + cw f (cw: carry flag)
+        if constexpr (j == 1) {
+            const u32 u0 = __builtin_addc(y0, y1, 0u, &cu);
+            hi = u0 + cu;                                   // no overflow: cu = 1 leaves u0 <= 2^32 - 2
+            s0 = __builtin_addc(y1, y2, cu, &cw);
+        } else {
+            hi = y0;
+            s0 = __builtin_addc(y0, y1, 0u, &cw);
+            cw += y2;                                       // high word of the subtrahend: y2 + carry (< 2^31 + 1)
+        }
+        const u32 d0 = __builtin_subc(0u, s0, 0u, &b0);
+        const u32 d1 = __builtin_subc(hi, cw, b0, &B1);
+        (void)B2;
+        const u32 m = 0u - B1;                              // borrowed: + p, i.e. - EPS (mod 2^64)
+        const u32 e0 = __builtin_subc(d0, m, 0u, &kk);
+        const u32 e1 = d1 - kk;
+        return (u64)e0 | ((u64)e1 << 32);
     }
 }
 
