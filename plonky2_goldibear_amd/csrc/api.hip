@@ -205,7 +205,14 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
     if (it != ctx->gl_tables.end()) { *out = &it->second.t; return GB_OK; }
     if (!ctx->tw4096_fwd) {
         u64 w = gl::two_adic_generator(12);
-        gb_status s = upload(ctx, powers(w, 4096), &ctx->tw4096_fwd, nullptr);
+        // [0, 4096): w_4096^j.  [4096, 8192): the same powers in the order k_gl_lde_pb16's first stage reads them,
+        // T[s][m] = w_4096^(brev4(s) m), s < 16, m < 256 - a wave's 64 lanes then read 512 contiguous bytes per slot instead of
+        // gathering at stride brev4(s) (up to 60 cache lines per load instruction).
+        std::vector<u64> fwd = powers(w, 4096);
+        fwd.resize(8192);
+        for (u32 sl = 0; sl < 16; sl++)
+            for (u32 m = 0; m < 256; m++) fwd[4096 + sl * 256 + m] = fwd[(bitrev32(sl, 4) * m) & 4095];
+        gb_status s = upload(ctx, fwd, &ctx->tw4096_fwd, nullptr);
         if (s) return s;
         s = upload(ctx, powers(gl::inv(w), 4096), &ctx->tw4096_inv, nullptr);
         if (s) return s;

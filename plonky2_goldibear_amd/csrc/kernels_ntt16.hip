@@ -138,16 +138,22 @@ __device__ __forceinline__ void load_tw16(u64 (&tw)[16], const u64* __restrict__
 
 // ------------------------------------------------------------------ LDE pass B: 4096 contiguous points, 3 radix-16 stages
 // grid = number of 4096-tiles of `lde` (in place).  natural -> bit-reversed.
+// The inter-stage twiddles cost as much as the butterflies here (ablations in DESIGN.md: without their loads and products the pass
+// runs 33 % faster, close to a plain copy): the first stage reads them from a copy of the table laid out [slot][tid] (coalesced),
+// the second from a 256-entry table in LDS.
 __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, const u64* __restrict__ tw4096) {
     __shared__ u64 sh[16 * 272];
+    __shared__ u64 tw256[256];  // w_256^m = w_4096^(16 m): the stage-2 twiddles
     u64* p = lde + ((size_t)blockIdx.x << 12);
     const u32 tid = threadIdx.x;
+    tw256[tid] = tw4096[tid * 16];
     u64 x[16];
     // stage 1: digit d2 (stride 256); this thread is (d1, d0) = tid
 #pragma unroll
     for (u32 d = 0; d < 16; d++) x[d] = p[d * 256 + tid];
     u64 tw[16];
-    load_tw16(tw, tw4096, tid);  // w_4096^(k2 (16 d1 + d0))
+#pragma unroll
+    for (u32 s = 1; s < 16; s++) tw[s] = tw4096[4096 + s * 256 + tid];  // w_4096^(k2 (16 d1 + d0)), k2 = brev4(s)
     dft16<false>(x);
 #pragma unroll
     for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul(x[s], tw[s]) : x[s];
@@ -156,11 +162,11 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
     const u32 hi4 = tid >> 4, lo4 = tid & 15;
 #pragma unroll
     for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 272 + d * 16 + lo4];
-    load_tw16(tw, tw4096, lo4 * 16);  // w_256^(k1 d0)
     dft16<false>(x);
     __syncthreads();
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[hi4 * 272 + lo4 * 17 + s] = s ? gl::mul(x[s], tw[s]) : x[s];  // [k2 slot][d0][k1 slot], rows padded to 17
+    for (u32 s = 0; s < 16; s++)   // w_256^(k1 d0) from LDS; [k2 slot][d0][k1 slot], rows padded to 17
+        sh[hi4 * 272 + lo4 * 17 + s] = s ? gl::mul(x[s], tw256[(brev4(s) * lo4) & 255]) : x[s];
     __syncthreads();
     // stage 3: digit d0; this thread is (k2 slot, k1 slot)
 #pragma unroll
