@@ -66,6 +66,7 @@ struct gb_ctx {
     std::map<std::string, ScopeAcc> scopes;
     u64* tw4096_fwd = nullptr;
     u64* tw4096_inv = nullptr;
+    u64 *tw4096_fwd_m = nullptr, *tw4096_inv_m = nullptr;  // times R (Montgomery form)
     std::map<u32, GlTableSet> gl_tables;                    // by log_n
     std::map<std::tuple<u32, u32, u64, int>, GlCosetSet> gl_cosets;  // by (log_n, rate_bits, shift, inverse)
     u32 *bb_tw4096_fwd = nullptr, *bb_tw4096_inv = nullptr;
@@ -200,6 +201,12 @@ u32 bitrev32(u32 x, u32 bits) {
     return r;
 }
 
+std::vector<u64> times_r(const std::vector<u64>& v) {   // Montgomery form of a table: x R mod p, R = 2^64 mod p
+    std::vector<u64> o(v.size());
+    for (size_t i = 0; i < v.size(); i++) o[i] = gl::to_mont_slow(v[i]);
+    return o;
+}
+
 gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
     auto it = ctx->gl_tables.find(log_n);
     if (it != ctx->gl_tables.end()) { *out = &it->second.t; return GB_OK; }
@@ -214,24 +221,40 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
             for (u32 m = 0; m < 256; m++) fwd[4096 + sl * 256 + m] = fwd[(bitrev32(sl, 4) * m) & 4095];
         gb_status s = upload(ctx, fwd, &ctx->tw4096_fwd, nullptr);
         if (s) return s;
-        s = upload(ctx, powers(gl::inv(w), 4096), &ctx->tw4096_inv, nullptr);
+        const std::vector<u64> inv = powers(gl::inv(w), 4096);
+        s = upload(ctx, inv, &ctx->tw4096_inv, nullptr);
         if (s) return s;
+        if ((s = upload(ctx, times_r(fwd), &ctx->tw4096_fwd_m, nullptr))) return s;
+        if ((s = upload(ctx, times_r(inv), &ctx->tw4096_inv_m, nullptr))) return s;
     }
     GlTableSet set;
     set.t.log_n = log_n;
     set.t.tw4096_fwd = ctx->tw4096_fwd;
     set.t.tw4096_inv = ctx->tw4096_inv;
+    set.t.tw4096_fwd_m = ctx->tw4096_fwd_m;
+    set.t.tw4096_inv_m = ctx->tw4096_inv_m;
     u64 w = gl::two_adic_generator(log_n), wi = gl::inv(w);
     size_t n = (size_t)1 << log_n;
     size_t nhi = n > 1024 ? n / 1024 : 1;
     u64 *lo_f, *hi_f, *lo_i, *hi_i;
     gb_status s;
-    if ((s = upload(ctx, powers(w, 1024), &lo_f, &set.owned))) return s;
-    if ((s = upload(ctx, powers(gl::pow(w, 1024), nhi), &hi_f, &set.owned))) return s;
-    if ((s = upload(ctx, powers(wi, 1024), &lo_i, &set.owned))) return s;
-    if ((s = upload(ctx, powers(gl::pow(wi, 1024), nhi), &hi_i, &set.owned))) return s;
+    const std::vector<u64> vlo_f = powers(w, 1024), vhi_f = powers(gl::pow(w, 1024), nhi), vlo_i = powers(wi, 1024),
+                           vhi_i = powers(gl::pow(wi, 1024), nhi);
+    if ((s = upload(ctx, vlo_f, &lo_f, &set.owned))) return s;
+    if ((s = upload(ctx, vhi_f, &hi_f, &set.owned))) return s;
+    if ((s = upload(ctx, vlo_i, &lo_i, &set.owned))) return s;
+    if ((s = upload(ctx, vhi_i, &hi_i, &set.owned))) return s;
     set.t.tw_lo_fwd = lo_f; set.t.tw_hi_fwd = hi_f; set.t.tw_lo_inv = lo_i; set.t.tw_hi_inv = hi_i;
     set.t.n_inv = gl::inv((u64)n % gl::P);
+    {
+        u64 *a, *b, *c, *d;
+        if ((s = upload(ctx, times_r(vlo_f), &a, &set.owned))) return s;
+        if ((s = upload(ctx, times_r(vhi_f), &b, &set.owned))) return s;
+        if ((s = upload(ctx, times_r(vlo_i), &c, &set.owned))) return s;
+        if ((s = upload(ctx, times_r(vhi_i), &d, &set.owned))) return s;
+        set.t.tw_lo_fwd_m = a; set.t.tw_hi_fwd_m = b; set.t.tw_lo_inv_m = c; set.t.tw_hi_inv_m = d;
+        set.t.n_inv_m = gl::to_mont_slow(set.t.n_inv);
+    }
     auto res = ctx->gl_tables.emplace(log_n, std::move(set));
     *out = &res.first->second.t;
     return GB_OK;
@@ -263,6 +286,12 @@ gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u64 shift, bool i
     if ((s = upload(ctx, lo, &dlo, &set.owned))) return s;
     if ((s = upload(ctx, hi, &dhi, &set.owned))) return s;
     set.t.pow_lo = dlo; set.t.pow_hi = dhi;
+    {
+        u64 *a, *b;
+        if ((s = upload(ctx, times_r(lo), &a, &set.owned))) return s;
+        if ((s = upload(ctx, times_r(hi), &b, &set.owned))) return s;
+        set.t.pow_lo_m = a; set.t.pow_hi_m = b;
+    }
     auto res = ctx->gl_cosets.emplace(key, std::move(set));
     *out = &res.first->second.t;
     return GB_OK;
@@ -619,6 +648,8 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     if (ctx->bb_tw4096_inv) hipFree(ctx->bb_tw4096_inv);
     if (ctx->tw4096_fwd) hipFree(ctx->tw4096_fwd);
     if (ctx->tw4096_inv) hipFree(ctx->tw4096_inv);
+    if (ctx->tw4096_fwd_m) hipFree(ctx->tw4096_fwd_m);
+    if (ctx->tw4096_inv_m) hipFree(ctx->tw4096_inv_m);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->small.p) hipFree(ctx->small.p);
     if (ctx->upload_mark) hipEventDestroy(ctx->upload_mark);

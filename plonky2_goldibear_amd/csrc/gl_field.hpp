@@ -127,6 +127,33 @@ __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& h
 #endif
     r0 = (u32)p00; r1 = (u32)p10; hl = (u32)p11; hh = (u32)(p11 >> 32);
 }
+// (x0 + 2^32 x1 + 2^64 x2 + 2^96 x3) / 2^64 mod p as SOME u64 congruent to it: Montgomery reduction with R = 2^64, for which
+// p = 2^64 - 2^32 + 1 needs no multiplication (-1/p = -(1 + 2^32) mod 2^64):  a = lo + (lo << 32), b = a - (a >> 32) - carry,
+// r = hi - b, minus EPS when that borrows.  b <= p - 1 for every 128-bit input, so the last step cannot borrow twice.
+// 8 carry ops against fold128's 11.
+__device__ __forceinline__ u64 mont_fold(u32 x0, u32 x1, u32 x2, u32 x3) {
+    u32 e, bw, k0, c0, c, k;
+    const u32 a1 = __builtin_addc(x1, x0, 0u, &e);   // a = (x0, a1), carry e
+    const u32 b0 = __builtin_subc(x0, a1, e, &bw);
+    const u32 b1 = __builtin_subc(a1, 0u, bw, &k0);
+    const u32 r0 = __builtin_subc(x2, b0, 0u, &c0);
+    const u32 r1 = __builtin_subc(x3, b1, c0, &c);
+    const u32 m = 0u - c;                            // EPS when hi < b: r + p = r - EPS (mod 2^64)
+    const u32 f0 = __builtin_subc(r0, m, 0u, &k);
+    const u32 f1 = r1 - k;
+    return (u64)f0 | ((u64)f1 << 32);
+}
+// a * t for a table value stored in MONTGOMERY form (t R mod p, R = 2^64): a (t R) / R = a t.  Any u64 a; the _lazy form returns
+// any residue (for values that are only multiplied again - and Montgomery times Montgomery stays Montgomery), the other canonical.
+__device__ __forceinline__ u64 mul_mont_lazy(u64 a, u64 t_mont) {
+    u32 r0, r1, hl, hh;
+    mul_limbs(a, t_mont, r0, r1, hl, hh);
+    return mont_fold(r0, r1, hl, hh);
+}
+__device__ __forceinline__ u64 mul_mont(u64 a, u64 t_mont) { return canon(mul_mont_lazy(a, t_mont)); }
+// x R mod p on the host (table builders)
+__host__ __device__ inline u64 to_mont_slow(u64 x);
+
 // a * b mod p, any u64 in, canonical out.
 __host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -138,6 +165,7 @@ __host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
 #endif
 }
 __host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
+__host__ __device__ inline u64 to_mont_slow(u64 x) { return mul(x, EPS); }   // R = 2^64 mod p = 2^32 - 1
 
 __host__ __device__ inline u64 pow(u64 b, u64 e) {
     u64 r = 1;

@@ -22,6 +22,11 @@ struct GlNttTables {
     const u64* tw_lo_inv;    // same for w_n^-1
     const u64* tw_hi_inv;
     u64 n_inv;               // n^-1 mod p
+    // the same tables times R = 2^64 mod p (Montgomery form) for the register-radix kernels of kernels_ntt16.hip, whose
+    // multiplications by table values then end in the 8-instruction Montgomery fold (gl::mul_mont) instead of fold128's 11;
+    // tw4096_fwd_m is [8192]: the powers, then the same powers in k_gl_lde_pb16's stage-1 order [slot][tid]
+    const u64 *tw4096_fwd_m, *tw4096_inv_m, *tw_lo_fwd_m, *tw_hi_fwd_m, *tw_lo_inv_m, *tw_hi_inv_m;
+    u64 n_inv_m;
 };
 
 // Coset tables for the LDE of rate 2^rate_bits: coset c (leaf block c) has shift
@@ -30,6 +35,7 @@ struct GlCosetTables {
     u32 rate_bits;
     const u64* pow_lo;  // [2^r][min(n,4096)]
     const u64* pow_hi;  // [2^r][max(1, n/4096)]
+    const u64 *pow_lo_m, *pow_hi_m;  // the same times R (Montgomery form), for kernels_ntt16.hip
 };
 
 // values on H_n (natural order) -> coefficients (natural order), in `coeffs` [ncols][n].

@@ -125,7 +125,7 @@ __device__ __forceinline__ constexpr u32 brevk(u32 x, int k) {
 __device__ __forceinline__ u64 tw_split16(const u64* __restrict__ hi, const u64* __restrict__ lo, u32 e) {
     u32 eh = e >> 10, el = e & 1023;
     u64 w = lo[el];
-    return eh ? gl::mul(w, hi[eh]) : w;
+    return eh ? gl::mul_mont_lazy(w, hi[eh]) : w;   // Montgomery-form tables: (lo R)(hi R) / R = lo hi R, any residue
 }
 
 // The 15 inter-stage twiddles w_4096^(k m), k = brev4(slot), as ONE batch of independent loads issued before the
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
     for (u32 s = 1; s < 16; s++) tw[s] = tw4096[4096 + s * 256 + tid];  // w_4096^(k2 (16 d1 + d0)), k2 = brev4(s)
     dft16<false>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul(x[s], tw[s]) : x[s];
+    for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
     __syncthreads();
     // stage 2: digit d1; this thread is (k2 slot, d0)
     const u32 hi4 = tid >> 4, lo4 = tid & 15;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
     __syncthreads();
 #pragma unroll
     for (u32 s = 0; s < 16; s++)   // w_256^(k1 d0) from LDS; [k2 slot][d0][k1 slot], rows padded to 17
-        sh[hi4 * 272 + lo4 * 17 + s] = s ? gl::mul(x[s], tw256[(brev4(s) * lo4) & 255]) : x[s];
+        sh[hi4 * 272 + lo4 * 17 + s] = s ? gl::mul_mont(x[s], tw256[(brev4(s) * lo4) & 255]) : x[s];
     __syncthreads();
     // stage 3: digit d0; this thread is (k2 slot, k1 slot)
 #pragma unroll
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
         for (u32 a1 = 0; a1 < 16; a1++) x[a1] = ph[a1 * 16];  // s_c^(4096 a): 16 independent loads (entry 0 is 1)
         const u64 sl = pow_lo[(size_t)c * 4096 + l];
 #pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul(orig[a1], x[a1]);
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul_mont(orig[a1], x[a1]);
         dft16<false>(x);
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul(x[s], tw256[(brev4(s) * hi4) & 255]) : x[s];  // w_256^(k_a1 a0); [k_a1 slot][a0][j]
+        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul_mont(x[s], tw256[(brev4(s) * hi4) & 255]) : x[s];  // w_256^(k_a1 a0); [k_a1 slot][a0][j]
         __syncthreads();
         // stage 2 thread = (k_a1 slot = hi4, j): digit a0
 #pragma unroll
@@ -227,11 +227,11 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
         dft16<false>(x);
         u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
         // output twiddle s^l w_n^(k_a l), k_a = k_a1 + 16 k': a geometric progression in k' with ratio w_n^(16 l)
-        u64 f = gl::mul(sl, f0);
+        u64 f = gl::mul_mont_lazy(sl, f0);
 #pragma unroll
         for (u32 k = 0; k < 16; k++) {  // k' = k: slot brev4(k), row position = brev8(k_a)
-            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul(x[brev4(k)], f);
-            if (k < 15) f = gl::mul(f, ratio);
+            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul_mont(x[brev4(k)], f);
+            if (k < 15) f = gl::mul_mont_lazy(f, ratio);
         }
         __syncthreads();
     }
@@ -268,11 +268,11 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16xs(const u64* __restr
 #pragma unroll
         for (u32 a1 = 0; a1 < 16; a1++) x[a1] = ph[a1 << K];  // s_c^(4096 a)
 #pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul(orig[a1], x[a1]);
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul_mont(orig[a1], x[a1]);
         dft16<false>(x);
 #pragma unroll
         for (u32 s = 0; s < 16; s++)  // inter-stage twiddle w_{2^LA}^(k_a1 a0)
-            sh[s * 272 + a0 * M + jl] = (s && a0) ? gl::mul(x[s], tw4096[((brev4(s) * a0) << (12 - LA)) & 4095]) : x[s];
+            sh[s * 272 + a0 * M + jl] = (s && a0) ? gl::mul_mont(x[s], tw4096[((brev4(s) * a0) << (12 - LA)) & 4095]) : x[s];
         __syncthreads();
 #pragma unroll
         for (u32 u = 0; u < M / 16; u++) {
@@ -282,13 +282,13 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16xs(const u64* __restr
             for (u32 b = 0; b < R; b++) y[b] = sh[s2 * 272 + b * M + jj];
             dft_small<false, K>(y);
             // output twiddle s^l w_n^(k_a l), k_a = k_a1 + 16 k': a geometric progression in k' with ratio w_n^(16 l)
-            u64 f = gl::mul(pow_lo[(size_t)c * 4096 + l], tw_split16(tw_hi, tw_lo, ka1 * l));
+            u64 f = gl::mul_mont_lazy(pow_lo[(size_t)c * 4096 + l], tw_split16(tw_hi, tw_lo, ka1 * l));
             const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
             u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
 #pragma unroll
             for (u32 k = 0; k < R; k++) {  // row position = brev_LA(k_a) = slot * 2^K + brevK(k')
-                out[(size_t)(s2 * R + brevk(k, K)) << 12] = gl::mul(y[brevk(k, K)], f);
-                if (k + 1 < R) f = gl::mul(f, ratio);
+                out[(size_t)(s2 * R + brevk(k, K)) << 12] = gl::mul_mont(y[brevk(k, K)], f);
+                if (k + 1 < R) f = gl::mul_mont_lazy(f, ratio);
             }
         }
         __syncthreads();
@@ -314,14 +314,14 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pa_small(const u64* __restri
         const u64* ph = pow_hi + ((size_t)c << K);
         u64 x[16];
 #pragma unroll
-        for (u32 a = 0; a < R; a++) x[a] = a ? gl::mul(orig[a], ph[a]) : orig[a];  // s_c^(4096 a)
+        for (u32 a = 0; a < R; a++) x[a] = a ? gl::mul_mont(orig[a], ph[a]) : orig[a];  // s_c^(4096 a)
         dft_small<false, K>(x);
         u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
         u64 f = pow_lo[(size_t)c * 4096 + l];  // s^l w_n^(k l), k = 0..R-1
 #pragma unroll
         for (u32 k = 0; k < R; k++) {
-            out[(size_t)brevk(k, K) << 12] = gl::mul(x[brevk(k, K)], f);
-            if (k + 1 < R) f = gl::mul(f, ratio);
+            out[(size_t)brevk(k, K) << 12] = gl::mul_mont(x[brevk(k, K)], f);
+            if (k + 1 < R) f = gl::mul_mont_lazy(f, ratio);
         }
     }
 }
@@ -344,14 +344,14 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pa16x1(const u64* __restrict
         const u64* ph = pow_hi + (size_t)c * 16;
         u64 x[16];
 #pragma unroll
-        for (u32 a = 0; a < 16; a++) x[a] = a ? gl::mul(orig[a], ph[a]) : orig[a];
+        for (u32 a = 0; a < 16; a++) x[a] = a ? gl::mul_mont(orig[a], ph[a]) : orig[a];
         dft16<false>(x);
         u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
         u64 f = pow_lo[(size_t)c * 4096 + l];  // s^l w_n^(k l), k = 0..15
 #pragma unroll
         for (u32 k = 0; k < 16; k++) {
-            out[(size_t)brev4(k) << 12] = gl::mul(x[brev4(k)], f);
-            if (k < 15) f = gl::mul(f, ratio);
+            out[(size_t)brev4(k) << 12] = gl::mul_mont(x[brev4(k)], f);
+            if (k < 15) f = gl::mul_mont_lazy(f, ratio);
         }
     }
 }
@@ -384,15 +384,15 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p1(const u64* __restrict_
     const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
     dft16<true>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul(x[s], tw[s]) : x[s];
+    for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
     __syncthreads();
 #pragma unroll
     for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * 272 + a0 * 16 + j];
     dft16<true>(x);
 #pragma unroll
     for (u32 k = 0; k < 16; k++) {
-        dst[base + ((size_t)(ka1 + 16 * k) << LL) + j] = gl::mul(x[brev4(k)], f);
-        if (k < 15) f = gl::mul(f, ratio);
+        dst[base + ((size_t)(ka1 + 16 * k) << LL) + j] = gl::mul_mont(x[brev4(k)], f);
+        if (k < 15) f = gl::mul_mont_lazy(f, ratio);
     }
 }
 
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p2(const u64* __restrict_
     dft16<true>(x);
 #pragma unroll
     for (u32 s = 0; s < 16; s++)
-        dst[cbase + ((size_t)brev4(s) << 16) + ((size_t)ka << 8) + c] = s ? gl::mul(x[s], tw[s]) : x[s];
+        dst[cbase + ((size_t)brev4(s) << 16) + ((size_t)ka << 8) + c] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
 }
 
 // P2 for LB = K in 1..3 (L = 16 + K): the same pass with a radix-2^K DFT over b; src [k_a][b][c] -> dst [k_b][k_a][c]
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p2s(const u64* __restrict
     dft_small<true, K>(x);
 #pragma unroll
     for (u32 s = 0; s < R; s++)
-        dst[cbase + ((size_t)brevk(s, K) << 16) + ((size_t)ka << 8) + c] = s ? gl::mul(x[s], tw[s]) : x[s];
+        dst[cbase + ((size_t)brevk(s, K) << 16) + ((size_t)ka << 8) + c] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
 }
 
 // P3: grid = ncols * 2^LB * 16; tile 16 k_a x 256 c (c = 16 c1 + c0); src [k_b][k_a][c];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p3(const u64* __restrict_
     load_tw16(tw, tw4096, lo4 * 16);  // w_256^-(k_c1 c0)
     dft16<true>(x);
 #pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[s * 272 + lo4 * 17 + hi4] = s ? gl::mul(x[s], tw[s]) : x[s];  // [k_c1 slot][c0][ia], rows padded to 17
+    for (u32 s = 0; s < 16; s++) sh[s * 272 + lo4 * 17 + hi4] = s ? gl::mul_mont(x[s], tw[s]) : x[s];  // [k_c1 slot][c0][ia], rows padded to 17
     __syncthreads();
     // stage 2 thread = (k_c1 slot = hi4, ia = lo4): digit c0
 #pragma unroll
@@ -465,11 +465,13 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p3(const u64* __restrict_
 #pragma unroll
     for (u32 s = 0; s < 16; s++) {
         const u32 kc = kc1 + 16 * brev4(s);
-        dst[cbase + ((size_t)kc << (8 + g.LB)) + ((size_t)kb << 8) + 16 * ga + lo4] = gl::mul(x[s], n_inv);
+        dst[cbase + ((size_t)kc << (8 + g.LB)) + ((size_t)kb << 8) + 16 * ga + lo4] = gl::mul_mont(x[s], n_inv);
     }
 }
 
 // ------------------------------------------------------------------ launchers (called from kernels_ntt.hip's dispatchers)
+// Every kernel of this file takes the MONTGOMERY-form copies of the tables (GlNttTables::*_m, GlCosetTables::*_m): all of their
+// general multiplications have a table value as one factor (gl::mul_mont).
 
 bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream) {
     const u32 L = t.log_n;
@@ -477,15 +479,15 @@ bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols
     Inv16Geom g{L, L - 16};
     const u32 LL = g.LB + 8;
     u64* p1_dst = g.LB ? coeffs : scratch;
-    hipLaunchKernelGGL(k_gl_intt16_p1, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv,
-                       t.tw_hi_inv, t.tw_lo_inv);
+    hipLaunchKernelGGL(k_gl_intt16_p1, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv_m,
+                       t.tw_hi_inv_m, t.tw_lo_inv_m);
     const dim3 g2((u32)(ncols << 8));
-    if (g.LB == 4) hipLaunchKernelGGL(k_gl_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv);
-    else if (g.LB == 3) hipLaunchKernelGGL(k_gl_intt16_p2s<3>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
-    else if (g.LB == 2) hipLaunchKernelGGL(k_gl_intt16_p2s<2>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
-    else if (g.LB == 1) hipLaunchKernelGGL(k_gl_intt16_p2s<1>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
+    if (g.LB == 4) hipLaunchKernelGGL(k_gl_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv_m);
+    else if (g.LB == 3) hipLaunchKernelGGL(k_gl_intt16_p2s<3>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv_m);
+    else if (g.LB == 2) hipLaunchKernelGGL(k_gl_intt16_p2s<2>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv_m);
+    else if (g.LB == 1) hipLaunchKernelGGL(k_gl_intt16_p2s<1>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv_m);
     hipLaunchKernelGGL(k_gl_intt16_p3, dim3((u32)(ncols << (g.LB + 4))), dim3(THREADS), 0, stream, scratch, coeffs, g,
-                       t.tw4096_inv, t.n_inv);
+                       t.tw4096_inv_m, t.n_inv_m);
     return true;
 }
 
@@ -493,17 +495,17 @@ bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables&
     const u32 L = t.log_n;
     if (L == 20) {
         hipLaunchKernelGGL(k_gl_lde_pa16x2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, ct.rate_bits,
-                           t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+                           t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
         return true;
     }
 #define GB_PAS(KK)                                                                                                        \
     hipLaunchKernelGGL(k_gl_lde_pa16xs<KK>, dim3((u32)(ncols << (4 + KK))), dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, \
-                       t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi)
+                       t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m)
     if (L >= 13 && L <= 15) {
         const dim3 grid((u32)(ncols << 4));
-        if (L == 13) hipLaunchKernelGGL(k_gl_lde_pa_small<1>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-        if (L == 14) hipLaunchKernelGGL(k_gl_lde_pa_small<2>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-        if (L == 15) hipLaunchKernelGGL(k_gl_lde_pa_small<3>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        if (L == 13) hipLaunchKernelGGL(k_gl_lde_pa_small<1>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
+        if (L == 14) hipLaunchKernelGGL(k_gl_lde_pa_small<2>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
+        if (L == 15) hipLaunchKernelGGL(k_gl_lde_pa_small<3>, grid, dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
         return true;
     }
     if (L == 17) { GB_PAS(1); return true; }
@@ -512,14 +514,14 @@ bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables&
 #undef GB_PAS
     if (L == 16) {
         hipLaunchKernelGGL(k_gl_lde_pa16x1, dim3((u32)(ncols << 4)), dim3(THREADS), 0, stream, coeffs, lde, ct.rate_bits,
-                           t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+                           t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
         return true;
     }
     return false;
 }
 
 void gl_lde_pb_r16(u64* lde, size_t ntiles, const GlNttTables& t, hipStream_t stream) {
-    hipLaunchKernelGGL(k_gl_lde_pb16, dim3((u32)ntiles), dim3(THREADS), 0, stream, lde, t.tw4096_fwd);
+    hipLaunchKernelGGL(k_gl_lde_pb16, dim3((u32)ntiles), dim3(THREADS), 0, stream, lde, t.tw4096_fwd_m);
 }
 
 }  // namespace gbk

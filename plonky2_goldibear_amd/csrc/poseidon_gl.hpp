@@ -154,22 +154,7 @@ __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
     gl::mul_limbs(a, b, r0, r1, hl, hh);
     return gl::fold128(r0, r1, hl, hh);
 }
-// (x0 + 2^32 x1 + 2^64 x2 + 2^96 x3) / 2^64 mod p as SOME u64 congruent to it: Montgomery reduction with R = 2^64, for which
-// p = 2^64 - 2^32 + 1 needs no multiplication (-1/p = -(1 + 2^32) mod 2^64):  a = lo + (lo << 32), b = a - (a >> 32) - carry,
-// r = hi - b, minus EPS when that borrows.  b <= p - 1 for every 128-bit input, so the last step cannot borrow twice.
-// 8 carry ops against fold128's 11.
-__device__ __forceinline__ u64 mont_fold(u32 x0, u32 x1, u32 x2, u32 x3) {
-    u32 e, bw, k0, c0, c, k;
-    const u32 a1 = __builtin_addc(x1, x0, 0u, &e);   // a = (x0, a1), carry e
-    const u32 b0 = __builtin_subc(x0, a1, e, &bw);
-    const u32 b1 = __builtin_subc(a1, 0u, bw, &k0);
-    const u32 r0 = __builtin_subc(x2, b0, 0u, &c0);
-    const u32 r1 = __builtin_subc(x3, b1, c0, &c);
-    const u32 m = 0u - c;                            // EPS when hi < b: r + p = r - EPS (mod 2^64)
-    const u32 f0 = __builtin_subc(r0, m, 0u, &k);
-    const u32 f1 = r1 - k;
-    return (u64)f0 | ((u64)f1 << 32);
-}
+using gl::mont_fold;   // the Montgomery reduction (gl_field.hpp): 8 carry ops against fold128's 11
 // a b / R for two Montgomery-form residues: any u64 in, any u64 out
 __device__ __forceinline__ u64 mul_mont(u64 a, u64 b) {
     u32 r0, r1, hl, hh;
