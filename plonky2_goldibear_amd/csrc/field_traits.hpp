@@ -42,6 +42,17 @@ struct GlF {
     }
     // a + b for a result that is only multiplied (by a canonical partner): canonical here
     static GB_HD T add_lazy(T a, T b) { return gl::add(a, b); }
+    // Multiplication by a per-proof CONSTANT (a challenge, a table value) that the host stores in "constant form": for Goldilocks
+    // c R (Montgomery), so that x c costs 5 mads + 8 carry ops and comes out canonical for canonical x (gl::mul_mont) instead of
+    // 5 + 11 + 4; for BabyBear the device form is Montgomery already.
+    static GB_HD T cform(T c) { return gl::to_mont_slow(c); }
+    static GB_HD T mulc(T x, T c_form) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return gl::mul_mont(x, c_form);
+#else
+        return gl::mul(gl::mul(x, c_form), 0xFFFFFFFE00000001ULL);  // host: x (c R) R^-1; not on any hot path
+#endif
+    }
     static GB_HD T inv(T a) { return gl::inv(a); }
     static GB_HD T pow(T a, u64 e) { return gl::pow(a, e); }
     static GB_HD T generator() { return gl::GENERATOR; }
@@ -78,6 +89,8 @@ struct BbF {
     static GB_HD T mul_lazy(T a, T b) { return bb::mul(a, b); }
     // a + b < 2p unreduced: fine as ONE operand of a Montgomery product whose other operand is canonical (2 p^2 < p 2^32)
     static GB_HD T add_lazy(T a, T b) { return a + b; }
+    static GB_HD T cform(T c) { return c; }
+    static GB_HD T mulc(T x, T c_form) { return bb::mul(x, c_form); }
     static GB_HD T inv(T a) { return bb::inv(a); }
     static GB_HD T pow(T a, u64 e) { return bb::pow(a, e); }
     static GB_HD T generator() { return bb::to_mont(bb::GENERATOR); }

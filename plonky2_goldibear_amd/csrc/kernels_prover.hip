@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
     const T x = F::mul(F::generator(), pow_split(p.w_N, i));  // shifted_x = g * w_N^i
     const size_t jn = ((size_t)cidx << lgn) | brev32((il + 1) & (u32)(n - 1), lgn);  // leaf of i + 2^r
 
-    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash H]  (zh: see k_l0_table)
+    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash H]  (zh: see k_l0_table);
+    // betas and bk = beta * k_j in the field's CONSTANT form (F::cform / F::mulc: Montgomery for Goldilocks)
     const u32 nr = p.num_routed, nterms = p.nterms, R = 1u << r;
     const T* betas = uni;
     const T* gammas = uni + C;
@@ -235,8 +236,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
                     const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
-                    T num = F::add_lazy(wg, F::mul(bk[k * nr + w0 + q], x));
-                    T den = F::add_lazy(wg, F::mul(betas[k], sg[q]));
+                    T num = F::add_lazy(wg, F::mulc(x, bk[k * nr + w0 + q]));
+                    T den = F::add_lazy(wg, F::mulc(sg[q], betas[k]));
                     np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
                     dp[k] = F::mul_lazy(dp[k], den);
                 }
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
                     const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
-                    T num = F::add_lazy(wg, F::mul(bk[k * nr + w0 + q], x));
-                    T den = F::add_lazy(wg, F::mul(betas[k], sg[q]));
+                    T num = F::add_lazy(wg, F::mulc(x, bk[k * nr + w0 + q]));
+                    T den = F::add_lazy(wg, F::mulc(sg[q], betas[k]));
                     np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
                     dp[k] = F::mul_lazy(dp[k], den);
                 }
