@@ -46,6 +46,26 @@ struct GlF {
     // c R (Montgomery), so that x c costs 5 mads + 8 carry ops and comes out canonical for canonical x (gl::mul_mont) instead of
     // 5 + 11 + 4; for BabyBear the device form is Montgomery already.
     static GB_HD T cform(T c) { return gl::to_mont_slow(c); }
+    // Product chains np <- np * f that are only multiplied again: Montgomery steps (8-op fold instead of 11); each step divides
+    // by R, so a chain of `len` factors starts from R^len instead of 1 and ends on the plain product (some residue).
+    static GB_HD T chain_one(u32 len) {
+        constexpr unsigned __int128 R = gl::EPS;
+        struct Tab { u64 v[17]; };
+        constexpr Tab t = [] {
+            Tab x{};
+            unsigned __int128 a = 1;
+            for (int i = 0; i < 17; i++) { x.v[i] = (u64)a; a = a * R % gl::P; }
+            return x;
+        }();
+        return t.v[len];
+    }
+    static GB_HD T mul_chain(T acc, T f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return gl::mul_mont_lazy(acc, f);
+#else
+        return gl::mul(gl::mul(acc, f), 0xFFFFFFFE00000001ULL);
+#endif
+    }
     static GB_HD T mulc(T x, T c_form) {
 #if defined(__HIP_DEVICE_COMPILE__)
         return gl::mul_mont(x, c_form);
@@ -91,6 +111,8 @@ struct BbF {
     static GB_HD T add_lazy(T a, T b) { return a + b; }
     static GB_HD T cform(T c) { return c; }
     static GB_HD T mulc(T x, T c_form) { return bb::mul(x, c_form); }
+    static GB_HD T chain_one(u32) { return bb::R1; }
+    static GB_HD T mul_chain(T acc, T f) { return bb::mul(acc, f); }
     static GB_HD T inv(T a) { return bb::inv(a); }
     static GB_HD T pow(T a, u64 e) { return bb::pow(a, e); }
     static GB_HD T generator() { return bb::to_mont(bb::GENERATOR); }

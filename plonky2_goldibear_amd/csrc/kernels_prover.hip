@@ -227,9 +227,9 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
         for (u32 k = 0; k < C; k++)
             next[k] = m == num_prods ? zs[(size_t)k * N + jn] : zs[((size_t)C + (size_t)k * num_prods + m) * N + j];
         T np[C], dp[C];
-#pragma unroll
-        for (u32 k = 0; k < C; k++) np[k] = dp[k] = F::one();
         const u32 live = min(CH, nr - w0);  // wires in this chunk (uniform); only the tail chunk has fewer than CH
+#pragma unroll
+        for (u32 k = 0; k < C; k++) np[k] = dp[k] = F::chain_one(live);  // F::mul_chain: `live` Montgomery steps end on the plain product
         if (live == CH) {
 #pragma unroll
             for (u32 q = 0; q < CH; q++) {
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
                     const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
                     T num = F::add_lazy(wg, F::mulc(x, bk[k * nr + w0 + q]));
                     T den = F::add_lazy(wg, F::mulc(sg[q], betas[k]));
-                    np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
-                    dp[k] = F::mul_lazy(dp[k], den);
+                    np[k] = F::mul_chain(np[k], num);  // product chains: only multiplied again
+                    dp[k] = F::mul_chain(dp[k], den);
                 }
             }
         } else {
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
                     const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
                     T num = F::add_lazy(wg, F::mulc(x, bk[k * nr + w0 + q]));
                     T den = F::add_lazy(wg, F::mulc(sg[q], betas[k]));
-                    np[k] = F::mul_lazy(np[k], num);  // product chains: only multiplied again
-                    dp[k] = F::mul_lazy(dp[k], den);
+                    np[k] = F::mul_chain(np[k], num);  // product chains: only multiplied again
+                    dp[k] = F::mul_chain(dp[k], den);
                 }
             }
         }
