@@ -182,16 +182,16 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
     const T x = F::mul(F::generator(), pow_split(p.w_N, i));  // shifted_x = g * w_N^i
     const size_t jn = ((size_t)cidx << lgn) | brev32((il + 1) & (u32)(n - 1), lgn);  // leaf of i + 2^r
 
-    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash H]  (zh: see k_l0_table);
+    // uniform tables: [betas c][gammas c][bk c*routed][apow c*nterms][zh R][zh_inv R][pi_hash H][apow again, constant form];
     // betas and bk = beta * k_j in the field's CONSTANT form (F::cform / F::mulc: Montgomery for Goldilocks)
     const u32 nr = p.num_routed, nterms = p.nterms, R = 1u << r;
     const T* betas = uni;
     const T* gammas = uni + C;
     const T* bk = gammas + C;
-    const T* apow = bk + (size_t)C * nr;
-    const T* zh = apow + (size_t)C * nterms;
+    const T* zh = bk + (size_t)C * nr + (size_t)C * nterms;   // behind the plain alpha powers (read by the gate kernels)
     const T* zh_inv = zh + R;
     const T* pi_hash = zh_inv + R;
+    const T* apow = pi_hash + F::H;                           // [c][nterms] alpha powers in constant form (F::mulc)
 
     T acc[C];
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
     for (u32 k = 0; k < C; k++, t++) {
         T term = F::mul(l0, F::sub(zk[k], F::one()));
 #pragma unroll
-        for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mul(term, apow[k2 * nterms + t]));
+        for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mulc(term, apow[k2 * nterms + t]));
     }
     // partial-product checks (util/partial_products.rs:53-77); term index = C + k * nchunks + m
     const u32 num_prods = p.nchunks - 1;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
             const T term = F::sub(F::mul(prev[k], np[k]), F::mul(next[k], dp[k]));
             const u32 tt = C + k * p.nchunks + m;
 #pragma unroll
-            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mul(term, apow[k2 * nterms + tt]));
+            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mulc(term, apow[k2 * nterms + tt]));
             prev[k] = next[k];
         }
     }
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typ
                 term = F::add(term, F::mul(f_c, F::sub(kc, wv)));
             }
 #pragma unroll
-            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mul(term, apow[k2 * nterms + t]));
+            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mulc(term, apow[k2 * nterms + t]));
         }
     }
 #pragma unroll
