@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py - one JSON line for the driver (see DESIGN.md "Measurement").
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N>1 from a bare shell: starts its own N rank processes; under
+                                                        torch.distributed.run it is one of the ranks)
 
 A "step" is one full prove() (plonk/prover.rs:228-447) of the 2^20-row dummy circuit (BASELINE.json configs[2]:
 Goldilocks, standard_recursion_config_gl with num_challenges = 3) from a MatrixWitness to ProofWithPublicInputs
@@ -143,6 +144,14 @@ class ProveLeg:
                 circuit = CircuitData(lctx, log_n, cs_dev, k_is, num_challenges=challenges)
                 wit = DC.dummy_witness(log_n, pi_row, seed=rank * inflight + li)
             self.lanes.append([lctx, circuit, wit, None])
+        # A stream of DIFFERENT witnesses: the dummy witness is zero outside the PublicInputGate row, so witness k of
+        # a lane is the lane's buffer with that row re-written from seed k - N_WITNESSES pinned seeds, cycled, so that a field with a
+        # natural InvZeroPermArg rate (BabyBear: ~1 proof in 5 at 2^20 rows) shows it in `perm_arg_retries` and pays for it in `value`
+        self.pi_row = pi_row
+        gen = DC.dummy_witness_bb if bb else DC.dummy_witness
+        self.rows = [[np.ascontiguousarray(gen(3, 0, seed=(rank * inflight + li) * N_WITNESSES + k)[:, 0]) for k in range(N_WITNESSES)]
+                     for li in range(inflight)]
+        self.step_no = 0
         # prove_with_partition_witness's retry loop (plonk/prover.rs:183-226): on InvZeroPermArg the random wire - last
         # wire of the PublicInputGate row - is re-drawn and the proof redone; failed attempts stay inside the timed region
         self.random_wire = (self.nwires - 1, pi_row)
@@ -158,11 +167,28 @@ class ProveLeg:
             lane[3] = t.pin_memory().numpy().view(lane[2].dtype) if host else t.to(self.dev)
         self.torch.cuda.synchronize()
 
+    def next_witness(self):
+        """re-write the PublicInputGate row of every lane's witness from the next pinned seed (host: 135 / 167 scattered words;
+        HBM-resident: the same through a small copy, ordered before the proof by a device synchronisation)"""
+        k = self.step_no % N_WITNESSES
+        self.step_no += 1
+        for li, lane in enumerate(self.lanes):
+            row = self.rows[li][k]
+            if isinstance(lane[3], np.ndarray):
+                lane[3][:, self.pi_row] = row
+            else:
+                lane[3][:, self.pi_row] = self.torch.from_numpy(row.view(self.idt)).to(self.dev)
+        if not isinstance(self.lanes[0][3], np.ndarray):
+            self.torch.cuda.synchronize()
+
     def step(self):
+        self.next_witness()
+        t0 = time.perf_counter()
         if self.inflight == 1:
             lctx, circuit, _, wit = self.lanes[0]
             self.proof = circuit.prove(wit, random_wire=self.random_wire, rng=self.rng[0])
             self.retries += circuit.perm_arg_retries
+            self.step_log.append((time.perf_counter() - t0, circuit.perm_arg_retries))
         else:
             out, ret = [None] * self.inflight, [0] * self.inflight
 
@@ -191,9 +217,10 @@ class ProveLeg:
         from plonky2_goldibear_amd import sharding
         self.set_witness(host)
         self.rng = [np.random.default_rng(1234 + self.rank * self.inflight + i) for i in range(self.inflight)]
+        self.step_no, self.step_log = 0, []
         for _ in range(warmup):
             self.step()
-        self.retries = 0
+        self.retries, self.step_log = 0, []
         if self.inflight == 1:
             self.ctx.set_profiling(True)  # per-scope HIP events; with several proofs in flight scopes overlap, so only wall time
         self.ctx.scope_reset()
@@ -206,6 +233,11 @@ class ProveLeg:
         scopes = {s: self.ctx.scope_ms(s) for s in SCOPES}
         self.ctx.set_profiling(False)
         return dt, scopes, self.retries
+
+    def no_retry_rate(self):
+        """proofs/s over the timed steps that needed no InvZeroPermArg retry (this rank, one proof in flight); None if none"""
+        clean = [t for t, r in self.step_log if r == 0]
+        return len(clean) / sum(clean) if clean else None
 
     def verify_last(self):
         """outside the timed region: the library's own host-side verifier (gb_verify) on lane 0's last proof"""
@@ -276,6 +308,96 @@ class ProveLeg:
         self.torch.cuda.empty_cache()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Parent of a multi-GPU run started as `python bench.py --gpus N`: N rank processes under torch.distributed.run (the
+    command the driver itself uses), never an exec of this process.  Returns the launcher's exit code (non-zero if any rank failed)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _gpu_local_cpus(device_index):
+    """CPUs of the NUMA node the GPU's PCIe function hangs off (sysfs local_cpulist), or None when it cannot be told"""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        return _parse_cpulist(open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read()) or None
+    except Exception:
+        return None
+
+
+def bind_rank_to_local_cpus(local_rank, local_world, device_index):
+    """numactl-free placement: this rank's threads (and, by first touch, its page-locked witness) go to the cores nearest its
+    GPU; ranks whose GPUs share a NUMA node split that node's cores evenly.  Returns what was set, for the JSON line."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if local_world <= 1 or len(avail) < 2 * local_world:
+        return {"cpus": len(avail), "bound": False}
+    near = [None] * local_world
+    if device_index is not None:
+        import torch
+        ndev = max(1, torch.cuda.device_count())
+        shared = bool(os.environ.get("GB_BENCH_SHARE_DEVICE"))
+        near = [_gpu_local_cpus(j % ndev if shared else j) if (shared or j < ndev) else None for j in range(local_world)]
+    key = lambda j: tuple(sorted(near[j])) if near[j] else None
+    peers = [j for j in range(local_world) if key(j) == key(local_rank)]   # ranks that compete for the same cores
+    pool = [c for c in avail if near[local_rank] is None or c in near[local_rank]] or avail
+    k, m = peers.index(local_rank), len(peers)
+    mine = pool[k * len(pool) // m:(k + 1) * len(pool) // m] or pool
+    os.sched_setaffinity(0, mine)
+    info = {"cpus": len(mine), "bound": True, "first": mine[0], "last": mine[-1], "numa_local": near[local_rank] is not None}
+    print("bench.py rank-local %d: %d cpus [%d..%d]%s" % (local_rank, len(mine), mine[0], mine[-1],
+                                                          " (GPU's NUMA node)" if info["numa_local"] else ""), file=sys.stderr)
+    return info
+
+
+def stub_main(args, rank, world, affinity, dist):
+    """GB_BENCH_STUB=1: the multi-rank flow of main() with the GPU work replaced by a sleep (CPU tests of the launch path)"""
+    from plonky2_goldibear_amd import sharding
+    if os.environ.get("GB_BENCH_STUB_FAIL_RANK") == str(rank):   # test hook: a rank that dies must fail the whole run
+        sys.exit(3)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    sharding.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))   # the last rank is the slow one
+    sharding.barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "proofs/s", "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                          "config": {"workload": "STUB (GB_BENCH_STUB=1): no GPU work, launch-path rehearsal only"},
+                          "stub": True, "affinity": affinity}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def workload_name(leg, witness):
     return ("prove(): 2^%d-row %s dummy circuit (2^%d+1 NoopGates), %s with num_challenges=%d, %s, witness %s -> proof bytes "
             "(%d B)" % (leg.log_n, "BabyBear" if leg.bb else "Goldilocks", leg.log_n - 1,
@@ -284,6 +406,7 @@ def workload_name(leg, witness):
 
 
 HOST_W = "in page-locked host memory, handed over every step"
+N_WITNESSES = 16   # pinned witness seeds a leg cycles through
 
 
 def main():
@@ -308,25 +431,42 @@ def main():
     ap.add_argument("--host-witness", action="store_true", help="(default since round 2; kept for old command lines)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a bare shell: this process has touched no GPU (nothing imported so far does) and stays
+        # the parent of N fresh rank processes; rank 0's JSON line arrives on the inherited stdout
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` from a bare shell, or under "
+                 "torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    stub = bool(os.environ.get("GB_BENCH_STUB"))
+
+    import torch
+    import torch.distributed as dist
+
     # rehearsal switches (not used by the driver): GB_BENCH_BACKEND=gloo and GB_BENCH_SHARE_DEVICE=1 let several ranks share
-    # the one GPU of a test box, to exercise the multi-rank flow without a multi-GPU node
-    if os.environ.get("GB_BENCH_SHARE_DEVICE"):
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
+    # the one GPU of a test box, to exercise the multi-rank flow without a multi-GPU node; GB_BENCH_STUB=1 replaces the GPU
+    # work of a step by a sleep, so that launch -> rendezvous -> barrier -> max-over-ranks -> JSON line runs on a CPU-only box
+    device_index = local_rank
+    if os.environ.get("GB_BENCH_SHARE_DEVICE") and not stub:
+        device_index = local_rank % max(1, torch.cuda.device_count())
+    affinity = bind_rank_to_local_cpus(local_rank, local_world, None if stub else device_index)
+    if not stub:
+        torch.cuda.set_device(device_index)
+    local_rank = device_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GB_BENCH_BACKEND", "nccl")
+        backend = os.environ.get("GB_BENCH_BACKEND", "gloo" if stub else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    if stub:
+        return stub_main(args, rank, world, affinity, dist)
 
     from plonky2_goldibear_amd import GpuContext, PolynomialBatch, sharding
 
@@ -351,6 +491,9 @@ def main():
             out["scopes_ms_per_step"] = {k: v[0] / steps for k, v in scopes.items() if v[1]}
             out["verified"] = leg.verify_last()
             out["perm_arg_retries"] = retries  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
+            out["value_no_retry"] = _num(leg.no_retry_rate() and world * leg.no_retry_rate())
+            out["witnesses"] = "%d pinned seeds, cycled: every step proves a different witness" % N_WITNESSES
+            out["affinity"] = affinity
         if not args.no_resident:
             dt2, scopes2, _ = leg.timed(steps, args.warmup, host=False)
             if rank == 0:
@@ -367,7 +510,8 @@ def main():
             bb.update(bleg.report(steps, bscopes, inflight))
             bb["scopes_ms_per_step"] = {k: v[0] / steps for k, v in bscopes.items() if v[1]}
             bb["verified"] = bleg.verify_last()
-            bb["perm_arg_retries"] = bret
+            bb["perm_arg_retries"] = bret     # at their natural rate: `value` has the re-done proofs inside, value_no_retry has not
+            bb["value_no_retry"] = _num(bleg.no_retry_rate())
             if not args.no_resident:
                 bdt2, _, _ = bleg.timed(steps, args.warmup, host=False)
                 bb["value_hbm_resident"] = steps * inflight / bdt2

@@ -38,6 +38,15 @@ struct GlCosetTables {
     const u64 *pow_lo_m, *pow_hi_m;  // the same times R (Montgomery form), for kernels_ntt16.hip
 };
 
+// Column groups of the multi-pass transforms (kernels_ntt.hip): 0 = one launch per pass over all columns.  Defaults are the
+// measured optimum; GB_LDE_GROUP / GB_PA_LOG_SPLIT / GB_INTT_GROUP (environment, read once) override them for ablations.
+struct NttKnobs {
+    u32 lde_group;     // Goldilocks columns per PA -> PB group (BabyBear: twice as many)
+    u32 pa_log_split;  // log2 of the workgroups that share a PA tile's cosets
+    u32 intt_group;    // Goldilocks columns per inverse-transform group (BabyBear: twice as many)
+};
+const NttKnobs& ntt_knobs();
+
 // values on H_n (natural order) -> coefficients (natural order), in `coeffs` [ncols][n].
 // `scratch` must hold ncols*n elements. src may equal coeffs.
 void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);

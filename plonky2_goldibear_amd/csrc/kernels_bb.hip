@@ -5,6 +5,8 @@
 // fri/oracle.rs:68-150 (IFFT, FFT + blinding, transpose + bit-reverse folded into the leaf order),
 // hash/merkle_tree.rs:86-181 with Poseidon2BabyBearHash (hash/poseidon2_babybear.rs:163-176).
 // Device-resident element data is in Montgomery form; digests are canonical.
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "poseidon2_bb.hpp"
 #include "poseidon2_bb_coop.hpp"
@@ -379,10 +381,20 @@ static inline u32 nblk(size_t n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 
 // radix-16 register kernels (kernels_bb16.hip); return false when the shape is not covered
 bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
-bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream);
+bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, u32 log_split,
+                   hipStream_t stream);
+// column groups sized for the Infinity Cache: ntt_knobs() (kernels_ntt.hip)
+
+static void bb_intt_group(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
+void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
+    const size_t g = 2 * (size_t)ntt_knobs().intt_group, n = (size_t)1 << t.log_n;   // 4-byte words: twice Goldilocks' columns per group
+    if (g == 0 || t.log_n < 18 || ncols <= g) return bb_intt_group(src, coeffs, scratch, ncols, t, stream);
+    for (size_t c0 = 0; c0 < ncols; c0 += g)
+        bb_intt_group(src + c0 * n, coeffs + c0 * n, scratch, std::min(g, ncols - c0), t, stream);
+}
 void bb_lde_pb_r16(u32* lde, size_t ntiles, const BbNttTables& t, hipStream_t stream);
 
-void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
+static void bb_intt_group(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
     const u32 L = t.log_n;
     if (!ncols) return;
     if (L <= 12) {
@@ -409,10 +421,17 @@ void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables
                            ct.pow_lo);
         return;
     }
-    if (!bb_lde_pa_r16(coeffs, lde, ncols, t, ct, stream))
-        hipLaunchKernelGGL(k_bb_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
-                           t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-    bb_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
+    size_t g = 2 * (size_t)ntt_knobs().lde_group;
+    if (g == 0 || L < 18) g = ncols;
+    for (size_t c0 = 0; c0 < ncols; c0 += g) {
+        const size_t cc = std::min(g, ncols - c0);
+        const u32* cg = coeffs + (c0 << L);
+        u32* lg = lde + (c0 << (L + r));
+        if (!bb_lde_pa_r16(cg, lg, cc, t, ct, ntt_knobs().pa_log_split, stream))
+            hipLaunchKernelGGL(k_bb_lde_pa, dim3((u32)(cc << 8)), dim3(THREADS), 0, stream, cg, lg, L, r, t.tw4096_fwd,
+                               t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        bb_lde_pb_r16(lg, cc << (r + L - 12), t, stream);
+    }
 }
 // as for Goldilocks (kernels_merkle.hip): below this many states the lane-per-state kernels are latency-bound
 static constexpr u64 BB_COOP_MAX_STATES = 16384;

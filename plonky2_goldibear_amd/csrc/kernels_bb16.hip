@@ -171,12 +171,15 @@ template <u32 JW>
 __global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 L, u32 rate_bits,
                                                             const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
                                                             const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
-                                                            const u32* __restrict__ pow_hi) {
+                                                            const u32* __restrict__ pow_hi, u32 log_split) {
     constexpr u32 ROW = 16 * JW;  // one k_a1 slot: [a0][j]; 4-byte words, consecutive j -> consecutive banks
     __shared__ u32 sh[16 * ROW];
     constexpr u32 TPC = 4096 / JW;  // tiles per column
-    const size_t col = blockIdx.x / TPC;
-    const u32 tg = blockIdx.x % TPC;
+    // log_split > 0: a tile's cosets are shared among 2^log_split workgroups 8 blocks apart (same XCD: kernels_ntt16.hip)
+    const u32 bt = ((blockIdx.x >> (3 + log_split)) << 3) | (blockIdx.x & 7);
+    const u32 split = (blockIdx.x >> 3) & ((1u << log_split) - 1);
+    const size_t col = bt / TPC;
+    const u32 tg = bt % TPC;
     const u32 tid = threadIdx.x, hi4 = tid / JW, j = tid % JW;
     const u32 l = tg * JW + j;
     const size_t n = (size_t)1 << L;
@@ -184,12 +187,12 @@ __global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict
     u32 orig[16];
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
-    const u32 ncosets = 1u << rate_bits;
+    const u32 cpw = (1u << rate_bits) >> log_split;  // cosets per workgroup
     const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 16 * l);
     const u32 f0 = bb_tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // w_n^(k_a1 l)
     u32 tw[16];
     load_tw16(tw, tw4096, hi4 * 16);  // w_256^(k_a1 a0): the same for every coset
-    for (u32 c = 0; c < ncosets; c++) {
+    for (u32 c = split * cpw; c < (split + 1) * cpw; c++) {
         const u32* ph = pow_hi + (size_t)c * 256 + hi4;
         u32 x[16];
 #pragma unroll
@@ -469,11 +472,13 @@ bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols
     return true;
 }
 
-bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream) {
+bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, u32 log_split,
+                   hipStream_t stream) {
     const u32 L = t.log_n;
     if (L == 20) {
-        hipLaunchKernelGGL(k_bb_lde_pa16x2<32>, dim3((u32)(ncols << 7)), dim3(512), 0, stream, coeffs, lde, L, ct.rate_bits,
-                           t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        if (log_split > ct.rate_bits) log_split = ct.rate_bits;
+        hipLaunchKernelGGL(k_bb_lde_pa16x2<32>, dim3((u32)(ncols << (7 + log_split))), dim3(512), 0, stream, coeffs, lde, L, ct.rate_bits,
+                           t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi, log_split);
         return true;
     }
 #define GB_PAS(KK)                                                                                                        \

@@ -14,6 +14,9 @@
 //     PA: per coset: scale by s^(4096 a), DFT over a (LA = L-12 bits), twiddle w_n^(k_a l) s^l
 //     PB: contiguous 4096-point DIF, natural -> bit-reversed = leaf order
 //  L <= 12: one tile per column (inverse) / per (column, coset) (LDE).
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "gl_field.hpp"
 
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb(const u64* __restrict__ c
 
 // radix-16 register kernels (kernels_ntt16.hip); return false when the shape is not covered
 bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
-bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, hipStream_t stream);
+bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, u32 log_split,
+                   hipStream_t stream);
 void gl_lde_pb_r16(u64* lde, size_t ntiles, const GlNttTables& t, hipStream_t stream);
 
 static InvGeom inv_geom(u32 L) {
@@ -241,7 +245,28 @@ static InvGeom inv_geom(u32 L) {
     return g;
 }
 
+// Column groups (2^20 rows and up): the passes of one transform run group by group, so that what one pass writes is still in the
+// 256 MiB Infinity Cache when the next pass reads it - a 2^23-point LDE column is 64 MiB between PA and PB, a 2^20-row inverse
+// transform 8 MiB per column and buffer.  Tuning knobs for the ablations of DESIGN.md (environment, read once).
+static u32 ntt_knob(const char* name, u32 dflt) {
+    const char* s = getenv(name);
+    return s && *s ? (u32)atoi(s) : dflt;
+}
+const NttKnobs& ntt_knobs() {
+    static const NttKnobs k{ntt_knob("GB_LDE_GROUP", 0), ntt_knob("GB_PA_LOG_SPLIT", 0), ntt_knob("GB_INTT_GROUP", 0)};
+    return k;
+}
+
+static void gl_intt_group(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
+
 void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream) {
+    const size_t g = ntt_knobs().intt_group, n = (size_t)1 << t.log_n;
+    if (g == 0 || t.log_n < 18 || ncols <= g) return gl_intt_group(src, coeffs, scratch, ncols, t, stream);
+    for (size_t c0 = 0; c0 < ncols; c0 += g)   // the scratch block of one group is reused by the next: it never leaves the cache
+        gl_intt_group(src + c0 * n, coeffs + c0 * n, scratch, std::min(g, ncols - c0), t, stream);
+}
+
+static void gl_intt_group(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream) {
     const u32 L = t.log_n;
     if (ncols == 0) return;
     if (L <= 12) {
@@ -272,10 +297,17 @@ void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables
                            t.tw4096_fwd, ct.pow_lo);
         return;
     }
-    if (!gl_lde_pa_r16(coeffs, lde, ncols, t, ct, stream))
-        hipLaunchKernelGGL(k_gl_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
-                           t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-    gl_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
+    size_t g = ntt_knobs().lde_group;
+    if (g == 0 || L < 18) g = ncols;
+    for (size_t c0 = 0; c0 < ncols; c0 += g) {
+        const size_t cc = std::min(g, ncols - c0);
+        const u64* cg = coeffs + (c0 << L);
+        u64* lg = lde + (c0 << (L + r));
+        if (!gl_lde_pa_r16(cg, lg, cc, t, ct, ntt_knobs().pa_log_split, stream))
+            hipLaunchKernelGGL(k_gl_lde_pa, dim3((u32)(cc << 8)), dim3(THREADS), 0, stream, cg, lg, L, r, t.tw4096_fwd,
+                               t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        gl_lde_pb_r16(lg, cc << (r + L - 12), t, stream);
+    }
 }
 
 }  // namespace gbk

@@ -189,14 +189,19 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
 // two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
 // 3 waves/SIMD (<= 168 VGPRs, no spills): the tile's 16 coefficients per thread stay in registers across the coset
 // loop, so the coefficients cross HBM once (re-reading them per coset measured the same time but 7x the fetch bytes).
+// log_split > 0: the 2^rate_bits cosets of a tile are shared among 2^log_split workgroups (a column alone then fills the chip:
+// 256 << log_split workgroups), placed 8 blocks apart - blocks b and b + 8 share an XCD, so the tile's coefficients are re-read from
+// that XCD's L2.
 __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 L, u32 rate_bits,
                                                            const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
                                                            const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
-                                                           const u64* __restrict__ pow_hi) {
+                                                           const u64* __restrict__ pow_hi, u32 log_split) {
     __shared__ u64 sh[16 * 272];
     __shared__ u64 tw256[256];  // w_256^m: the stage-1 twiddles, read from LDS at their use (keeps 30 VGPRs free)
-    const size_t col = blockIdx.x >> 8;
-    const u32 tg = blockIdx.x & 255;
+    const u32 bt = ((blockIdx.x >> (3 + log_split)) << 3) | (blockIdx.x & 7);  // (column, tile) index
+    const u32 split = (blockIdx.x >> 3) & ((1u << log_split) - 1);
+    const size_t col = bt >> 8;
+    const u32 tg = bt & 255;
     const u32 tid = threadIdx.x, hi4 = tid >> 4, j = tid & 15;
     const u32 l = (tg << 4) + j;
     const size_t n = (size_t)1 << L;
@@ -206,10 +211,10 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
     __syncthreads();  // tw256 visible
-    const u32 ncosets = 1u << rate_bits;
+    const u32 cpw = (1u << rate_bits) >> log_split;  // cosets per workgroup
     const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
     const u64 f0 = tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // w_n^(k_a1 l)
-    for (u32 c = 0; c < ncosets; c++) {
+    for (u32 c = split * cpw; c < (split + 1) * cpw; c++) {
         const u64* ph = pow_hi + (size_t)c * 256 + hi4;
         u64 x[16];
 #pragma unroll
@@ -491,11 +496,13 @@ bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols
     return true;
 }
 
-bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, hipStream_t stream) {
+bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, u32 log_split,
+                   hipStream_t stream) {
     const u32 L = t.log_n;
     if (L == 20) {
-        hipLaunchKernelGGL(k_gl_lde_pa16x2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, ct.rate_bits,
-                           t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
+        if (log_split > ct.rate_bits) log_split = ct.rate_bits;
+        hipLaunchKernelGGL(k_gl_lde_pa16x2, dim3((u32)(ncols << (8 + log_split))), dim3(THREADS), 0, stream, coeffs, lde, L, ct.rate_bits,
+                           t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m, log_split);
         return true;
     }
 #define GB_PAS(KK)                                                                                                        \

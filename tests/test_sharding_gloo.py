@@ -1,7 +1,10 @@
 """The N > 1 path of bench.py (one process per GPU, independent circuits, barrier + max-over-ranks timing)
 exercised with world_size 2 on the gloo backend - no GPU needed."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -50,3 +53,41 @@ def test_two_rank_sharding_and_timing():
 def test_single_process_is_identity():
     assert sharding.circuits_for_rank(5, 1, 0) == [0, 1, 2, 3, 4]
     assert sharding.max_over_ranks(1.5) == 1.5 and sharding.aggregate_throughput(3, 1.5) == 2.0
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench_parent(extra_env, *args):
+    env = dict(os.environ, GB_BENCH_STUB="1", GB_BENCH_BACKEND="gloo", GB_BENCH_SHARE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", *args],
+                          env=env, capture_output=True, text=True, timeout=240)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): the parent starts two rank processes, relays rank 0's
+    line and exits 0 - the launch path of the driver's multi-GPU run, with the GPU work stubbed out."""
+    r = _run_bench_parent({})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["stub"] is True
+    assert j["ms_per_step"] >= 4.0                      # the slower rank (2 x 2 ms per step) sets the time: max over ranks
+    assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    assert "rank-local 0" in r.stderr and "rank-local 1" in r.stderr   # each rank printed its CPU binding
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    r = _run_bench_parent({"GB_BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_a_mismatched_world_size():
+    env = dict(os.environ, GB_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
