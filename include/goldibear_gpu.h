@@ -118,9 +118,11 @@ gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** di
  * gb_circuit holds what CircuitBuilder::build() leaves in ProverOnlyCircuitData / CommonCircuitData
  * for the prover (plonk/circuit_builder.rs:1214-1312): the constants||sigmas commitment (committed
  * here, :1230-1239), the sigma values, k_is, and circuit_digest (:1300-1312, empty domain separator).
- * Only the gate set of the reference's dummy circuit is evaluated on the GPU:
- * gates sorted by (degree, id) = [NoopGate, ConstantGate{num_constants}, PublicInputGate<H>], one selector
- * column (gates/selectors.rs:142-159); anything else is GB_ERR_UNSUPPORTED and stays on the CPU path.
+ * gb_circuit_create takes the gate set of the reference's dummy circuit: gates sorted by
+ * (degree, id) = [NoopGate, ConstantGate{num_constants}, PublicInputGate<H>], one selector column
+ * (gates/selectors.rs:142-159), evaluated inside the quotient kernel.  gb_circuit_create_gates (below) takes any gate set
+ * over the eighteen gate kinds GB_GATE_* with any selector grouping - every gate DefaultGateSerializer knows except
+ * LookupGate / LookupTableGate, which are GB_ERR_UNSUPPORTED - and evaluates it on the GPU as well.
  * Both of the reference's configurations are served (plonk/config.rs:119-150): GB_GOLDILOCKS = D 2, H 4,
  * Poseidon-12, 8-byte elements; GB_BABYBEAR = D 4 (x^4 - 11), H 8, Poseidon2-16, 4-byte elements.  The quotient
  * kernel is compiled for max_quotient_degree_factor 8 with 1..4 challenges (Goldilocks; also 16 with 1..2) and
@@ -277,7 +279,10 @@ typedef struct gb_challenger_state {
  * fri_proof (fri/prover.rs:29-81): commit phase, proof of work (the MINIMUM nonce), query rounds.  zeta: [D]; `challenger` is the
  * transcript after observe_openings (plonk/prover.rs:418) and is left as the reference leaves it.  fri_proof_out receives the
  * FriProof bytes (util/serialization/mod.rs:1679-1695): commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness -
- * the part of ProofWithPublicInputs between the opening set and the public inputs; *fri_proof_len is the size needed. */
+ * the part of ProofWithPublicInputs between the opening set and the public inputs; *fri_proof_len is the size needed.
+ * On ANY error - GB_ERR_BUFFER_TOO_SMALL of a size query included - *challenger is left exactly as it was passed in, so the
+ * call can be repeated with a buffer of *fri_proof_len bytes and returns the bytes gb_prove would (the query itself runs the
+ * whole stage: ask once, keep the size - it depends on the configuration only). */
 gb_status gb_prove_openings(gb_circuit* c, gb_batch* wires, gb_batch* zs_partial_products, gb_batch* quotient, const void* zeta,
                             gb_challenger_state* challenger, void* fri_proof_out, size_t fri_proof_cap, size_t* fri_proof_len);
 

@@ -157,10 +157,10 @@ class DummyCircuit:
         vals = [cfg.num_wires, cfg.num_routed_wires, self.num_constants, cfg.num_challenges, cfg.rate_bits, cfg.cap_height,
                 cfg.proof_of_work_bits, cfg.num_query_rounds, cfg.arity_bits, cfg.final_poly_bits,
                 cfg.max_quotient_degree_factor, self.degree_bits, self.num_selectors, self.GATE_NOOP, self.GATE_CONSTANT,
-                self.GATE_PI, cfg.num_constants, len(self.gate_table)]
-        for g in self.gate_table:
+                self.GATE_PI, cfg.num_constants, min(16, len(self.gate_table))]
+        for g in self.gate_table[:16]:   # beyond 16 kinds the gate terms come from gate_constraint_terms() anyway
             vals += list(g[:5])   # the C oracle prover knows the kinds without a second parameter
-        vals += [0] * (5 * (16 - len(self.gate_table)))
+        vals += [0] * (5 * (16 - min(16, len(self.gate_table))))
         return (C.c_uint * len(vals))(*vals)
 
 
@@ -211,6 +211,37 @@ class CommonDataCircuit(DummyCircuit):
         return self._cd
 
 
+def gate_constraint_terms(circ, witness, public_inputs=()):
+    """The gate part of eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:741-774) on the prover's whole LDE coset, for any
+    gate set of oracle/gates.py: out[i][j] = sum over the gates of compute_filter(selector)(x_i) * unfiltered constraint j at
+    x_i = shift * w_N^i, num_gate_constraints columns.  The wires and constants at x_i are base-field values; gates.py's
+    evaluators work on the extension algebra, in which a base value v is (v, 0, ..) and every constraint comes out as (c, 0, ..).
+    Pure Python: meant for circuits of 2^6..2^8 rows."""
+    e, cfg = circ.F, circ.cfg
+    r, H, nsel = cfg.rate_bits, e.hout, circ.num_selectors
+    N = circ.n << r
+    pi_hash = [int(x) for x in e.hash_no_pad(np.asarray(list(public_inputs), dtype=e.dtype))]
+    cs = e.mod.PolynomialBatch.from_values(np.ascontiguousarray(circ.constants_sigmas[:circ.num_constants]), r, cfg.cap_height)
+    wb = e.mod.PolynomialBatch.from_values(np.ascontiguousarray(witness, dtype=e.dtype), r, cfg.cap_height)
+    ngc = max(G.num_constraints(g, H, e.D) for g in circ.gate_table)
+    out = np.zeros((N, ngc), dtype=e.dtype)
+    pad = (0,) * (e.D - 1)
+    for i in range(N):
+        consts = [(int(v),) + pad for v in cs.get_lde_values(i, 1)[:circ.num_constants]]
+        wires = [(int(v),) + pad for v in wb.get_lde_values(i, 1)[:cfg.num_wires]]
+        acc = [0] * ngc
+        for row, g in enumerate(circ.gate_table):
+            f = G.compute_filter(e, row, g, consts[g[2]], nsel > 1)
+            assert f[1:] == pad
+            if f[0] == 0:
+                continue
+            for j, cj in enumerate(G.eval_unfiltered(e, g, wires, consts[nsel:], pi_hash)):
+                assert cj[1:] == pad, "a constraint on base-field wires is a base-field value"
+                acc[j] = (acc[j] + f[0] * cj[0]) % e.P
+        out[i] = acc
+    return out
+
+
 def prove_cpu(circ, witness, public_inputs=(), salts=None, dump=None):
     """Run the CPU oracle prover; returns (proof_bytes, debug challenges).  `dump`: a dict that receives the prover's own
     intermediates - "zs_partial_products" [c * (1 + num_partial_products)][n] values as handed to from_values (prover.rs:318-329)
@@ -239,16 +270,29 @@ def prove_cpu(circ, witness, public_inputs=(), salts=None, dump=None):
     out = np.zeros(cap, dtype=np.uint8)
     out_len = C.c_size_t()
     dbg = np.zeros(3 * c + 2 * F.D + 1, dtype=F.dtype)  # betas, gammas, alphas, zeta, fri_alpha, pow response
-    rc = fn(circ.c_cfg(), cs.ctypes.data_as(C.c_void_p), dig.ctypes.data_as(C.c_void_p), circ.k_is.ctypes.data_as(C.c_void_p),
-            wit.ctypes.data_as(C.c_void_p), pis.ctypes.data_as(C.c_void_p), C.c_size_t(len(public_inputs)),
-            out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p),
-            salts.ctypes.data_as(C.c_void_p) if salts is not None else None)
-    if dump is not None:
-        getattr(L, F.prove_symbol + "_set_dump")(None, None)
+    gate_terms = None
+    if any(g[0] > G.POSEIDON2_BABYBEAR for g in getattr(circ, "gate_table", ())):
+        # gates the C prover has no evaluator for (the recursion gate set): their terms come from oracle/gates.py
+        gate_terms = np.ascontiguousarray(gate_constraint_terms(circ, wit, public_inputs))
+        getattr(L, F.prove_symbol + "_set_gate_terms")(gate_terms.ctypes.data_as(C.c_void_p), C.c_uint(gate_terms.shape[1]))
+    try:
+        rc = _call_prover(fn, circ, cs, dig, wit, pis, public_inputs, out, cap, out_len, dbg, salts)
+    finally:
+        if gate_terms is not None:
+            getattr(L, F.prove_symbol + "_set_gate_terms")(None, C.c_uint(0))
+        if dump is not None:
+            getattr(L, F.prove_symbol + "_set_dump")(None, None)
     if rc != 0:
         raise RuntimeError("oracle prover failed: rc=%d" % rc)
     prove_cpu.last_cs_commit_seconds = C.c_double.in_dll(L, "gbo_last_cs_commit_seconds").value  # build() share of the call
     return out[: out_len.value].tobytes(), dbg
+
+
+def _call_prover(fn, circ, cs, dig, wit, pis, public_inputs, out, cap, out_len, dbg, salts):
+    return fn(circ.c_cfg(), cs.ctypes.data_as(C.c_void_p), dig.ctypes.data_as(C.c_void_p), circ.k_is.ctypes.data_as(C.c_void_p),
+            wit.ctypes.data_as(C.c_void_p), pis.ctypes.data_as(C.c_void_p), C.c_size_t(len(public_inputs)),
+            out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(out_len), dbg.ctypes.data_as(C.c_void_p),
+            salts.ctypes.data_as(C.c_void_p) if salts is not None else None)
 
 
 # ----------------------------------------------------------------------------- verify()

@@ -111,6 +111,14 @@ static F_T *dump_zs_values = NULL, *dump_quotient_chunks = NULL;
 #define X_CAT2(a, b) a##b
 #define X_CAT(a, b) X_CAT2(a, b)
 void X_CAT(X_PROVE_DUMMY, _set_dump)(F_T *zs_values, F_T *quotient_chunks) { dump_zs_values = zs_values; dump_quotient_chunks = quotient_chunks; }
+/* Gate sets beyond the five kinds evaluated below (the recursion circuits' gates): the caller hands over the gate part of
+ * eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:741-774) - for every LDE point i (index of shift * w_N^i) the
+ * num_gate_constraints sums  sum_gates filter(selector) * unfiltered_constraint_j  - computed by oracle/plonk_dummy.py
+ * gate_constraint_terms() with the evaluators of oracle/gates.py (the ones the reference's recursion proof pins);
+ * [N][nterms], used by the next proof instead of the inline evaluators. */
+static const F_T *ext_gate_terms = NULL;
+static unsigned ext_gate_nterms = 0;
+void X_CAT(X_PROVE_DUMMY, _set_gate_terms)(const F_T *terms, unsigned nterms) { ext_gate_terms = terms; ext_gate_nterms = nterms; }
 
 /* Status: 0 ok, 1 = InvZeroPermArg (plonk/prover.rs:512-514), 2 = opening point in subgroup, <0 internal */
 int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas /*[ncs][n] values*/,
@@ -228,9 +236,10 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
             unsigned m = kind == 1 || kind == 3 ? param : (kind == 2 ? HOUT : (kind == 4 ? 123 : (kind == 5 ? 150 * param : 0)));
             if (m > ngc) ngc = m;
         }
+        if (ext_gate_terms) ngc = ext_gate_nterms;
         const unsigned nterms = c + c * nchunks + ngc; /* z_1 terms, partial product terms, gate constraints */
         const unsigned nsel = cfg->num_selectors;
-        if (nterms > GBO_MAX_TERMS || ngc > GBO_MAX_GATE_CONSTRAINTS || cfg->num_gates > 16) { rc = -11; goto done; }
+        if (nterms > GBO_MAX_TERMS || ngc > GBO_MAX_GATE_CONSTRAINTS || (!ext_gate_terms && cfg->num_gates > 16)) { rc = -11; goto done; }
         /* Rayon par_chunks(BATCH_SIZE = 32) over the points (prover.rs:791-797) */
 #pragma omp parallel for schedule(static)
         for (size_t i0 = 0; i0 < N; i0 += 32) {
@@ -259,7 +268,9 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
                 }
             }
             /* gate constraints (vanishing_poly.rs:741-774): filter * unfiltered, summed per constraint index */
-            {
+            if (ext_gate_terms) {
+                for (unsigned j = 0; j < ngc; j++) terms[t++] = ext_gate_terms[i * ngc + j];
+            } else {
                 const F_T *gc = consts + nsel; /* remove_prefix(num_selectors) */
                 F_T cons[GBO_MAX_GATE_CONSTRAINTS], gcons[GBO_MAX_GATE_CONSTRAINTS];
                 for (unsigned j = 0; j < ngc; j++) cons[j] = 0;

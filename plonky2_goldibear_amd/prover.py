@@ -225,10 +225,12 @@ class CircuitData(_ProofBytesOps):
                                             g.ctypes.data, a.ctypes.data, N.GB_INPUT_HOST, out.ctypes.data), self.ctx.handle)
         return out
 
-    def prove_openings(self, wires, zs_partial_products, quotient, zeta, challenger):
+    def prove_openings(self, wires, zs_partial_products, quotient, zeta, challenger, out_cap=None):
         """PolynomialBatch::prove_openings on this circuit's FRI instance (fri/oracle.rs:187-246, plonk/prover.rs:422-437).
         `challenger` = (sponge_state, input_buffer, output_buffer) after observe_openings, canonical ints.
-        -> (FriProof bytes, challenger afterwards in the same form)"""
+        -> (FriProof bytes, challenger afterwards in the same form).  `out_cap` (tests): capacity handed to the library instead
+        of the wrapper's own buffer; when it is too small the call raises (status GB_ERR_BUFFER_TOO_SMALL) after recording the
+        size the library asked for in `last_fri_proof_len` and the challenger it handed back in `last_challenger`."""
         d = 2 if self.field == N.GB_GOLDILOCKS else 4
         z = np.ascontiguousarray(zeta, dtype=self._dt)
         if z.shape != (d,):
@@ -248,10 +250,13 @@ class CircuitData(_ProofBytesOps):
         if self._proof_buf is None:
             self._proof_buf = np.empty(8 << 20, dtype=np.uint8)
         n = C.c_size_t()
-        N.check(self._lib.gb_prove_openings(self.handle, wires.handle, zs_partial_products.handle, quotient.handle, z.ctypes.data,
-                                            C.byref(cs), self._proof_buf.ctypes.data, self._proof_buf.size, C.byref(n)), self.ctx.handle)
+        cap = self._proof_buf.size if out_cap is None else min(int(out_cap), self._proof_buf.size)
+        st = self._lib.gb_prove_openings(self.handle, wires.handle, zs_partial_products.handle, quotient.handle, z.ctypes.data,
+                                         C.byref(cs), self._proof_buf.ctypes.data if cap else None, cap, C.byref(n))
         after = ([int(cs.sponge_state[i]) for i in range(w)], [int(cs.input_buffer[i]) for i in range(cs.input_len)],
                  [int(cs.output_buffer[i]) for i in range(cs.output_len)])
+        self.last_fri_proof_len, self.last_challenger = n.value, after
+        N.check(st, self.ctx.handle)
         return self._proof_buf[: n.value].tobytes(), after
 
     def verify(self, proof_bytes):

@@ -1,11 +1,13 @@
 """GPU prove() of circuits that use the recursion gate set (csrc/gates.hpp: ArithmeticExtension, MulExtension, BaseSum,
-Reducing, ReducingExtension, RandomAccess, PoseidonMds, CosetInterpolation, Exponentiation), both fields, through the C ABI.
+Reducing, ReducingExtension, RandomAccess, PoseidonMds, CosetInterpolation, Exponentiation, AddMany, ApplyMat4,
+Poseidon2InternalPermutation), both fields, through the C ABI.
 
-Parity bar for these gates: the proof is accepted by the oracle verifier (oracle/plonk_dummy.verify with oracle/gates.py, whose
-evaluators the reference's own regression proof pins one by one - tests/test_oracle_fixture.py) and by gb_verify (pinned the same
-way - tests/test_abi_verify_fixture.py).  A valid witness's constraint polynomials are non-zero off the subgroup, so the quotient
-the GPU commits only matches vanishing(zeta) if k_gate_constraints evaluated every gate correctly on the whole LDE coset.
-(The CPU oracle PROVER has no evaluators for these gates, so there is no byte comparison here.)  -m gpu only."""
+Parity bar (round 3): an ORACLE COMPARISON on the prover's coset.  oracle/plonk_dummy.gate_constraint_terms evaluates every gate
+of the set at every LDE point with the evaluators of oracle/gates.py - the ones the reference's own regression proof pins one by
+one (tests/test_oracle_fixture.py) - and the CPU oracle prover builds its quotient from them (plonk/vanishing_poly.rs:741-774):
+the GPU's quotient chunk coefficients (gb_quotient_polys) equal the oracle's element for element, and the proof bytes are
+identical.  On top of that the proof is accepted by the oracle verifier and by gb_verify, and a perturbed gate row is rejected
+by both.  The 2^12-row circuit below stays acceptance-only (the pure-Python evaluators take ~30 ms per LDE point).  -m gpu only."""
 import numpy as np
 import pytest
 
@@ -27,8 +29,9 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("field,public_inputs", [(N.GB_GOLDILOCKS, True), (N.GB_GOLDILOCKS, False), (N.GB_BABYBEAR, True)])
-def test_recursion_gate_rows_prove_and_verify(ctx, field, public_inputs):
+@pytest.mark.parametrize("field,public_inputs", [(N.GB_GOLDILOCKS, True), (N.GB_GOLDILOCKS, False), (N.GB_BABYBEAR, True),
+                                                 (N.GB_BABYBEAR, False)])
+def test_recursion_gate_rows_equal_the_oracle_prover(ctx, field, public_inputs):
     b, pw, rows = recursion_gates_circuit(field, seed=7, public_inputs=public_inputs)
     c = b.build(ctx)
     w, pis = c.generate_witness(pw)
@@ -36,6 +39,15 @@ def test_recursion_gate_rows_prove_and_verify(ctx, field, public_inputs):
     assert c.data.verify(proof)
     oc = oracle_circuit(c, len(pis))
     assert (c.data.circuit_digest == oc.circuit_digest).all()
+    # the oracle prover with every gate evaluated on the whole coset by oracle/gates.py: same quotient, same bytes
+    oc.set_cap(c.data.constants_sigmas_cap)
+    dump, mid = {}, {}
+    want, _ = PD.prove_cpu(oc, w, pis, dump=dump)
+    assert proof == want
+    from test_gpu_stage_abi import prove_by_stages
+    assert prove_by_stages(c.data, oc, w, pis, field, mid) == want
+    assert (mid["zs_partial_products"] == dump["zs_partial_products"]).all()
+    assert (mid["quotient_chunks"] == dump["quotient_chunks"]).all()
     stats = {}
     assert PD.verify(oc, proof, stats)
     assert c.data.prove(w, pis) == proof  # deterministic

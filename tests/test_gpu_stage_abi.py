@@ -130,6 +130,34 @@ def test_stage_by_stage_equals_oracle_prover(ctx, field_name, degree_bits, num_c
     gpu.free()
 
 
+def test_prove_openings_size_query_leaves_the_challenger_alone(ctx):
+    """a call with too small a buffer reports the size needed and must not advance the caller's Challenger - the
+    retry with that size then returns exactly the bytes (and the transcript) of a call that had room from the start."""
+    circ = D.DummyCircuit(8, D.CircuitConfig(num_challenges=2), F=GL)
+    gpu = _gpu_circuit(ctx, circ, N.GB_GOLDILOCKS)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    w = circ.witness(seed=7)
+    calls = []
+    real = gpu.prove_openings
+
+    def probing(wires, zs, quot, zeta, chal):
+        for cap in (0, 100):                      # a NULL buffer, then a short one
+            with pytest.raises(N.GoldibearError) as e:
+                real(wires, zs, quot, zeta, chal, out_cap=cap)
+            assert e.value.status == N.GB_ERR_BUFFER_TOO_SMALL
+            assert gpu.last_challenger == (list(chal[0]), list(chal[1]), list(chal[2]))   # untouched
+            calls.append(gpu.last_fri_proof_len)
+        out = real(wires, zs, quot, zeta, chal, out_cap=calls[-1])                          # exactly the size asked for
+        assert len(out[0]) == calls[0] == calls[1]
+        return out
+
+    gpu.prove_openings = probing
+    got = prove_by_stages(gpu, circ, w, [], N.GB_GOLDILOCKS)
+    gpu.prove_openings = real
+    assert len(calls) == 2 and got == gpu.prove(w) == D.prove_cpu(circ, w)[0]
+    gpu.free()
+
+
 def test_stages_on_a_general_gate_set(ctx):
     """the factorial example's circuit (ArithmeticGate + PoseidonGate + public inputs, two selector groups): stage by stage =
     oracle prover = gb_prove"""

@@ -80,3 +80,27 @@ def test_gate_order_and_selector_groups_match_the_reference_fixture(golden_dir):
     ci = next(g for g in gates if g.kind == G.COSET_INTERPOLATION)
     assert ci.barycentric_weights == G.barycentric_weights(GL, 4)[1]
     assert (ci.degree, ci.num_intermediates) == (6, 2)
+
+
+@pytest.mark.parametrize("field", [N.GB_GOLDILOCKS, N.GB_BABYBEAR])
+def test_oracle_prover_evaluates_the_recursion_gates_on_the_coset(field):
+    """The CPU oracle prover with the gate terms of oracle/plonk_dummy.gate_constraint_terms (every gate of the recursion set at
+    every LDE point, evaluators of oracle/gates.py): its proof satisfies the vanishing identity under the pinned verifier, and a
+    witness that breaks one gate row does not - the oracle side of tests/test_gpu_recursion_gates.py, runnable without a GPU."""
+    from oracle import plonk_dummy as PD
+    from circuits import oracle_circuit, recursion_gates_circuit
+    b, pw, rows = recursion_gates_circuit(field, seed=11)
+    c = b.build(None)
+    w, pis = c.generate_witness(pw)
+    oc = oracle_circuit(c, len(pis))
+    terms = PD.gate_constraint_terms(oc, w, pis)
+    n, r = 1 << c.degree_bits, oc.cfg.rate_bits
+    assert terms.shape[0] == n << r and terms.any()       # off the subgroup the constraint polynomials do not vanish
+    proof, _ = PD.prove_cpu(oc, w, pis)
+    assert PD.verify(oc, proof)
+    row = rows["coset_interpolation"]
+    gate = b.gate_instances[row][0]
+    bad = w.copy()
+    bad[gate.num_wires - 1, row] = (int(bad[gate.num_wires - 1, row]) + 1) % oc.F.P
+    with pytest.raises(AssertionError, match="vanishing"):
+        PD.verify(oc, PD.prove_cpu(oc, bad, pis)[0])
