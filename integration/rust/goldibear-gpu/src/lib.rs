@@ -15,6 +15,7 @@ pub struct gb_batch { _p: [u8; 0] }
 pub struct gb_circuit { _p: [u8; 0] }
 
 pub const GB_OK: i32 = 0;
+pub const GB_ERR_INVALID: i32 = 1;
 pub const GB_ERR_PERM_ARG_ZERO: i32 = 16;
 pub const GB_ERR_VERIFY: i32 = 19;
 pub const GB_GOLDILOCKS: u32 = 0;
@@ -118,6 +119,14 @@ extern "C" {
 pub struct GpuError {
     pub status: i32,
     pub message: String,
+}
+
+/// The library reads fixed element counts through the raw pointers it is given: a safe wrapper checks the slice first.
+fn need(what: &str, have: usize, want: usize) -> Result<(), GpuError> {
+    if have == want {
+        return Ok(());
+    }
+    Err(GpuError { status: GB_ERR_INVALID, message: format!("{what}: {have} elements, the circuit configuration needs {want}") })
 }
 
 fn check(ctx: *const gb_ctx, status: i32) -> Result<(), GpuError> {
@@ -325,6 +334,8 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
     }
     /// `internal_prove_with_partition_witness` (plonk/prover.rs:228-447): `witness` = wire_values [num_wires][n]
     pub fn prove(&self, witness: &[W], public_inputs: &[u64]) -> Result<ProveOutcome, GpuError> {
+        need("witness", witness.len(), (self.config.num_wires as usize) << self.config.degree_bits)?;
+        need("public_inputs", public_inputs.len(), self.config.num_public_inputs as usize)?;
         let mut buf = vec![0u8; 8 << 20];
         let mut len = 0usize;
         let st = unsafe {
@@ -342,6 +353,9 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
     /// `PolynomialBatch::from_values`, Zs first.  `Ok(None)` = `ProverError::InvZeroPermArg`.
     pub fn zs_partial_products(&self, witness: &[W], betas: &[W], gammas: &[W]) -> Result<Option<Vec<W>>, GpuError> {
         let c = &self.config;
+        need("witness", witness.len(), (c.num_wires as usize) << c.degree_bits)?;
+        need("betas", betas.len(), c.num_challenges as usize)?;
+        need("gammas", gammas.len(), c.num_challenges as usize)?;
         let chunks = (c.num_routed_wires + c.max_quotient_degree_factor - 1) / c.max_quotient_degree_factor;
         let mut out = vec![W::default(); (c.num_challenges * chunks) as usize << c.degree_bits];
         let st = unsafe {
@@ -358,6 +372,10 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
     pub fn quotient_polys(&self, wires: &GpuPolynomialBatch<'c, W>, zs_partial_products: &GpuPolynomialBatch<'c, W>,
                           public_inputs_hash: &[W], betas: &[W], gammas: &[W], alphas: &[W]) -> Result<Vec<W>, GpuError> {
         let c = &self.config;
+        need("public_inputs_hash", public_inputs_hash.len(), if std::mem::size_of::<W>() == 8 { 4 } else { 8 })?;
+        need("betas", betas.len(), c.num_challenges as usize)?;
+        need("gammas", gammas.len(), c.num_challenges as usize)?;
+        need("alphas", alphas.len(), c.num_challenges as usize)?;
         let mut out = vec![W::default(); (c.num_challenges * c.max_quotient_degree_factor) as usize << c.degree_bits];
         check(self.ctx.0, unsafe {
             gb_quotient_polys(self.handle, wires.handle, zs_partial_products.handle, public_inputs_hash.as_ptr() as *const c_void,
@@ -371,6 +389,7 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
     pub fn prove_openings(&self, wires: &GpuPolynomialBatch<'c, W>, zs_partial_products: &GpuPolynomialBatch<'c, W>,
                           quotient: &GpuPolynomialBatch<'c, W>, zeta: &[W], challenger: &mut gb_challenger_state)
                           -> Result<Vec<u8>, GpuError> {
+        need("zeta", zeta.len(), if std::mem::size_of::<W>() == 8 { 2 } else { 4 })?;   // extension degree D
         let mut buf = vec![0u8; 8 << 20];
         let mut len = 0usize;
         check(self.ctx.0, unsafe {

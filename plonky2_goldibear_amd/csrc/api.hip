@@ -138,6 +138,22 @@ gb_status wait_uploads(gb_ctx* ctx) {
     ctx->upload_marked = false;
     return e == hipSuccess ? GB_OK : fail(ctx, GB_ERR_HIP, "waiting for the upload of the host input failed");
 }
+// Every exit of a commit from HOST input: on success wait for the uploads (the kernels behind them keep running); after an error
+// nothing of the call is worth keeping, so wait for both streams - copies from the caller's buffer and into pool blocks that
+// commit()'s cleanup has already handed back may still be in flight - and keep the error that was reported first.  A batch
+// whose uploads cannot be confirmed is freed, not returned.
+gb_status finish_host_commit(gb_ctx* ctx, gb_status s, gb_batch** out) {
+    if (!ctx) return s;
+    if (s == GB_OK) {
+        s = wait_uploads(ctx);
+        if (s != GB_OK && out && *out) { gb_batch_free(*out); *out = nullptr; }
+        return s;
+    }
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->upload_marked = false;
+    return s;
+}
 
 gb_status ensure(gb_ctx* ctx, DeviceBuf& buf, size_t bytes) {
     if (buf.bytes >= bytes) return GB_OK;
@@ -723,14 +739,14 @@ gb_status gb_ctx_scope_reset(gb_ctx* ctx) {
 gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                            uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
     gb_status s = commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, false, out);
-    if (s == GB_OK && !(flags & GB_INPUT_DEVICE)) s = wait_uploads(ctx);   // `cols` / `salts` are the caller's again on return
+    if (!(flags & GB_INPUT_DEVICE)) s = finish_host_commit(ctx, s, out);   // `cols` / `salts` are the caller's again on return
     return s;
 }
 
 gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                            uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
     gb_status s = commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, true, out);
-    if (s == GB_OK && !(flags & GB_INPUT_DEVICE)) s = wait_uploads(ctx);
+    if (!(flags & GB_INPUT_DEVICE)) s = finish_host_commit(ctx, s, out);
     return s;
 }
 

@@ -245,15 +245,19 @@ static InvGeom inv_geom(u32 L) {
     return g;
 }
 
-// Column groups (2^20 rows and up): the passes of one transform run group by group, so that what one pass writes is still in the
-// 256 MiB Infinity Cache when the next pass reads it - a 2^23-point LDE column is 64 MiB between PA and PB, a 2^20-row inverse
-// transform 8 MiB per column and buffer.  Tuning knobs for the ablations of DESIGN.md (environment, read once).
+// Column groups (2^18 rows and up): the passes of one transform can run group by group, so that what one pass writes is still in
+// the 256 MiB Infinity Cache when the next pass reads it - a 2^23-point LDE column is 64 MiB between PA and PB, a 2^20-row inverse
+// transform 8 MiB per column and buffer.  Measured (profiles/r03_ntt_column_group_sweep_*.txt, 135 x 2^20 Goldilocks): the LDE
+// passes do NOT gain from it - they are bound by VALU issue and latency, not by HBM, and small groups only add launch tails
+// (8.55 ms with all columns per launch, 8.7-14.5 ms in groups of 16..1) - so the LDE default stays "all columns"; the three
+// memory-bound passes of the inverse transform gain 8 % in groups of 16 columns (1.49 -> 1.36 ms).  The knobs remain for ablations
+// (environment, read once).
 static u32 ntt_knob(const char* name, u32 dflt) {
     const char* s = getenv(name);
     return s && *s ? (u32)atoi(s) : dflt;
 }
 const NttKnobs& ntt_knobs() {
-    static const NttKnobs k{ntt_knob("GB_LDE_GROUP", 0), ntt_knob("GB_PA_LOG_SPLIT", 0), ntt_knob("GB_INTT_GROUP", 0)};
+    static const NttKnobs k{ntt_knob("GB_LDE_GROUP", 0), ntt_knob("GB_PA_LOG_SPLIT", 0), ntt_knob("GB_INTT_GROUP", 16)};
     return k;
 }
 

@@ -252,6 +252,18 @@ struct Dot {
 // reference's mds_layer :497-528, without its FFT form).
 // `rc`: the constants of the layer that FOLLOWS (next round's constant layer), added into the unreduced sums as two
 // 32-bit halves - two 64-bit adds per word instead of a separate add-with-carry-fix after the fold.
+// sl + 2^32 sh for two unreduced sums of 32-bit halves (sl, sh < 2^63, sh >> 32 < 2^31) as a lazy u64 residue: 2^64 = EPS moves
+// sh's high word onto sl (one mad), sh's low word goes onto the high word, and the one possible carry is worth EPS again.
+__device__ __forceinline__ u64 fold_halves(u64 sl, u64 sh) {
+    const u64 t = sl + (u64)(u32)(sh >> 32) * EPS;
+    u32 cy, k;
+    u32 r1 = __builtin_addc((u32)(t >> 32), (u32)sh, 0u, &cy);
+    const u32 m = 0u - cy;
+    const u32 r0 = __builtin_addc((u32)t, m, 0u, &k);
+    r1 += k;
+    return (u64)r0 | ((u64)r1 << 32);
+}
+
 __device__ __forceinline__ void mds_layer(u64 (&s)[12], const u64* __restrict__ rc) {
     u32 lo[12], hi[12];
 #pragma unroll
