@@ -109,8 +109,20 @@ def _num(x):
 
 
 def _latest_profile(pattern):
+    """newest profiles/ summary matching `pattern`, with "stale": True when the library sources have changed since it was measured
+    (the summary carries the hash of the csrc tree it was taken on, tools/csrc_hash.py; older files carry none and count as stale)"""
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))  # r01e_..., r02_...: newest round last
-    return json.load(open(paths[-1])) if paths else None
+    if not paths:
+        return None
+    j = json.load(open(paths[-1]))
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from csrc_hash import csrc_sha16
+        j["stale"] = j.get("csrc_sha16") != csrc_sha16()
+    except Exception:
+        j["stale"] = None
+    j["profile_file"] = os.path.relpath(paths[-1], ROOT)
+    return j
 
 
 class ProveLeg:
@@ -259,10 +271,17 @@ class ProveLeg:
             for l in range(nlayers))
         return alg_bytes, perms, leaf_perms, nzs, nq
 
-    def report(self, steps, scopes, inflight):
-        """roofline / roofline_alu / merkle objects of one timed region"""
+    def report(self, steps, scopes, inflight, retries=0):
+        """roofline / roofline_alu / merkle objects of one timed region.  A proof that hit InvZeroPermArg redid its wires commitment
+        (prover.rs:183-226): that work is inside the scopes, so it is inside the per-step byte and permutation counts as well."""
         bb, fname = self.bb, self.field
         alg_bytes, perms, leaf_perms, nzs, nq = self.counts()
+        redo = retries / float(steps)   # extra wires commitments per step
+        n_, N_ = 1 << self.log_n, (1 << self.log_n) << 3
+        wires_leaf_perms = N_ * (-(-self.nwires // 8))
+        alg_bytes += int(redo * (2 + 8) * self.nwires * n_ * self.esz)
+        leaf_perms += int(redo * wires_leaf_perms)
+        perms += int(redo * (wires_leaf_perms + N_ - 16))
         live = inflight == 1
         ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps if live else None
         merkle_ms = scopes["build Merkle tree"][0] / steps if live else None
@@ -277,6 +296,7 @@ class ProveLeg:
                              ("k_bb_intt16_*", "k_bb_lde_pa16*+pb16") if bb else ("k_gl_intt16_*", "k_gl_lde_pa16*+pb16")),
                          "achieved": _num(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": _num(achieved / HBM_PEAK_GBS if achieved else None), "traffic": traffic,
+                         "traffic_source": tj and {"file": tj["profile_file"], "stale": tj["stale"]},
                          "algorithmic_bytes": alg_bytes, "ms": _num(ntt_ms)},
             "merkle": {"permutations": perms, "Gperm_per_s": _num(perms / (merkle_ms * 1e-3) / 1e9 if merkle_ms else None),
                        "ms": _num(merkle_ms)},
@@ -292,8 +312,12 @@ class ProveLeg:
         if pj and leaves_ms:
             ipp = pj["valu_instr_per_permutation"]
             ach = ipp * leaf_perms / 64.0 / (leaves_ms * 1e-3) / 1e9
+            # issue_cost_floor_frac: the same instructions priced with the measured per-class issue costs (mad 4.5, plain 32-bit 2.4,
+            # carry / select / 64-bit 2.9 cycles; tools/isa_mix.py) over the SIMD cycles the kernel had, live time
+            cyc = (pj.get("isa_mix") or {}).get("model_cycles_per_valu_instruction")
             alu.update({"valu_instr_per_permutation": ipp, "achieved": ach, "frac": ach / peak,
-                        "issue_cost_floor_frac": pj.get("issue_cost_floor_frac"), "source": pj.get("source_file")})
+                        "issue_cost_floor_frac": _num(ipp * leaf_perms / 64.0 * cyc / (SIMDS * CLOCK_HZ * leaves_ms * 1e-3)) if cyc else None,
+                        "source": pj.get("profile_file"), "stale": pj.get("stale")})
         out["roofline_alu"] = alu
         return out
 
@@ -487,7 +511,7 @@ def main():
                            "cap_height": cap_height, "proofs_in_flight_per_gpu": inflight, "witness": HOST_W,
                            "sharding": "one independent circuit per GPU, no collective"},
             }
-            out.update(leg.report(steps, scopes, inflight))
+            out.update(leg.report(steps, scopes, inflight, retries))
             out["scopes_ms_per_step"] = {k: v[0] / steps for k, v in scopes.items() if v[1]}
             out["verified"] = leg.verify_last()
             out["perm_arg_retries"] = retries  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
@@ -507,7 +531,7 @@ def main():
             bdt, bscopes, bret = bleg.timed(steps, args.warmup, host=True)
             bb = {"metric": "proofs/s", "value": steps * inflight / bdt, "ms_per_step": bdt / steps * 1e3, "dtype": "u32",
                   "config": {"workload": workload_name(bleg, HOST_W), "witness": HOST_W}}
-            bb.update(bleg.report(steps, bscopes, inflight))
+            bb.update(bleg.report(steps, bscopes, inflight, bret))
             bb["scopes_ms_per_step"] = {k: v[0] / steps for k, v in bscopes.items() if v[1]}
             bb["verified"] = bleg.verify_last()
             bb["perm_arg_retries"] = bret     # at their natural rate: `value` has the re-done proofs inside, value_no_retry has not

@@ -12,17 +12,33 @@
 namespace gbk {
 
 using poseidon_gl::from_mont;
+using poseidon_gl::mds_mfma_matrix;
 using poseidon_gl::permute;
-using poseidon_gl::permute_mont;
 using poseidon_gl::to_mont;
+// The lane-per-state kernels run the full rounds' MDS layers on the matrix pipe (poseidon_gl.hpp, mds_layer_mfma): an MFMA is a
+// wave-wide instruction, so no lane leaves early - lanes past the end work on a clamped index and skip the store.  Waves per SIMD:
+// the MFMA form holds 16-register result tiles next to the state (measured: tools/ab_kernel_times.sh, GB_POSEIDON_OCC).
+#ifndef GB_POSEIDON_OCC
+#define GB_POSEIDON_OCC 4
+#endif
+// All 30 MDS layers on the matrix pipe, the partial rounds in the reference's naive form (permute_mont_mfma_naive): 54.3 ms for the
+// 2^23 leaves x 17 permutations of a wires commitment, against 57.2 ms with only the seven full-round layers there and the partial
+// rounds in the fast sparse form (GB_POSEIDON_HYBRID, kept for the ablation) and 60.4 ms all-VALU (round 2).
+#ifdef GB_POSEIDON_HYBRID
+#define permute_mont_mfma poseidon_gl::permute_mont_mfma
+#else
+#define permute_mont_mfma poseidon_gl::permute_mont_mfma_naive
+#endif
 // The sponge state of these kernels is kept in the permutation's Montgomery form (poseidon_gl.hpp): absorbed words go through
 // to_mont, the digest through from_mont (canonical); the capacity words never leave that form between absorptions.
 
 // hash/hashing.rs:100-123 (overwrite-mode sponge, rate 8) + plonk/config.rs:70-84 (hash_or_noop)
-__global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
-                                                          u64 num_leaves, u64* __restrict__ out) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= num_leaves) return;
+__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
+                                                                        u64 num_leaves, u64* __restrict__ out) {
+    const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j0 < num_leaves;
+    const u64 j = live ? j0 : num_leaves - 1;
+    const poseidon_gl::v4i amat = mds_mfma_matrix();
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -39,11 +55,12 @@ __global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves(const u64* __restri
                 for (int i = 0; i < 8; i++)
                     if (c0 + i < width) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
             }
-            permute_mont(s);  // the state stays a lazy Montgomery-form residue between absorptions
+            permute_mont_mfma(s, amat);  // the state stays a lazy Montgomery-form residue between absorptions
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) s[i] = from_mont(s[i]);
     }
+    if (!live) return;
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * j);
     o[0] = make_ulonglong2(s[0], s[1]);
     o[1] = make_ulonglong2(s[2], s[3]);
@@ -55,11 +72,13 @@ __global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves(const u64* __restri
 // last absorption leaves alone (`keep_from` .. 7) when the following segment starts with it.  FIRST: fresh sponge; LAST: the
 // digest goes to `out`.  Every segment but the last absorbs whole groups of 8 columns.
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves_seg(const u64* __restrict__ cols, size_t col_stride, u32 c_begin, u32 c_end,
-                                                              u64 num_leaves, u64* __restrict__ state, u32 keep_from,
-                                                              u64* __restrict__ out) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= num_leaves) return;
+__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(const u64* __restrict__ cols, size_t col_stride, u32 c_begin,
+                                                                            u32 c_end, u64 num_leaves, u64* __restrict__ state,
+                                                                            u32 keep_from, u64* __restrict__ out) {
+    const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j0 < num_leaves;
+    const u64 j = live ? j0 : num_leaves - 1;
+    const poseidon_gl::v4i amat = mds_mfma_matrix();
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = 0;
@@ -79,8 +98,9 @@ __global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves_seg(const u64* __re
             for (int i = 0; i < 8; i++)
                 if (c0 + i < c_end) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
         }
-        permute_mont(s);
+        permute_mont_mfma(s, amat);
     }
+    if (!live) return;
     if (!LAST) {
 #pragma unroll
         for (int i = 8; i < 12; i++) state[(size_t)i * num_leaves + j] = s[i];
@@ -97,14 +117,17 @@ __global__ __launch_bounds__(256, 6) void k_gl_merkle_leaves_seg(const u64* __re
 }
 
 // hash/hashing.rs:76-96 compress / Hasher::two_to_one
-__global__ __launch_bounds__(256, 6) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_out) return;
+__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < num_out;
+    const u64 i = live ? i0 : num_out - 1;
+    const poseidon_gl::v4i amat = mds_mfma_matrix();
     const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
     ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
     u64 s[12] = {to_mont(a.x), to_mont(a.y), to_mont(b.x), to_mont(b.y), to_mont(c.x), to_mont(c.y), to_mont(d.x), to_mont(d.y),
                  0, 0, 0, 0};
-    permute_mont(s);
+    permute_mont_mfma(s, amat);
+    if (!live) return;
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
     o[0] = make_ulonglong2(from_mont(s[0]), from_mont(s[1]));
     o[1] = make_ulonglong2(from_mont(s[2]), from_mont(s[3]));
@@ -213,15 +236,19 @@ __global__ void k_u64_transpose_to_rows(const u64* __restrict__ cols, size_t col
     dst[g] = cols[(size_t)c * col_stride + r];
 }
 
-__global__ __launch_bounds__(256) void k_gl_poseidon_permute(const u64* __restrict__ in, u64* __restrict__ out, u64 count) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// raw permutation, canonical in and out, through the same MFMA form the tree kernels use (gb_permute: the reference's KATs)
+__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_poseidon_permute(const u64* __restrict__ in, u64* __restrict__ out, u64 count) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < count;
+    const u64 i = live ? i0 : count - 1;
+    const poseidon_gl::v4i amat = mds_mfma_matrix();
     u64 s[12];
 #pragma unroll
-    for (int e = 0; e < 12; e++) s[e] = in[12 * i + e];
-    permute(s);
+    for (int e = 0; e < 12; e++) s[e] = to_mont(in[12 * i + e]);
+    permute_mont_mfma(s, amat);
+    if (!live) return;
 #pragma unroll
-    for (int e = 0; e < 12; e++) out[12 * i + e] = s[e];
+    for (int e = 0; e < 12; e++) out[12 * i + e] = from_mont(s[e]);
 }
 
 static inline u32 blocks_for(u64 n, u32 bs) { return (u32)((n + bs - 1) / bs); }

@@ -143,10 +143,11 @@ __device__ __forceinline__ void load_tw16(u64 (&tw)[16], const u64* __restrict__
 // the second from a 256-entry table in LDS.
 __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, const u64* __restrict__ tw4096) {
     __shared__ u64 sh[16 * 272];
-    __shared__ u64 tw256[256];  // w_256^m = w_4096^(16 m): the stage-2 twiddles
+    __shared__ u64 tw2[256];  // the stage-2 twiddles as the threads read them: tw2[s][d0] = w_256^(brev4(s) d0) - consecutive lanes,
+                              // consecutive words (indexed by exponent, slots with brev4(s) = 4, 8, 12 were 2- and 4-way bank conflicts)
     u64* p = lde + ((size_t)blockIdx.x << 12);
     const u32 tid = threadIdx.x;
-    tw256[tid] = tw4096[tid * 16];
+    tw2[tid] = tw4096[((brev4(tid >> 4) * (tid & 15)) & 255) * 16];
     u64 x[16];
     // stage 1: digit d2 (stride 256); this thread is (d1, d0) = tid
 #pragma unroll
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
     __syncthreads();
 #pragma unroll
     for (u32 s = 0; s < 16; s++)   // w_256^(k1 d0) from LDS; [k2 slot][d0][k1 slot], rows padded to 17
-        sh[hi4 * 272 + lo4 * 17 + s] = s ? gl::mul_mont(x[s], tw256[(brev4(s) * lo4) & 255]) : x[s];
+        sh[hi4 * 272 + lo4 * 17 + s] = s ? gl::mul_mont(x[s], tw2[s * 16 + lo4]) : x[s];
     __syncthreads();
     // stage 3: digit d0; this thread is (k2 slot, k1 slot)
 #pragma unroll

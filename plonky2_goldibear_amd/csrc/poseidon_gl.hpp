@@ -295,6 +295,149 @@ __device__ __forceinline__ void mds_layer(u64 (&s)[12], const u64* __restrict__ 
 
 __device__ static const u64 ZERO_RC[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+// ------------------------------------------------------------------ the MDS layer on the matrix pipe
+// The hash kernels saturate VALU issue while the MFMA pipe idles, and the MDS matrix is CONSTANT with entries < 2^6.  Cut into
+// byte planes, s_i = sum_p b_{i,p} 2^(8p), the layer is eight 12 x 12 integer matrix-vector products per state, one per plane:
+// C_p[q] = sum_i M[q][i] b_{i,p} < 2^17, and  out[q] = sum_p 2^(8p) C_p[q].  One v_mfma_i32_32x32x32_i8 does a plane for the 64
+// states of a wave (one state per lane) with NO cross-lane traffic, because the constant operand A is block-diagonal:
+//   B (data):   lane l = (r = l & 31, h = l >> 5) supplies k = 16 h + j, j < 16, of column r: byte p of word j of ITS OWN state
+//   A (matrix): row m = (q & 3) + 8 (q >> 2) + 4 h' holds M[q][.] in the k-block h' only (q < 12 the output word, h' in {0, 1})
+//   D:          lane l, register q = D[(q & 3) + 8 (q >> 2) + 4 h][r] = sum_i M[q][i] byte_p(word i of state l)
+// (C/D map of the 32 x 32 shapes, /opt/skills/guides/cdna_hip_programming.md section 3; A and B use the same lane -> k rule, so
+// only "same h, same j meet" is relied on.)  The i8 operands are signed: bytes go in as b ^ 0x80 = b - 128, which shifts every
+// plane sum by the per-row constant 128 rowsum(q); that shift, the biases that keep the signed accumulators non-negative and the
+// round constants of the layer that follows are ONE constant per (layer, word), folded into the accumulators' start values
+// (MFMA_INIT).  Per layer: 24 v_xor + 48 v_perm (six 4 x 4 byte transposes) to build the planes, 8 MFMAs, then per word four
+// v_lshl_add_u32 (planes pairwise, 2^8 apart), four v_mad_i64_i32 (2^16 apart, low and high 32-bit halves) and the 5-instruction
+// fold_halves: ~250 VALU instructions where the VALU form takes ~480 (24 mads per word plus folds and moves).
+// tools/microbench_mds_mfma.hip: bit-identical on 12.6 M words, layer alone 2.6x faster, a full round (12 s-boxes + layer) 1.36x.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+static constexpr long long MFMA_BIAS = 1ll << 41;   // > |sum_p<4 2^(8p) C'_p| (< 2^39.2): the accumulators stay positive
+static constexpr int MFMA_NO_RC = 30;               // index of "no constants follow" in MFMA_INIT
+namespace raw {
+constexpr u64 caddmod(u64 a, u64 b) { return (u64)(((u128)a + b) % gl::P); }
+constexpr u64 csubmod(u64 a, u64 b) { return (u64)(((u128)a + gl::P - b % gl::P) % gl::P); }
+constexpr u32 mds_entry(int q, int i) { return (u32)CIRC[((i - q) % 12 + 12) % 12] + (q == 0 && i == 0 ? MDS_DIAG0 : 0u); }
+struct MfmaInitTable {
+    u64 lo[31 * 12], hi[31 * 12];   // [next round | MFMA_NO_RC][word]: start values of the low / high half accumulators
+};
+constexpr MfmaInitTable mfma_init_table() {
+    MfmaInitTable t{};
+    for (int q = 0; q < 12; q++) {
+        u64 rowsum = 0;
+        for (int i = 0; i < 12; i++) rowsum += mds_entry(q, i);
+        // true value = acc_lo + 2^32 acc_hi + 128 rowsum 0x0101..01 - BIAS - 2^32 BIAS: what has to be added, mod p
+        u64 k = cmulmod(128 * rowsum, 0x0101010101010101ULL % gl::P);
+        k = csubmod(k, (u64)MFMA_BIAS);
+        k = csubmod(k, cmulmod((u64)MFMA_BIAS, 1ULL << 32));
+        for (int rn = 0; rn <= 30; rn++) {
+            const u64 c = rn < 30 ? caddmod(k, cmulmod_r(ALL_RC[12 * rn + q])) : k;   // + the next round's constant (times R)
+            t.lo[12 * rn + q] = (u64)MFMA_BIAS + (c & 0xFFFFFFFFULL);
+            t.hi[12 * rn + q] = (u64)MFMA_BIAS + (c >> 32);
+        }
+    }
+    return t;
+}
+}  // namespace raw
+__device__ static const raw::MfmaInitTable MFMA_INIT = raw::mfma_init_table();
+
+// a * b + c, signed 32 x 32 + 64, as ONE v_mad_i64_i32 (the compiler expands the C expression to sign-extend + shift + add)
+__device__ __forceinline__ long long mad_i64(int a, int b, long long c) {
+    long long d;
+    u64 carry_unused;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+// a + c with c a UNIFORM 64-bit value: the accumulator's start value goes in as the scalar operand of the first mad (multiplier
+// 1 is an inline constant, so the one scalar source VOP3 allows on gfx950 is free for it) instead of through two v_mov
+__device__ __forceinline__ long long mad_i64_start(int a, u64 c_uniform) {
+    long long d;
+    u64 carry_unused;
+    asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(c_uniform));
+    return d;
+}
+// some register, no instruction: the fourth dword of an MFMA B operand whose k = 12..15 meet zeros in A
+__device__ __forceinline__ int any_vgpr() {
+    int x;
+    asm("" : "=v"(x));
+    return x;
+}
+// 4 x 4 byte transpose: t[p] = [w0.b_p, w1.b_p, w2.b_p, w3.b_p] (8 v_perm_b32)
+__device__ __forceinline__ void byte_transpose4(u32 w0, u32 w1, u32 w2, u32 w3, u32 (&t)[4]) {
+    const u32 a_lo = __builtin_amdgcn_perm(w1, w0, 0x05010400u);  // [w0.b0, w1.b0, w0.b1, w1.b1]
+    const u32 a_hi = __builtin_amdgcn_perm(w1, w0, 0x07030602u);  // [w0.b2, w1.b2, w0.b3, w1.b3]
+    const u32 b_lo = __builtin_amdgcn_perm(w3, w2, 0x05010400u);
+    const u32 b_hi = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+    t[0] = __builtin_amdgcn_perm(b_lo, a_lo, 0x05040100u);
+    t[1] = __builtin_amdgcn_perm(b_lo, a_lo, 0x07060302u);
+    t[2] = __builtin_amdgcn_perm(b_hi, a_hi, 0x05040100u);
+    t[3] = __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
+}
+// This lane's share of the constant A operand (see above); call with all 64 lanes of the wave active, blockDim.x a multiple of 64.
+__device__ __forceinline__ v4i mds_mfma_matrix() {
+    const u32 l = threadIdx.x & 63, r = l & 31, h = l >> 5;
+    const u32 hp = (r >> 2) & 1, q = (r & 3) + 4 * (r >> 3);
+    v4i a = {0, 0, 0, 0};
+    if (h == hp && q < 12) {
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            u32 v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const u32 i = 4 * g + e;
+                u32 m = mds_circ((int)((i + 12 - q) % 12));
+                if (q == 0 && i == 0) m += MDS_DIAG0;
+                v |= m << (8 * e);
+            }
+            a[g] = (int)v;
+        }
+    }
+    return a;
+}
+// s <- MDS s + constants of round `rnext` (MFMA_NO_RC: none); every lane of the wave must execute this (MFMA), whatever its data.
+__device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int rnext) {
+    u32 w[24];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        w[i] = (u32)s[i] ^ 0x80808080u;
+        w[12 + i] = (u32)(s[i] >> 32) ^ 0x80808080u;
+    }
+    u32 pl[8][3];   // pl[p][g]: byte p of words 4g .. 4g + 3
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            u32 t[4];
+            byte_transpose4(w[12 * half + 4 * g], w[12 * half + 4 * g + 1], w[12 * half + 4 * g + 2], w[12 * half + 4 * g + 3], t);
+#pragma unroll
+            for (int p = 0; p < 4; p++) pl[4 * half + p][g] = t[p];
+        }
+    long long lo[12], hi[12];
+    const u64* ilo = MFMA_INIT.lo + 12 * rnext;   // uniform index: scalar loads
+    const u64* ihi = MFMA_INIT.hi + 12 * rnext;
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int pad = any_vgpr();
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {   // planes two at a time: d_p + 2^8 d_(p+1) fits 32 bits (|.| < 2^25)
+        v4i b0, b1;
+        b0[0] = (int)pl[2 * pp][0]; b0[1] = (int)pl[2 * pp][1]; b0[2] = (int)pl[2 * pp][2]; b0[3] = pad;
+        b1[0] = (int)pl[2 * pp + 1][0]; b1[1] = (int)pl[2 * pp + 1][1]; b1[2] = (int)pl[2 * pp + 1][2]; b1[3] = pad;
+        const v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat, b0, zero, 0, 0, 0);
+        const v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat, b1, zero, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            const int t = (int)(((u32)d1[q] << 8) + (u32)d0[q]);
+            if (pp == 0) lo[q] = mad_i64_start(t, ilo[q]);
+            else if (pp == 1) lo[q] = mad_i64(t, 65536, lo[q]);
+            else if (pp == 2) hi[q] = mad_i64_start(t, ihi[q]);
+            else hi[q] = mad_i64(t, 65536, hi[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; q++) s[q] = fold_halves((u64)lo[q], (u64)hi[q]);
+}
+
 // Four full rounds; the state comes in with round0's constants already added, and leaves with `tail_rc` added (the
 // constants of whatever layer follows: FAST_PARTIAL_FIRST_ROUND_CONSTANT after the first half, nothing after the second).
 __device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0, const u64* __restrict__ tail_rc) {
@@ -308,12 +451,17 @@ __device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0, const u64*
 // Rounds 0..3 of the permutation (state comes in with round 0's constants added) and everything linear up to the first
 // partial round: the fourth round's MDS, partial_first_constant_layer (:632-638) and mds_partial_layer_init (:657-683)
 // are applied as ONE 12 x 11 dot-product layer (MI_L, MI_K) plus the MDS's row 0 for the word that stays outside M_init.
+__device__ __forceinline__ void first_half_tail(u64 (&s)[12]);
 __device__ __forceinline__ void first_half(u64 (&s)[12]) {
     for (int k = 0; k < HALF_FULL - 1; k++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
         mds_layer(s, GB_RC + 12 * (k + 1));
     }
+    first_half_tail(s);
+}
+// the fourth round: s-boxes, then MDS + first partial constants + M_init as one dot-product layer
+__device__ __forceinline__ void first_half_tail(u64 (&s)[12]) {
     u64 y[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) y[i] = sbox(s[i]);
@@ -385,6 +533,46 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
             s[i] = gl::fold160(r0, r1, r2, r3, r4);
         }
         s[0] = d1.finish();
+    }
+}
+
+// permute_mont with the seven plain MDS layers of the full rounds on the matrix pipe (the fourth round's layer stays inside the
+// merged 12 x 11 dot-product layer of first_half, the partial rounds in their fast form).  `amat` = mds_mfma_matrix(); all 64
+// lanes of the wave must be here together.  Same function, same lazy Montgomery-form conventions as permute_mont.
+__device__ __forceinline__ void permute_mont_mfma(u64 (&s)[12], const v4i amat) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
+    for (int k = 0; k < HALF_FULL - 1; k++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        mds_layer_mfma(s, amat, k + 1);
+    }
+    first_half_tail(s);
+    partial_rounds(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[12 * (HALF_FULL + N_PARTIAL) + i]);
+    for (int k = 0; k < HALF_FULL; k++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        mds_layer_mfma(s, amat, k + 1 < HALF_FULL ? HALF_FULL + N_PARTIAL + k + 1 : MFMA_NO_RC);
+    }
+}
+
+// The permutation in the reference's NAIVE round structure (hash/poseidon_goldilocks.rs:927-948: constants, s-box - all twelve
+// words in the full rounds, word 0 in the partial ones - then the full MDS; output-identical to the fast form, :1196-1198) with
+// every one of the 30 MDS layers on the matrix pipe: a partial round is then one s-box + one mds_layer_mfma (~310 VALU
+// instructions) where the fast form's sparse-matrix round is ~380 with 64-bit constants.
+__device__ __forceinline__ void permute_mont_mfma_naive(u64 (&s)[12], const v4i amat) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
+    for (int r = 0; r < 2 * HALF_FULL + N_PARTIAL; r++) {
+        if (r < HALF_FULL || r >= HALF_FULL + N_PARTIAL) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        } else {
+            s[0] = sbox(s[0]);
+        }
+        mds_layer_mfma(s, amat, r + 1 < 2 * HALF_FULL + N_PARTIAL ? r + 1 : MFMA_NO_RC);
     }
 }
 

@@ -8,7 +8,12 @@ SQ_INSTS_VALU counts wave-level instructions; one wave hashes 64 leaves, a leaf 
 permutations (overwrite-mode sponge, rate 8), so instructions per permutation = SQ_INSTS_VALU / (N * ceil(cols/8) / 64)."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import measured_sha16 as csrc_sha16  # noqa: E402
+from isa_mix import kernel_mix    # noqa: E402
 
 path, field, cols, log_n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 kernel = "gbk::k_gl_merkle_leaves" if field == "goldilocks" else "gbk::k_bb_merkle_leaves"
@@ -17,7 +22,18 @@ N = 1 << (log_n + 3)
 perms = N * (-(-cols // 8)) * int(row["Dispatches"])
 insts = float(row["SQ_INSTS_VALU"])
 wave_cycles = float(row["SQ_WAVE_CYCLES"])
+# issue-cost floor: the kernel's instruction mix priced with the measured per-class issue costs, as a
+# fraction of the SIMD cycles the kernel had - 1.0 would mean the VALU port never waited
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sym = "_ZN3gbk18k_gl_merkle_leavesEPKymjyPy" if field == "goldilocks" else None
+mix = kernel_mix(os.path.join(root, "plonky2_goldibear_amd", "csrc", "kernels_merkle.hip"), sym) if sym else None
+dur_s = float(row["TotalDurationNs(under PMC)"]) * 1e-9
+floor = None
+if mix:
+    SIMDS, CLOCK = 1024, 2.4e9
+    floor = insts * mix["model_cycles_per_valu_instruction"] / (SIMDS * CLOCK * dur_s)
 res = {
+    "csrc_sha16": csrc_sha16(), "issue_cost_floor_frac": floor, "isa_mix": mix,
     "source_file": path, "kernel": kernel, "columns": cols, "log_n": log_n, "permutations": perms,
     "SQ_INSTS_VALU": insts, "valu_instr_per_permutation": insts / (perms / 64.0),
     "vgprs": int(row["VGPRs"]), "duration_ns_under_pmc": float(row["TotalDurationNs(under PMC)"]),

@@ -12,8 +12,12 @@ count closer to the bytes the kernel reads by design (every kernel here reads it
 listed per kernel), and `fetch_over_design` shows what is left: 1.0 = no re-reads reach the memory side.
 """
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import measured_sha16 as csrc_sha16  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -34,7 +38,7 @@ def main():
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python3 bench.py --workload commit "
                      "--steps 1 --warmup 0` (%d columns x 2^%d, %d-byte elements); KB -> bytes; per-kernel FETCH factor in "
                      "{1, 2} calibrated against the design read bytes (see tools/pmc_traffic.py)" % (ncols, log_n, es),
-           "columns": ncols, "log_n": log_n, "elem_bytes": es, "kernels": {}}
+           "csrc_sha16": csrc_sha16(), "columns": ncols, "log_n": log_n, "elem_bytes": es, "kernels": {}}
     for k in sorted(set(f) | set(w)):
         if "copyBuffer" in k:
             continue
