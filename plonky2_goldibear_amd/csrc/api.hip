@@ -451,27 +451,37 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     // Host input of a big batch: the leaf sponges run in segments of SEG columns as the columns arrive (chunked upload below), so
     // that the hashing - most of a commitment's time - overlaps the PCIe transfer instead of waiting for its end; the sponge state
     // waits in `seg_state` between segments (kernels_merkle.hip / kernels_bb.hip: k_*_merkle_leaves).
+    // Segment sizes: 8, 8, 16, then 32 columns.  The first segments are short so that the hashing starts as soon as the second
+    // upload chunk (16 columns) has been transformed instead of idling until 32 columns have crossed PCIe (~4.6 ms of a 2^20-row
+    // Goldilocks witness); later segments are long because every boundary parks and reloads the sponge state (0.27 GB at 2^23 leaves).
     constexpr u32 SEG = 32;
+    auto seg_size = [](u32 done) -> u32 { return done < 16 ? 8u : (done < 32 ? 16u : SEG); };
     const bool segmented = !dev_in && !is_coeffs && log_N >= 19 && ncols > SEG;
     u32 seg_done = 0;
     void* seg_state = nullptr;
-    const size_t seg_state_bytes = field == GB_GOLDILOCKS ? 12 * N * sizeof(u64) : 16 * N * sizeof(u32);
+    // the parked sponge state: the capacity words, plus the rate words a ragged LAST absorption leaves alone when it is a segment
+    // of its own (kernels_merkle.hip / kernels_bb.hip index the rows compactly)
+    u32 last_seg_start = 0;
+    for (u32 sz = seg_size(0); last_seg_start + sz < ncols; sz = seg_size(last_seg_start)) last_seg_start += sz;
+    const u32 kf_final = std::min<u32>(8u, (u32)(width - last_seg_start));
+    const size_t seg_rows = (field == GB_GOLDILOCKS ? 4 : 8) + (8 - kf_final);
+    const size_t seg_state_bytes = seg_rows * N * (field == GB_GOLDILOCKS ? sizeof(u64) : sizeof(u32));
     struct SegGuard {
         gb_ctx* ctx; void** p; size_t bytes;
         ~SegGuard() { if (*p) pool_free(ctx, *p, bytes); }
     } seg_guard{ctx, &seg_state, seg_state_bytes};
     auto hash_ready_segments = [&](size_t cols_ready) -> bool {   // every full segment that is not the last one
-        while (segmented && seg_done + SEG < ncols && seg_done + SEG <= cols_ready) {
+        for (u32 sz = seg_size(seg_done); segmented && seg_done + sz < ncols && seg_done + sz <= cols_ready; sz = seg_size(seg_done)) {
             if (!seg_state && pool_alloc(ctx, seg_state_bytes, &seg_state) != hipSuccess) { seg_state = nullptr; return false; }
             Scope sm(ctx, "build Merkle tree");
             Scope sl(ctx, "hash leaves");
-            const u32 next_cols = (u32)(width - (seg_done + SEG));
+            const u32 next_cols = (u32)(width - (seg_done + sz));
             if (field == GB_GOLDILOCKS)
-                gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, seg_done + SEG, N, (u64*)seg_state, false, next_cols, b->levels, st);
+                gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, seg_done + sz, N, (u64*)seg_state, false, next_cols, b->levels, st);
             else
-                gbk::bb_merkle_leaves_segment((const u32*)b->lde, N, seg_done, seg_done + SEG, N, (u32*)seg_state, false, next_cols,
+                gbk::bb_merkle_leaves_segment((const u32*)b->lde, N, seg_done, seg_done + sz, N, (u32*)seg_state, false, next_cols,
                                               (u32*)b->levels, st);
-            seg_done += SEG;
+            seg_done += sz;
         }
         return true;
     };

@@ -60,7 +60,7 @@ void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables
 
 // leaf digests: out[j] = hash_or_noop(row j), row j = { cols[c*col_stride + j] : c < width }
 void gl_merkle_leaves(const u64* cols, size_t col_stride, u32 width, u64 num_leaves, u64* out, hipStream_t stream);
-// a column segment [c_begin, c_end) of every leaf's sponge, the state parked in `state` ([12][num_leaves]) between segments
+// a column segment [c_begin, c_end) of every leaf's sponge, the state parked in `state` ([4 + 8 - keep_from][num_leaves], rows as used) between segments
 void gl_merkle_leaves_segment(const u64* cols, size_t col_stride, u32 c_begin, u32 c_end, u64 num_leaves, u64* state, bool last,
                               u32 next_cols, u64* out, hipStream_t stream);
 // one level: out[i] = two_to_one(in[2i], in[2i+1]), i < num_out
@@ -95,7 +95,7 @@ void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, co
 void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream);
 void bb_merkle_leaves(const u32* cols, size_t col_stride, u32 width, u64 num_leaves, u32* out, hipStream_t stream);
 void bb_merkle_leaves_segment(const u32* cols, size_t col_stride, u32 c_begin, u32 c_end, u64 num_leaves, u32* state, bool last,
-                              u32 next_cols, u32* out, hipStream_t stream);  // state: [16][num_leaves]
+                              u32 next_cols, u32* out, hipStream_t stream);  // state: [8 + 8 - keep_from][num_leaves]
 void bb_merkle_level(const u32* in, u32* out, u64 num_out, hipStream_t stream);
 void bb_poseidon2_permute(const u32* in, u32* out, u64 count, hipStream_t stream);  // canonical in/out
 void bb_to_mont(const u32* src, u32* dst, size_t n, hipStream_t stream);

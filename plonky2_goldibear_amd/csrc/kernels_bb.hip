@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_bb_merkle_leaves(const u32* __restrict_
 }
 // The leaf sponge in column SEGMENTS [c_begin, c_end) (see k_gl_merkle_leaves_seg): between segments the capacity words 8..15 - as
 // the permutation left them: the next absorption's renorm brings them back to scale 1 - and, in front of a ragged last
-// absorption, the rate words it leaves alone (`keep_from`..7) wait in `state` [16][num_leaves].
+// absorption, the rate words it leaves alone (`keep_from`..7) wait in `state` [8 + 8 - keep_from][num_leaves].
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(256, 7) void k_bb_merkle_leaves_seg(const u32* __restrict__ cols, size_t col_stride, u32 c_begin, u32 c_end,
                                                                  u64 num_leaves, u32* __restrict__ state, u32 keep_from,
@@ -241,12 +241,14 @@ __global__ __launch_bounds__(256, 7) void k_bb_merkle_leaves_seg(const u32* __re
     u32 s[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = 0;
+    // `state` holds only the rows that are used: [0, 8) the capacity words 8..15, then rate word i >= keep_from at row 8 + i - keep_from
 #pragma unroll
-    for (int i = 8; i < 16; i++) s[i] = FIRST ? 0 : state[(size_t)i * num_leaves + j];
+    for (int i = 8; i < 16; i++) s[i] = FIRST ? 0 : state[(size_t)(i - 8) * num_leaves + j];
     if (LAST && !FIRST && c_end - c_begin < 8) {
+        const u32 kf = c_end - c_begin;   // = the keep_from the segment before was given
 #pragma unroll
         for (int i = 1; i < 8; i++)
-            if ((u32)i >= c_end - c_begin) s[i] = state[(size_t)i * num_leaves + j];
+            if ((u32)i >= kf) s[i] = state[(size_t)(8 + i - kf) * num_leaves + j];
     }
     for (u32 c0 = c_begin; c0 < c_end; c0 += 8) {
         if (c0) {  // the capacity words go on at scale 1; the rate words are overwritten (partially in the last absorption)
@@ -269,11 +271,11 @@ __global__ __launch_bounds__(256, 7) void k_bb_merkle_leaves_seg(const u32* __re
     }
     if (!LAST) {
 #pragma unroll
-        for (int i = 8; i < 16; i++) state[(size_t)i * num_leaves + j] = s[i];
+        for (int i = 8; i < 16; i++) state[(size_t)(i - 8) * num_leaves + j] = s[i];
         if (keep_from < 8) {
 #pragma unroll
             for (int i = 1; i < 8; i++)
-                if ((u32)i >= keep_from) state[(size_t)i * num_leaves + j] = s[i];
+                if ((u32)i >= keep_from) state[(size_t)(8 + i - keep_from) * num_leaves + j] = s[i];
         }
         return;
     }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const
 
 // The sponge of a leaf run in SEGMENTS of columns [c_begin, c_end): a commitment whose columns arrive over PCIe hashes the columns
 // it already has while the rest is still in flight (api.hip commit()).  Between segments the words that the next absorption does
-// not overwrite wait in `state` ([12][num_leaves], lazy residues): the capacity words 8..11 always, and the rate words the ragged
+// not overwrite wait in `state` ([4 + 8 - keep_from][num_leaves], lazy residues): the capacity words 8..11 always, and the rate words the ragged
 // last absorption leaves alone (`keep_from` .. 7) when the following segment starts with it.  FIRST: fresh sponge; LAST: the
 // digest goes to `out`.  Every segment but the last absorbs whole groups of 8 columns.
 template <bool FIRST, bool LAST>
@@ -82,12 +82,14 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(c
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = 0;
+    // `state` holds only the rows that are used: [0, 4) the capacity words 8..11, then rate word i >= keep_from at row 4 + i - keep_from
 #pragma unroll
-    for (int i = 8; i < 12; i++) s[i] = FIRST ? 0 : state[(size_t)i * num_leaves + j];
+    for (int i = 8; i < 12; i++) s[i] = FIRST ? 0 : state[(size_t)(i - 8) * num_leaves + j];
     if (LAST && !FIRST && c_end - c_begin < 8) {  // this segment is the ragged absorption alone: the rate words it leaves alone
+        const u32 kf = c_end - c_begin;           // = the keep_from the segment before was given
 #pragma unroll
         for (int i = 1; i < 8; i++)
-            if ((u32)i >= c_end - c_begin) s[i] = state[(size_t)i * num_leaves + j];
+            if ((u32)i >= kf) s[i] = state[(size_t)(4 + i - kf) * num_leaves + j];
     }
     for (u32 c0 = c_begin; c0 < c_end; c0 += 8) {
         if (!LAST || c0 + 8 <= c_end) {
@@ -103,11 +105,11 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(c
     if (!live) return;
     if (!LAST) {
 #pragma unroll
-        for (int i = 8; i < 12; i++) state[(size_t)i * num_leaves + j] = s[i];
+        for (int i = 8; i < 12; i++) state[(size_t)(i - 8) * num_leaves + j] = s[i];
         if (keep_from < 8) {
 #pragma unroll
             for (int i = 1; i < 8; i++)
-                if ((u32)i >= keep_from) state[(size_t)i * num_leaves + j] = s[i];
+                if ((u32)i >= keep_from) state[(size_t)(4 + i - keep_from) * num_leaves + j] = s[i];
         }
         return;
     }

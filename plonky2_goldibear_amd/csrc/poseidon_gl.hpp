@@ -418,6 +418,25 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
     const u64* ihi = MFMA_INIT.hi + 12 * rnext;
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int pad = any_vgpr();
+#ifdef GB_MFMA_DEPTH4   // ablation: four MFMAs in flight (64 result registers) instead of two
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        v16i d[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            v4i b;
+            b[0] = (int)pl[4 * hh + p][0]; b[1] = (int)pl[4 * hh + p][1]; b[2] = (int)pl[4 * hh + p][2]; b[3] = pad;
+            d[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat, b, zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            const int t01 = (int)(((u32)d[1][q] << 8) + (u32)d[0][q]);
+            const int t23 = (int)(((u32)d[3][q] << 8) + (u32)d[2][q]);
+            if (hh == 0) lo[q] = mad_i64(t23, 65536, mad_i64_start(t01, ilo[q]));
+            else hi[q] = mad_i64(t23, 65536, mad_i64_start(t01, ihi[q]));
+        }
+    }
+#else
 #pragma unroll
     for (int pp = 0; pp < 4; pp++) {   // planes two at a time: d_p + 2^8 d_(p+1) fits 32 bits (|.| < 2^25)
         v4i b0, b1;
@@ -434,6 +453,7 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
             else hi[q] = mad_i64(t, 65536, hi[q]);
         }
     }
+#endif
 #pragma unroll
     for (int q = 0; q < 12; q++) s[q] = fold_halves((u64)lo[q], (u64)hi[q]);
 }
