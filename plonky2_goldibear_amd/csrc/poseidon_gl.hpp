@@ -454,8 +454,28 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
         }
     }
 #endif
+    // fold_halves with its carry fix on a rare path: value = lo + 2^32 hi = (lo + (hi >> 32) EPS) + 2^32 (u32)hi, and the last
+    // addition wraps only when (u32)hi lies within 2^12 of 2^32 - about 4e-4 of the wave-layers have such a lane.  The fast path
+    // is one mad and one add per word; the wave-wide OR of the carries is scalar work, and a wave in which any lane wrapped
+    // takes the branch and adds EPS (= 2^64 mod p) in those lanes (no second wrap: a wrapped high word is < 2^12).
+    u64 any_carry = 0;
 #pragma unroll
-    for (int q = 0; q < 12; q++) s[q] = fold_halves((u64)lo[q], (u64)hi[q]);
+    for (int q = 0; q < 12; q++) {
+        const u64 sl = (u64)lo[q], sh = (u64)hi[q];
+        const u64 t = sl + (u64)(u32)(sh >> 32) * EPS;
+        u32 r1;
+        u64 carry_lanes;   // the add's carry-out as it comes: a lane mask in a scalar register pair
+        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(r1), "=s"(carry_lanes) : "v"((u32)(t >> 32)), "v"((u32)sh));
+        any_carry |= carry_lanes;
+        s[q] = (u64)(u32)t | ((u64)r1 << 32);
+    }
+    if (__builtin_expect(any_carry != 0, 0)) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            const bool wrapped = (u32)(s[q] >> 32) < (u32)hi[q];   // r1 = t_hi + (u32)hi wrapped  <=>  r1 < (u32)hi
+            s[q] += wrapped ? EPS : 0;
+        }
+    }
 }
 
 // Four full rounds; the state comes in with round0's constants already added, and leaves with `tail_rc` added (the

@@ -33,6 +33,30 @@ def test_poseidon12_kats_and_random(ctx, kats):
         assert (got[i] == O.poseidon(rnd[i])).all()
 
 
+def test_poseidon12_matrix_pipe_edges(ctx):
+    """The permutation's MDS layers run as i8 MFMAs on byte planes of the state (csrc/poseidon_gl.hpp, mds_layer_mfma): states
+    made of the bytes where a signed-byte interpretation bites (0x00 / 0x7f / 0x80 / 0xff in every position), counts that leave
+    lanes of the last wave without data, and enough random states (2^17 x 30 layers) for the fold's rare carry path (a lane whose
+    high accumulator's low word lies within 2^12 of 2^32: ~4e-4 of the wave-layers) to be taken hundreds of times - every word
+    against the oracle's scalar permutation."""
+    pat = [0, 0x7f7f7f7f7f7f7f7f, 0x8080808080808080, 0xFFFFFFFF00000000, 0x00FF00FF00FF00FF, 0x80007fff0100ff80, P - 1, 1]
+    edge = np.array([[pat[(i + j) % len(pat)] for j in range(12)] for i in range(67)], dtype=np.uint64)   # 67: a ragged last wave
+    got = ctx.permute(edge)
+    for i in range(len(edge)):
+        assert (got[i] == O.poseidon(edge[i])).all(), i
+    for count in (1, 63, 65):
+        st = O.splitmix64_fill(90 + count, 12 * count).reshape(count, 12)
+        got = ctx.permute(st)
+        for i in range(count):
+            assert (got[i] == O.poseidon(st[i])).all()
+    big = O.splitmix64_fill(77, 12 << 17).reshape(1 << 17, 12)
+    got = ctx.permute(big)
+    want = np.empty_like(big)
+    for i in range(big.shape[0]):
+        want[i] = O.poseidon(big[i])
+    assert (got == want).all()
+
+
 def _check_batch(gpu, cpu, full=True):
     assert (gpu.merkle_tree.cap == cpu.cap).all()
     assert (gpu.polynomials == cpu.polynomials).all()
