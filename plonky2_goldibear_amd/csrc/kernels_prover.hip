@@ -166,8 +166,14 @@ __global__ __launch_bounds__(256) void k_zs_finalize(ZsParams<F> p, const typena
 // qv[(k * R + coset) * n + il], il = natural index of the point inside its coset block.
 // C = num_challenges and CH = chunk size (quotient_degree_factor) are compile-time so that the per-challenge
 // accumulators stay in registers and a chunk's 2*CH loads are issued together.
+// waves per SIMD of k_quotient: the Goldilocks instance needs 97 VGPRs unconstrained - one more than five waves allow; held to 96
+// it runs 5.14 -> 5.05 ms at 2^20 rows (tools/ab_kernel_times.sh)
+#ifndef GB_QUOTIENT_OCC_GL
+#define GB_QUOTIENT_OCC_GL 5
+#endif
+#define GB_QUOTIENT_OCC(F) (sizeof(typename F::T) == 8 ? GB_QUOTIENT_OCC_GL : 4)
 template <class F, u32 C, u32 CH>
-__global__ __launch_bounds__(256) void k_quotient(QuotientParams<F> p, const typename F::T* __restrict__ cs,
+__global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientParams<F> p, const typename F::T* __restrict__ cs,
                                                   const typename F::T* __restrict__ wires, const typename F::T* __restrict__ zs,
                                                   const typename F::T* __restrict__ uni, typename F::T* __restrict__ qv) {
     typedef typename F::T T;
@@ -483,14 +489,25 @@ __global__ __launch_bounds__(256) void k_ext_split(const typename F::E* __restri
 // Sponge over the field's permutation, rate 8, fed with DEVICE-form elements; out() gives canonical words.
 template <class F>
 struct Sponge;
+// The Goldilocks sponge runs the permutation with its MDS layers on the matrix pipe (poseidon_gl.hpp, mds_layer_mfma), like the
+// tree kernels: init() and permute() must be reached by all 64 lanes of a wave, so the kernels below clamp the index of lanes past
+// the end instead of returning early.
 template <>
 struct Sponge<GlF> {
     u64 s[12];
+    poseidon_gl::v4i amat;
     __device__ __forceinline__ void init() {
+        amat = poseidon_gl::mds_mfma_matrix();
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = 0;
     }
-    __device__ __forceinline__ void permute() { poseidon_gl::permute_lazy(s); }
+    __device__ __forceinline__ void permute() {   // plain lazy residues in and out, as poseidon_gl::permute_lazy
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon_gl::to_mont(s[i]);
+        poseidon_gl::permute_mont_mfma_naive(s, amat);
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon_gl::mont_fold((u32)s[i], (u32)(s[i] >> 32), 0u, 0u);
+    }
     __device__ __forceinline__ u64 out(int i) { return poseidon_gl::to_canonical(s[i]); }
     __device__ __forceinline__ void set_canonical(int i, u64 v) { s[i] = v; }
 };
@@ -513,12 +530,14 @@ __global__ __launch_bounds__(256) void k_fri_leaves(const typename F::T* __restr
                                                     u64 num_leaves, typename F::T* __restrict__ out) {
     typedef typename F::T T;
     constexpr u32 D = F::D, H = F::H, PER = 8 / D;  // extension elements per absorption of 8 base elements
-    u64 m = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (m >= num_leaves) return;
+    const u64 m0 = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool live = m0 < num_leaves;
+    const u64 m = live ? m0 : num_leaves - 1;      // no early exit: the sponge's permutation is wave-wide (MFMA)
     const u32 arity = 1u << arity_bits;
     const T* a = vals + (m << arity_bits);
     T* o = out + (size_t)H * m;
     if (D * arity <= H) {  // hash_or_noop (plonk/config.rs:70-84)
+        if (!live) return;
         for (u32 i = 0; i < H; i++) o[i] = 0;
         for (u32 k = 0; k < arity; k++)
             for (u32 d = 0; d < D; d++) o[D * k + d] = (T)F::dec(a[(size_t)d * len + k]);
@@ -535,6 +554,7 @@ __global__ __launch_bounds__(256) void k_fri_leaves(const typename F::T* __restr
             }
         sp.permute();
     }
+    if (!live) return;
 #pragma unroll
     for (u32 i = 0; i < H; i++) o[i] = sp.out(i);
 }
@@ -564,17 +584,19 @@ __global__ __launch_bounds__(256) void k_fri_fold(const typename F::T* __restric
 template <class F>
 __global__ __launch_bounds__(256) void k_pow_grind(PowState<F> st, u64 start, u64 count, u32 min_leading_zeros,
                                                    u64* __restrict__ result) {
-    u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (g >= count) return;
+    const u64 g0 = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool live = g0 < count;
+    const u64 g = live ? g0 : count - 1;           // no early exit (wave-wide permutation)
     u64 cand = start + g;
     Sponge<F> sp;
+    sp.init();
     // runtime position, static register indexing
 #pragma unroll
     for (int i = 0; i < (int)F::SPONGE_W; i++) sp.set_canonical(i, (u32)i == st.pos ? (typename F::T)cand : st.s[i]);
     sp.permute();
     u64 resp = sp.out(7);
     u32 lz = resp ? (u32)__clzll((long long)resp) : 64;
-    if (lz >= min_leading_zeros) atomicMin(result, cand);
+    if (live && lz >= min_leading_zeros) atomicMin(result, cand);
 }
 
 // ------------------------------------------------------------------ query gathers (outputs canonical)
