@@ -153,6 +153,11 @@ __device__ __forceinline__ u64 mul_mont_lazy(u64 a, u64 t_mont) {
     mul_limbs(a, t_mont, r0, r1, hl, hh);
     return mont_fold(r0, r1, hl, hh);
 }
+// mul_mont is mul_mont_lazy under the name that states its contract: CANONICAL operands in, canonical product out.  The NTT kernels
+// rely on it for what they store: their data operands are canonical (loaded from memory, or outputs of add / sub / mul_pow2 /
+// mul_mont), every table entry is canonical, and the running twiddles `f <- f * ratio` (computed with mul_mont_lazy) start from
+// canonical table entries and therefore stay canonical by induction.  A lazy operand (some residue >= p) would make the product a
+// non-canonical word in memory - and a Merkle leaf that differs from the reference's; keep add_lazy-style values out of these chains.
 __device__ __forceinline__ u64 mul_mont(u64 a_canonical, u64 t_mont_canonical) { return mul_mont_lazy(a_canonical, t_mont_canonical); }
 // x R mod p on the host (table builders)
 __host__ __device__ inline u64 to_mont_slow(u64 x);

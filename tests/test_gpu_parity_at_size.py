@@ -94,6 +94,29 @@ def test_full_batch_2pow20_every_leaf_and_digest(ctx, field_name):
     ctx.trim()
 
 
+@pytest.mark.parametrize("field_name,rate_bits", [("goldilocks", 1), ("goldilocks", 2), ("babybear", 1), ("babybear", 2)])
+def test_2pow20_rows_at_other_rates(ctx, field_name, rate_bits):
+    """The 2^20-row passes (k_*_lde_pa16x2's coset loop, pb16, the 16-column inverse-transform groups) at rate_bits 1 and 2 - every
+    stock configuration uses 3, so nothing else runs them with fewer cosets: 3 columns, the whole batch against the
+    oracle.  Also the place where a non-canonical word stored by the twiddle chains (mul_mont on a lazy operand) would show."""
+    log_n, ncols = 20, 3
+    seed = 0xFACE ^ (rate_bits << 40)
+    if field_name == "goldilocks":
+        vals = O.splitmix64_fill(seed, ncols << log_n).reshape(ncols, 1 << log_n)
+        cpu = O.PolynomialBatch.from_values(vals, rate_bits, 4)
+        gpu = PolynomialBatch.from_values(ctx, vals, rate_bits, 4)
+    else:
+        vals = B.fill(seed, ncols << log_n).reshape(ncols, 1 << log_n)
+        cpu = B.PolynomialBatch.from_values(vals, rate_bits, 4)
+        gpu = PolynomialBatch.from_values(ctx, vals, rate_bits, 4, field=GB_BABYBEAR)
+    assert (gpu.merkle_tree.cap == cpu.cap).all()
+    assert (gpu.polynomials == cpu.polynomials).all()
+    assert (gpu.merkle_tree.leaves == cpu.leaves).all()
+    assert (gpu.merkle_tree.digests == cpu.digests).all()
+    gpu.free()
+    ctx.trim()
+
+
 @pytest.mark.parametrize("field_name,ncols,salted", [
     ("goldilocks", 33, False), ("goldilocks", 40, False), ("goldilocks", 64, False), ("goldilocks", 70, False),
     ("goldilocks", 97, True), ("goldilocks", 135, False), ("babybear", 33, False), ("babybear", 44, True),
