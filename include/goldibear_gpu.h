@@ -198,6 +198,16 @@ gb_status gb_circuit_create_gates(gb_ctx* ctx, const gb_circuit_config* cfg, con
 gb_status gb_circuit_constants_sigmas_commitment(gb_circuit* c, gb_batch** out);
 /* VerifierOnlyCircuitData: constants_sigmas_cap [2^cap_height][H] and circuit_digest [H], field elements */
 gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_out);
+/* FriParams.reduction_arity_bits (fri/mod.rs, filled by FriConfig::fri_params from FriReductionStrategy::reduction_arity_bits,
+ * fri/reduction_strategies.rs:29-56).  gb_circuit_create* / gb_verifier_create derive the list of the stock strategy
+ * ConstantArityBits(cfg.arity_bits, cfg.final_poly_bits); a circuit configured with Fixed(..) or MinSize(..) hands the list its
+ * CommonCircuitData holds over with the setter before the first proof (prover, verifier and proof compression all read it).
+ * Rejected with GB_ERR_INVALID: more than GB_MAX_FRI_LAYERS layers, an arity outside [1, 4] (prover circuits; [1, 8] for
+ * verify-only circuits), arities that sum past degree_bits, or a layer whose tree would be lower than cap_height
+ * (MerkleTree::new's assert, hash/merkle_tree.rs:154-157).  The getter writes at most GB_MAX_FRI_LAYERS entries. */
+#define GB_MAX_FRI_LAYERS 32
+gb_status gb_circuit_set_fri_reduction_arity_bits(gb_circuit* c, const uint32_t* arity_bits, uint32_t num_layers);
+gb_status gb_circuit_fri_reduction_arity_bits(gb_circuit* c, uint32_t* arity_bits_out, uint32_t* num_layers_out);
 /* prove_with_partition_witness -> internal_prove_with_partition_witness (plonk/prover.rs:160-447):
  * witness = MatrixWitness.wire_values [num_wires][n] (iop/witness.rs:277-284), already generated.
  * Writes ProofWithPublicInputs bytes (util/serialization/mod.rs:2134-2151) to proof_out; *proof_len

@@ -21,6 +21,7 @@ pub const GB_ERR_VERIFY: i32 = 19;
 pub const GB_GOLDILOCKS: u32 = 0;
 pub const GB_BABYBEAR: u32 = 1;
 pub const GB_INPUT_HOST: u32 = 0;
+pub const GB_MAX_FRI_LAYERS: usize = 32;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -90,6 +91,8 @@ extern "C" {
                          flags: u32, out: *mut *mut gb_circuit) -> i32;
     fn gb_circuit_free(c: *mut gb_circuit) -> i32;
     fn gb_circuit_verifier_data(c: *mut gb_circuit, cap_out: *mut c_void, digest_out: *mut c_void) -> i32;
+    fn gb_circuit_set_fri_reduction_arity_bits(c: *mut gb_circuit, arity_bits: *const u32, num_layers: u32) -> i32;
+    fn gb_circuit_fri_reduction_arity_bits(c: *mut gb_circuit, arity_bits_out: *mut u32, num_layers_out: *mut u32) -> i32;
     fn gb_prove(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
                 proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
     fn gb_verify(c: *mut gb_circuit, proof: *const c_void, proof_len: usize) -> i32;
@@ -323,6 +326,19 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         }
         check(self.ctx.0, st)?;
         Ok(true)
+    }
+    /// `FriParams.reduction_arity_bits` of a circuit whose `FriReductionStrategy` is `Fixed(..)` or `MinSize(..)`
+    /// (fri/reduction_strategies.rs:29-56): hand over `common.fri_params.reduction_arity_bits` before the first proof.
+    pub fn set_fri_reduction_arity_bits(&self, arity_bits: &[usize]) -> Result<(), GpuError> {
+        let bits: Vec<u32> = arity_bits.iter().map(|&b| b as u32).collect();
+        check(self.ctx.0, unsafe { gb_circuit_set_fri_reduction_arity_bits(self.handle, bits.as_ptr(), bits.len() as u32) })
+    }
+    /// the list in force (derived from ConstantArityBits unless set)
+    pub fn fri_reduction_arity_bits(&self) -> Result<Vec<usize>, GpuError> {
+        let mut bits = [0u32; GB_MAX_FRI_LAYERS];
+        let mut n = 0u32;
+        check(self.ctx.0, unsafe { gb_circuit_fri_reduction_arity_bits(self.handle, bits.as_mut_ptr(), &mut n) })?;
+        Ok(bits[..n as usize].iter().map(|&b| b as usize).collect())
     }
     /// (constants_sigmas_cap, circuit_digest)
     pub fn verifier_data(&self) -> Result<(Vec<W>, Vec<W>), GpuError> {

@@ -270,6 +270,10 @@ def prove_cpu(circ, witness, public_inputs=(), salts=None, dump=None):
     out = np.zeros(cap, dtype=np.uint8)
     out_len = C.c_size_t()
     dbg = np.zeros(3 * c + 2 * F.D + 1, dtype=F.dtype)  # betas, gammas, alphas, zeta, fri_alpha, pow response
+    custom_arities = list(circ.reduction_arity_bits) != reduction_arity_bits(circ.cfg, circ.degree_bits)
+    if custom_arities:   # FriReductionStrategy::Fixed / MinSize: the circuit carries its own list (set circ.reduction_arity_bits)
+        arr = (C.c_uint * max(1, len(circ.reduction_arity_bits)))(*circ.reduction_arity_bits)
+        getattr(L, F.prove_symbol + "_set_reduction_arity_bits")(arr, C.c_uint(len(circ.reduction_arity_bits)))
     gate_terms = None
     if any(g[0] > G.POSEIDON2_BABYBEAR for g in getattr(circ, "gate_table", ())):
         # gates the C prover has no evaluator for (the recursion gate set): their terms come from oracle/gates.py
@@ -278,6 +282,8 @@ def prove_cpu(circ, witness, public_inputs=(), salts=None, dump=None):
     try:
         rc = _call_prover(fn, circ, cs, dig, wit, pis, public_inputs, out, cap, out_len, dbg, salts)
     finally:
+        if custom_arities:
+            getattr(L, F.prove_symbol + "_set_reduction_arity_bits")(None, C.c_uint(0))
         if gate_terms is not None:
             getattr(L, F.prove_symbol + "_set_gate_terms")(None, C.c_uint(0))
         if dump is not None:

@@ -116,6 +116,15 @@ void X_CAT(X_PROVE_DUMMY, _set_dump)(F_T *zs_values, F_T *quotient_chunks) { dum
  * num_gate_constraints sums  sum_gates filter(selector) * unfiltered_constraint_j  - computed by oracle/plonk_dummy.py
  * gate_constraint_terms() with the evaluators of oracle/gates.py (the ones the reference's recursion proof pins);
  * [N][nterms], used by the next proof instead of the inline evaluators. */
+/* FriParams.reduction_arity_bits of a circuit whose FriReductionStrategy is Fixed(..) or MinSize(..) (fri/reduction_strategies.rs:
+ * 29-56): when set, the next proofs use this list instead of deriving ConstantArityBits' from the configuration. */
+static unsigned ext_arity_bits[32], ext_narity = 0;
+static int ext_arity_set = 0;
+void X_CAT(X_PROVE_DUMMY, _set_reduction_arity_bits)(const unsigned *bits, unsigned n) {
+    ext_arity_set = bits != NULL;
+    ext_narity = 0;
+    for (unsigned i = 0; bits && i < n && i < 32; i++) ext_arity_bits[ext_narity++] = bits[i];
+}
 static const F_T *ext_gate_terms = NULL;
 static unsigned ext_gate_nterms = 0;
 void X_CAT(X_PROVE_DUMMY, _set_gate_terms)(const F_T *terms, unsigned nterms) { ext_gate_terms = terms; ext_gate_nterms = nterms; }
@@ -408,7 +417,9 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
 
     GBO_SCOPE("prove_openings");
     /* ---- fri_committed_trees (fri/prover.rs:83-133) */
-    { /* ConstantArityBits (fri/reduction_strategies.rs:44-56) */
+    if (ext_arity_set) {
+        for (unsigned i = 0; i < ext_narity; i++) arity_bits_list[narity++] = ext_arity_bits[i];
+    } else { /* ConstantArityBits (fri/reduction_strategies.rs:44-56) */
         unsigned db = lg;
         while (db > cfg->final_poly_bits && db + r >= capH + cfg->arity_bits) { arity_bits_list[narity++] = cfg->arity_bits; db -= cfg->arity_bits; }
     }

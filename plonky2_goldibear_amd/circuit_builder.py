@@ -33,9 +33,18 @@ class CircuitConfig:
 
     def __init__(self, field=N.GB_GOLDILOCKS, num_wires=135, num_routed_wires=80, num_constants=2, num_challenges=2,
                  max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16, num_query_rounds=28,
-                 arity_bits=4, final_poly_bits=5, security_bits=100):
+                 arity_bits=4, final_poly_bits=5, security_bits=100, fri_reduction_strategy=None):
+        """fri_reduction_strategy: None = FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (every stock
+        configuration); ("fixed", [bits..]) or ("min_size", max_arity_bits or None) as in fri/reduction_strategies.rs:11-25"""
         self.__dict__.update(locals())
         del self.__dict__["self"]
+
+    def reduction_arity_bits(self, degree_bits):
+        """FriConfig::fri_params' list for a circuit of 2^degree_bits rows (fri/mod.rs; None = let the library derive it)"""
+        if self.fri_reduction_strategy is None:
+            return None
+        from . import fri_params
+        return fri_params.reduction_arity_bits(self.fri_reduction_strategy, degree_bits, self.rate_bits, self.cap_height, self.num_query_rounds)
 
     @classmethod
     def standard_recursion_config_gl(cls, **kw):
@@ -726,7 +735,8 @@ class BuiltCircuit:
                                     rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, proof_of_work_bits=cfg.proof_of_work_bits,
                                     num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits,
                                     final_poly_bits=cfg.final_poly_bits, num_selectors=num_selectors, field=cfg.field,
-                                    gates=gate_table, num_public_inputs=len(public_inputs))
+                                    gates=gate_table, num_public_inputs=len(public_inputs),
+                                    reduction_arity_bits=cfg.reduction_arity_bits(degree_bits))
 
     def generate_witness(self, pw, rng=None):
         """generate_partial_witness + full_witness (iop/generator.rs:25-117, iop/witness.rs:359-371)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "gb_circuit_free": (_i32, [_vp]),
     "gb_circuit_verifier_data": (_i32, [_vp, _vp, _vp]),
     "gb_circuit_constants_sigmas_commitment": (_i32, [_vp, _pvp]),
+    "gb_circuit_set_fri_reduction_arity_bits": (_i32, [_vp, C.POINTER(_u32), _u32]),
+    "gb_circuit_fri_reduction_arity_bits": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "gb_zs_partial_products": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp]),
     "gb_quotient_polys": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "gb_prove_openings": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),

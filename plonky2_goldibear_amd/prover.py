@@ -61,7 +61,21 @@ class _ProofBytesOps:
         return True
 
 
-class CircuitData(_ProofBytesOps):
+class _FriParamsOps:
+    """FriParams.reduction_arity_bits of a circuit object (gb_circuit_set_fri_reduction_arity_bits / its getter)"""
+
+    def set_reduction_arity_bits(self, bits):
+        arr = (C.c_uint32 * max(1, len(bits)))(*[int(b) for b in bits])
+        N.check(self._lib.gb_circuit_set_fri_reduction_arity_bits(self.handle, arr, len(bits)), getattr(getattr(self, "ctx", None), "handle", None))
+
+    @property
+    def reduction_arity_bits(self):
+        arr, n = (C.c_uint32 * 32)(), C.c_uint32()
+        N.check(self._lib.gb_circuit_fri_reduction_arity_bits(self.handle, arr, C.byref(n)), getattr(getattr(self, "ctx", None), "handle", None))
+        return [int(arr[i]) for i in range(n.value)]
+
+
+class CircuitData(_ProofBytesOps, _FriParamsOps):
     """Defaults are standard_recursion_config_gl (plonk/circuit_data.rs:102-116); `CircuitData.babybear(...)`
     fills in recursion_config_bb_narrow (:131-139)."""
 
@@ -74,7 +88,7 @@ class CircuitData(_ProofBytesOps):
     def __init__(self, ctx, degree_bits, constants_sigmas, k_is, *, num_wires=135, num_routed_wires=80, num_constants=2,
                  num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16,
                  num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1, gate_constant=1, gate_pi=2,
-                 field=N.GB_GOLDILOCKS, gates=None, zero_knowledge=False, num_public_inputs=0):
+                 field=N.GB_GOLDILOCKS, gates=None, zero_knowledge=False, num_public_inputs=0, reduction_arity_bits=None):
         """`gates` = None: the dummy circuit's gate set, given by the selector values gate_constant / gate_pi
         (gb_circuit_create).  Otherwise CommonCircuitData.gates with selectors_info, one tuple
         (kind, param, selector_index, group_start, group_end) per gate in sorted order (gb_circuit_create_gates; what
@@ -114,6 +128,8 @@ class CircuitData(_ProofBytesOps):
         self.constants_sigmas_cap, self.circuit_digest = cap, dig
         self._proof_buf = None
         _live_circuits.add(self)
+        if reduction_arity_bits is not None:   # FriReductionStrategy::Fixed / MinSize (fri_params.py); None = ConstantArityBits
+            self.set_reduction_arity_bits(reduction_arity_bits)
 
     MAX_PERM_ARG_RETRIES = 3  # plonk/prover.rs:183
 
@@ -276,16 +292,17 @@ class CircuitData(_ProofBytesOps):
             self.free()
 
 
-class VerifierCircuitData(_ProofBytesOps):
+class VerifierCircuitData(_ProofBytesOps, _FriParamsOps):
     """VerifierCircuitData (plonk/circuit_data.rs:358-380): CommonCircuitData + VerifierOnlyCircuitData, enough to verify and
     nothing else.  Built on gb_verifier_create, which touches no device - usable without a GPU context."""
 
     def __init__(self, degree_bits, gates, k_is, constants_sigmas_cap, circuit_digest, *, num_wires=135, num_routed_wires=80,
                  num_constants=2, num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4,
                  proof_of_work_bits=16, num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1,
-                 zero_knowledge=False, field=N.GB_GOLDILOCKS, num_public_inputs=0):
+                 zero_knowledge=False, field=N.GB_GOLDILOCKS, num_public_inputs=0, reduction_arity_bits=None):
         """`gates`: (kind, param, selector_index, group_start, group_end[, param2, param3]) per gate, sorted as in
-        CommonCircuitData.gates; num_constants counts the constant columns after the selectors."""
+        CommonCircuitData.gates; num_constants counts the constant columns after the selectors; reduction_arity_bits:
+        FriParams.reduction_arity_bits when the strategy is not ConstantArityBits(arity_bits, final_poly_bits)."""
         self._lib = N.load()
         self.field, self._dt = field, _dtype(field)
         hout = 4 if field == N.GB_GOLDILOCKS else 8
@@ -303,6 +320,8 @@ class VerifierCircuitData(_ProofBytesOps):
         N.check(self._lib.gb_verifier_create(None, C.byref(self.cfg), arr, len(gates), k.ctypes.data, cap.ctypes.data,
                                              dig.ctypes.data, C.byref(h)))
         self.handle = h
+        if reduction_arity_bits is not None:
+            self.set_reduction_arity_bits(reduction_arity_bits)
 
     def verify(self, proof_bytes):
         """plonk/verifier.rs:17-128; True, or raises VerifyError naming the failed check."""

@@ -75,8 +75,12 @@ def oracle_circuit(built, num_public_inputs):
                             proof_of_work_bits=cfg.proof_of_work_bits, num_query_rounds=cfg.num_query_rounds,
                             arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits,
                             max_quotient_degree_factor=cfg.max_quotient_degree_factor)
-    return PD.BuiltCircuit(ocfg, F, built.degree_bits, built.constants_sigmas, built.k_is, built.gate_table, built.num_selectors,
-                           num_public_inputs)
+    oc = PD.BuiltCircuit(ocfg, F, built.degree_bits, built.constants_sigmas, built.k_is, built.gate_table, built.num_selectors,
+                         num_public_inputs)
+    bits = cfg.reduction_arity_bits(built.degree_bits) if hasattr(cfg, "reduction_arity_bits") else None
+    if bits is not None:   # FriReductionStrategy::Fixed / MinSize: FriParams carries the list
+        oc.reduction_arity_bits = list(bits)
+    return oc
 
 
 def recursion_gates_circuit(field=N.GB_GOLDILOCKS, seed=1, public_inputs=True, **cfg_kw):
