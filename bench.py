@@ -318,6 +318,10 @@ class ProveLeg:
             alu.update({"valu_instr_per_permutation": ipp, "achieved": ach, "frac": ach / peak,
                         "issue_cost_floor_frac": _num(ipp * leaf_perms / 64.0 * cyc / (SIMDS * CLOCK_HZ * leaves_ms * 1e-3)) if cyc else None,
                         "source": pj.get("profile_file"), "stale": pj.get("stale")})
+            mpp = pj.get("mfma_instr_per_permutation")
+            if mpp:   # Goldilocks: the MDS layers run on the matrix pipe - v_mfma_i32_32x32x32_i8, 32 cycles each on its SIMD
+                alu["mfma_instr_per_permutation"] = mpp
+                alu["matrix_pipe_busy_frac"] = _num(mpp * 32.0 * leaf_perms / 64.0 / (SIMDS * CLOCK_HZ * leaves_ms * 1e-3))
         out["roofline_alu"] = alu
         return out
 

@@ -32,8 +32,16 @@ floor = None
 if mix:
     SIMDS, CLOCK = 1024, 2.4e9
     floor = insts * mix["model_cycles_per_valu_instruction"] / (SIMDS * CLOCK * dur_s)
+# matrix-pipe share of the same kernel (its MDS layers are i8 MFMAs): from the MFMA counter pass when make_profiles.sh collected one
+mfma_per_perm = None
+mfma_csv = path.replace("_sq_counters.csv", "_mfma_counters.csv")
+if field == "goldilocks" and os.path.exists(mfma_csv):
+    mrow = next((r for r in csv.DictReader(open(mfma_csv)) if r["Kernel"] == kernel), None)
+    if mrow and float(mrow.get("SQ_INSTS_MFMA", 0) or 0) > 0:
+        mperms = N * (-(-cols // 8)) * int(mrow["Dispatches"])
+        mfma_per_perm = float(mrow["SQ_INSTS_MFMA"]) / (mperms / 64.0)
 res = {
-    "csrc_sha16": csrc_sha16(), "issue_cost_floor_frac": floor, "isa_mix": mix,
+    "csrc_sha16": csrc_sha16(), "issue_cost_floor_frac": floor, "isa_mix": mix, "mfma_instr_per_permutation": mfma_per_perm,
     "source_file": path, "kernel": kernel, "columns": cols, "log_n": log_n, "permutations": perms,
     "SQ_INSTS_VALU": insts, "valu_instr_per_permutation": insts / (perms / 64.0),
     "vgprs": int(row["VGPRs"]), "duration_ns_under_pmc": float(row["TotalDurationNs(under PMC)"]),
