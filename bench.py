@@ -272,16 +272,20 @@ class ProveLeg:
         return alg_bytes, perms, leaf_perms, nzs, nq
 
     def report(self, steps, scopes, inflight, retries=0):
-        """roofline / roofline_alu / merkle objects of one timed region.  A proof that hit InvZeroPermArg redid its wires commitment
-        (prover.rs:183-226): that work is inside the scopes, so it is inside the per-step byte and permutation counts as well."""
+        """roofline / roofline_alu / merkle objects of one timed region.  A proof that hit InvZeroPermArg redid (part of) its wires
+        commitment (prover.rs:183-226): that work is inside the scopes, so it is inside the per-step byte and permutation counts as
+        well.  From a host witness the retry is incremental (gb_prove_retry: the random wire's column, the last absorption of
+        every leaf sponge, the tree above); this is the host-witness leg's report."""
         bb, fname = self.bb, self.field
         alg_bytes, perms, leaf_perms, nzs, nq = self.counts()
-        redo = retries / float(steps)   # extra wires commitments per step
+        redo = retries / float(steps)   # extra (partial) wires commitments per step
         n_, N_ = 1 << self.log_n, (1 << self.log_n) << 3
-        wires_leaf_perms = N_ * (-(-self.nwires // 8))
-        alg_bytes += int(redo * (2 + 8) * self.nwires * n_ * self.esz)
-        leaf_perms += int(redo * wires_leaf_perms)
-        perms += int(redo * (wires_leaf_perms + N_ - 16))
+        incremental = self.log_n + 3 >= 19 and self.nwires > 32      # the library's condition (include/goldibear_gpu.h, gb_prove_retry)
+        redo_cols = 1 if incremental else self.nwires
+        redo_leaf_perms = N_ * (1 if incremental else -(-self.nwires // 8))
+        alg_bytes += int(redo * (2 + 8) * redo_cols * n_ * self.esz)
+        leaf_perms += int(redo * redo_leaf_perms)
+        perms += int(redo * (redo_leaf_perms + N_ - 16))
         live = inflight == 1
         ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps if live else None
         merkle_ms = scopes["build Merkle tree"][0] / steps if live else None

@@ -107,6 +107,8 @@ extern "C" {
                          fri_proof_cap: usize, fri_proof_len: *mut usize) -> i32;
     fn gb_circuit_create_gates(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, gates: *const gb_gate, num_gates: u32,
                                constants_sigmas: *const c_void, k_is: *const c_void, flags: u32, out: *mut *mut gb_circuit) -> i32;
+    fn gb_prove_retry(c: *mut gb_circuit, witness: *const c_void, flags: u32, wire: u32, row: u64, public_inputs: *const u64,
+                      num_public_inputs: usize, proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
     fn gb_prove_salted(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
                        salts: *const c_void, proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
     fn gb_verifier_create(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, gates: *const gb_gate, num_gates: u32, k_is: *const c_void,
@@ -357,6 +359,24 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         let st = unsafe {
             gb_prove(self.handle, witness.as_ptr() as *const c_void, GB_INPUT_HOST, public_inputs.as_ptr(), public_inputs.len(),
                      buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
+        };
+        if st == GB_ERR_PERM_ARG_ZERO {
+            return Ok(ProveOutcome::PermArgZero);
+        }
+        check(self.ctx.0, st)?;
+        buf.truncate(len);
+        Ok(ProveOutcome::Proof(buf))
+    }
+    /// The retry of `prove_with_partition_witness` (plonk/prover.rs:183-226): `witness` is the matrix of the `prove` call that has
+    /// just returned `PermArgZero`, with `wire_values[wire][row]` (the circuit's `random_wire`) re-drawn.  Same result as `prove`.
+    pub fn prove_retry(&self, witness: &[W], wire: usize, row: usize, public_inputs: &[u64]) -> Result<ProveOutcome, GpuError> {
+        need("witness", witness.len(), (self.config.num_wires as usize) << self.config.degree_bits)?;
+        need("public_inputs", public_inputs.len(), self.config.num_public_inputs as usize)?;
+        let mut buf = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        let st = unsafe {
+            gb_prove_retry(self.handle, witness.as_ptr() as *const c_void, GB_INPUT_HOST, wire as u32, row as u64, public_inputs.as_ptr(),
+                           public_inputs.len(), buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
         };
         if st == GB_ERR_PERM_ARG_ZERO {
             return Ok(ProveOutcome::PermArgZero);

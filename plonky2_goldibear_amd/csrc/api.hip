@@ -407,8 +407,16 @@ struct EventList {  // events of one enqueue sequence, destroyed together (destr
 // and LDE of the chunk before it run on the main stream.  values_dev (optional): a device buffer [ncols][n] that receives the input
 // values in the field's device form, so that the caller gets them on the device without a second transfer (prove() needs the
 // routed wires there for the permutation argument).
+// What a segmented host-input commit can leave behind for a caller that may have to redo its LAST column segment (the prover's
+// InvZeroPermArg retry re-draws one wire of the last column): the sponge state every leaf had after columns [0, start).
+struct SegKeep {
+    void* state = nullptr;   // pool block; the taker returns it with pool_free(ctx, state, bytes)
+    size_t bytes = 0;
+    u32 start = 0;           // first column of the last segment
+};
 gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                 uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr) {
+                 uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr,
+                 SegKeep* keep = nullptr) {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     if (!out) return fail(ctx, GB_ERR_INVALID, "null out");
     *out = nullptr;
@@ -563,6 +571,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
                 gbk::bb_merkle_level(lv + 8 * level_offset(N, k), lv + 8 * level_offset(N, k + 1), N >> (k + 1), st);
         }
         if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, GB_ERR_HIP, "kernel launch failed"));
+        if (keep && seg_done && seg_state) { *keep = SegKeep{seg_state, seg_state_bytes, seg_done}; seg_state = nullptr; }
         *out = b;
         return GB_OK;
     }
@@ -634,6 +643,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             gbk::gl_merkle_level(b->levels + 4 * level_offset(N, k), b->levels + 4 * level_offset(N, k + 1), N >> (k + 1), st);
     }
     if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, GB_ERR_HIP, "kernel launch failed"));
+    if (keep && seg_done && seg_state) { *keep = SegKeep{seg_state, seg_state_bytes, seg_done}; seg_state = nullptr; }
     *out = b;
     return GB_OK;
 }

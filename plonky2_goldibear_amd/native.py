@@ -58,6 +58,7 @@ SIGNATURES = {
     "gb_quotient_polys": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "gb_prove_openings": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "gb_prove": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "gb_prove_retry": (_i32, [_vp, _vp, _u32, _u32, _u64, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "gb_prove_salted": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
 }
 

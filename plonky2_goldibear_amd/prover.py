@@ -155,12 +155,15 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
                     witness[col, row] = val - (1 << (8 * witness.element_size())) if val >> (8 * witness.element_size() - 1) else val
                 self.perm_arg_retries = attempt
             try:
-                return self.prove_once(witness, public_inputs, salts)
+                # the second and third attempts differ from the failed one in the random wire only: gb_prove_retry rebuilds just
+                # that column of the wires commitment where the library kept the rest (host witness, no salts)
+                retry = (col, row) if attempt > 0 and salts is None and isinstance(witness, np.ndarray) else None
+                return self.prove_once(witness, public_inputs, salts, retry_wire=retry)
             except N.PermArgZeroError:
                 continue
         raise N.TooManyPermArgFailuresError(N.GB_ERR_PERM_ARG_ZERO, "ProverError::TooManyPermArgFailures")
 
-    def prove_once(self, witness, public_inputs=(), salts=None):
+    def prove_once(self, witness, public_inputs=(), salts=None, retry_wire=None):
         """internal_prove_with_partition_witness (plonk/prover.rs:228-447); raises PermArgZeroError.  A circuit created with
         zero_knowledge=True takes `salts`: [3][4][N] canonical elements (the F::rand_vec columns of the wires / Zs / quotient
         commitments, fri/oracle.rs:144-148), in the same memory space as the witness."""
@@ -173,7 +176,10 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
             self._proof_buf = np.empty(8 << 20, dtype=np.uint8)
         n = C.c_size_t()
         pis_ptr = pis.ctypes.data if pis.size else None
-        if salts is None:
+        if salts is None and retry_wire is not None:   # (wire, row): the one element re-drawn since the attempt that failed
+            st = self._lib.gb_prove_retry(self.handle, ptr, flags, int(retry_wire[0]), int(retry_wire[1]), pis_ptr, pis.size,
+                                          self._proof_buf.ctypes.data, self._proof_buf.size, C.byref(n))
+        elif salts is None:
             st = self._lib.gb_prove(self.handle, ptr, flags, pis_ptr, pis.size, self._proof_buf.ctypes.data, self._proof_buf.size,
                                     C.byref(n))
         else:

@@ -119,10 +119,40 @@ def test_bb_inv_zero_perm_arg_and_retry(ctx):
     with pytest.raises(TooManyPermArgFailuresError):  # no random wire given: the reference bails the same way
         gpu.prove(bad.copy())
     w = bad.copy()
-    proof = gpu.prove(w, random_wire=(circ.cfg.num_wires - 1, circ.pi_row), rng=np.random.default_rng(5))
+    rw = (circ.cfg.num_wires - 1, circ.pi_row)
+    proof = gpu.prove(w, random_wire=rw, rng=np.random.default_rng(5))
     assert gpu.perm_arg_retries >= 1
-    assert (w != bad).sum() == 1 and w[circ.cfg.num_wires - 1, circ.pi_row] != bad[circ.cfg.num_wires - 1, circ.pi_row]
+    assert (w != bad).sum() == 1 and w[rw] != bad[rw]
     assert D.verify(circ, proof)
+    # The attempts after the first went through gb_prove_retry, which rebuilds only the random wire's column of the failed
+    # attempt's wires commitment (2^19 leaves, 167 wires, host witness: the incremental path): same bytes as proving the final
+    # witness from scratch, on the GPU and on the CPU oracle.
+    assert proof == gpu.prove_once(w)
+    assert proof == D.prove_cpu(circ, w)[0]
+    # gb_prove_retry is gb_prove whenever there is nothing to build on: no failed attempt before it ...
+    assert gpu.prove_once(w, retry_wire=rw) == proof
+    # ... a wire outside the last leaf-sponge segment (columns 160..166 here) ...
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(bad)
+    w2 = bad.copy()
+    w2[5, 7] = (int(w2[5, 7]) + 1) % 2013265921
+    try:
+        p2 = gpu.prove_once(w2, retry_wire=(5, 7))
+        assert p2 == gpu.prove_once(w2)
+    except PermArgZeroError:
+        pass                                   # the other wire's change did not lift the zero denominator: also gb_prove's answer
+    # ... or another proof in between (the kept state belongs to the last failed attempt only)
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(bad)
+    other = circ.witness(seed=99)
+    gpu.prove_once(other)
+    assert gpu.prove_once(w, retry_wire=rw) == proof
+    # two failures in a row: the second attempt's state is kept for the third
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(bad)
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(bad, retry_wire=rw)     # "re-drawn" to the same value: fails again, incrementally
+    assert gpu.prove_once(w, retry_wire=rw) == proof
 
 
 @pytest.mark.parametrize("degree_bits,num_challenges", [(15, 7), (17, 8), (18, 8), (19, 9)])
