@@ -226,11 +226,11 @@ gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uin
  * fresh F::rand() and proves again.  gb_prove_retry(witness, wire, row) is that second call: `witness` is the matrix of the failed
  * gb_prove on this circuit with wire_values[wire][row] re-drawn and nothing else changed.  It returns exactly what
  * gb_prove(witness) returns - same bytes, same errors (another GB_ERR_PERM_ARG_ZERO included: call it again) - but where the failed
- * attempt has left its wires commitment behind (host witness, >= 2^19 leaves, more than 32 wires, `wire` among the columns of the
+ * attempt has left its wires commitment behind (host or device witness, >= 2^19 leaves, more than 32 wires, `wire` among the columns of the
  * last leaf-sponge segment - true for the random wire of every stock configuration) only that wire's column is transformed again
  * and only the last absorption of every leaf sponge and the tree above are re-hashed: ~5 ms instead of ~40 at 2^20 BabyBear rows,
- * where one proof in five needs it.  Anything else - no failed attempt before it, another gb_prove* in between, a device-resident
- * witness, a zero-knowledge circuit - is simply the full computation.  The state of a failed attempt is held until the next
+ * where one proof in five needs it.  Anything else - no failed attempt before it, another gb_prove* in between, a device attempt
+ * retried with a host matrix, a zero-knowledge circuit - is simply the full computation.  The state of a failed attempt is held until the next
  * gb_prove* / gb_circuit_free on the circuit. */
 gb_status gb_prove_retry(gb_circuit* c, const void* witness, uint32_t flags, uint32_t wire, uint64_t row, const uint64_t* public_inputs,
                          size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);

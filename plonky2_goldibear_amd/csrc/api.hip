@@ -465,6 +465,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     constexpr u32 SEG = 32;
     auto seg_size = [](u32 done) -> u32 { return done < 16 ? 8u : (done < 32 ? 16u : SEG); };
     const bool segmented = !dev_in && !is_coeffs && log_N >= 19 && ncols > SEG;
+    const bool keep_split = keep && dev_in && !is_coeffs && log_N >= 19 && ncols > SEG;   // same split for device input, on request
     u32 seg_done = 0;
     void* seg_state = nullptr;
     // the parked sponge state: the capacity words, plus the rate words a ragged LAST absorption leaves alone when it is a segment
@@ -564,6 +565,11 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             u32* lv = (u32*)b->levels;
             {
                 Scope sl(ctx, "hash leaves");
+                if (!seg_done && keep_split) {   // device input whose last column segment may have to be redone: hash in two segments
+                    if (pool_alloc(ctx, seg_state_bytes, &seg_state) != hipSuccess) { seg_state = nullptr; return cleanup(fail(ctx, GB_ERR_OOM, "sponge state")); }
+                    gbk::bb_merkle_leaves_segment(lde, N, 0, last_seg_start, N, (u32*)seg_state, false, (u32)(width - last_seg_start), lv, st);
+                    seg_done = last_seg_start;
+                }
                 if (seg_done) gbk::bb_merkle_leaves_segment(lde, N, seg_done, (u32)width, N, (u32*)seg_state, true, 0, lv, st);
                 else gbk::bb_merkle_leaves(lde, N, (u32)width, N, lv, st);
             }
@@ -636,6 +642,11 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         Scope sc(ctx, "build Merkle tree");
         {
             Scope sl(ctx, "hash leaves");
+            if (!seg_done && keep_split) {   // device input whose last column segment may have to be redone: hash in two segments
+                if (pool_alloc(ctx, seg_state_bytes, &seg_state) != hipSuccess) { seg_state = nullptr; return cleanup(fail(ctx, GB_ERR_OOM, "sponge state")); }
+                gbk::gl_merkle_leaves_segment(b->lde, N, 0, last_seg_start, N, (u64*)seg_state, false, (u32)(width - last_seg_start), b->levels, st);
+                seg_done = last_seg_start;
+            }
             if (seg_done) gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, (u32)width, N, (u64*)seg_state, true, 0, b->levels, st);
             else gbk::gl_merkle_leaves(b->lde, N, (u32)width, N, b->levels, st);
         }

@@ -156,8 +156,8 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
                 self.perm_arg_retries = attempt
             try:
                 # the second and third attempts differ from the failed one in the random wire only: gb_prove_retry rebuilds just
-                # that column of the wires commitment where the library kept the rest (host witness, no salts)
-                retry = (col, row) if attempt > 0 and salts is None and isinstance(witness, np.ndarray) else None
+                # that column of the wires commitment where the library kept the rest (no salts)
+                retry = (col, row) if attempt > 0 and salts is None else None
                 return self.prove_once(witness, public_inputs, salts, retry_wire=retry)
             except N.PermArgZeroError:
                 continue

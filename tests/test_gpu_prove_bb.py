@@ -153,6 +153,25 @@ def test_bb_inv_zero_perm_arg_and_retry(ctx):
     with pytest.raises(PermArgZeroError):
         gpu.prove_once(bad, retry_wire=rw)     # "re-drawn" to the same value: fails again, incrementally
     assert gpu.prove_once(w, retry_wire=rw) == proof
+    # a device-resident witness: the column is read from the caller's matrix, the kept leaf-sponge state comes from a two-
+    # segment hash of the device input
+    import torch
+    dbad = torch.from_numpy(bad.view(np.int32)).cuda()
+    dw = torch.from_numpy(w.view(np.int32)).cuda()
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(dbad)
+    assert gpu.prove_once(dw, retry_wire=rw) == proof
+    assert gpu.prove_once(dw) == proof
+    d = dbad.clone()
+    assert gpu.prove(d, random_wire=rw, rng=np.random.default_rng(5)) == proof   # the same draw as the host run above
+    assert gpu.perm_arg_retries >= 1
+    # a failed host attempt followed by a device retry, and the other way round
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(bad)
+    assert gpu.prove_once(dw, retry_wire=rw) == proof
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(dbad)
+    assert gpu.prove_once(w, retry_wire=rw) == proof
 
 
 @pytest.mark.parametrize("degree_bits,num_challenges", [(15, 7), (17, 8), (18, 8), (19, 9)])
