@@ -93,17 +93,23 @@ constexpr Plan PLAN = make_plan();
 __device__ static const plan::Plan PLAN = plan::PLAN;
 __device__ static const u32 ZERO16[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-// x^7 for canonical x; the result is LAZY (< 2p): x3 = x x2 and x7 = x3 x4 skip the final selection of the Montgomery
-// reduction (x2 and x4 are canonical, so every product stays below p 2^32).  Every consumer here takes a lazy word:
-// the unreduced sums of the external layer and the multiplication by kappa^-6 of the internal rounds.
+// x^7 for a word x with |x| <= 1.03 p as a signed number (canonical, or what bb::reduce_signed leaves); the result is LAZY
+// (in (0, 2p)).  The three inner products are SIGNED Montgomery products (bb::mul_signed: no final selection, the word just stays
+// within +-0.97 p), the last one adds p to come out non-negative: 12 multiplies + 5 plain operations, where two canonical and two
+// lazy unsigned products took 12 + 10.  Every consumer here takes a lazy word: the unreduced sums of the external layer and the
+// multiplication by kappa^-6 of the internal rounds.
 __device__ __forceinline__ u32 sbox7(u32 x) {
-    u32 x2 = bb::sqr(x), x4 = bb::sqr(x2), x3 = bb::mul_lazy(x, x2);
-    return bb::mul_lazy(x3, x4);
+    const int x1 = (int)x;
+    const int x2 = bb::mul_signed(x1, x1), x4 = bb::mul_signed(x2, x2), x3 = bb::mul_signed(x1, x2);
+    return (u32)bb::mul_signed(x3, x4, bb::P);
 }
 
 // M_E (gates/poseidon2_babybear.rs:804-832, 903-917): per 4-block [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], i.e.
 // n0 = T + a + 2b, n1 = T + b + 2c, n2 = T + c + 2d, n3 = T + d + 2a with T = a + b + c + d, then every word gets the sum
 // of its column class.  All in 64 bits, `c` (the next constants, scaled) added, one reduction per word (scale / R).
+// SIGNED: the words go straight into s-boxes, which take signed words within +-1.03 p (bb::reduce_signed: two operations fewer per
+// word); otherwise canonical.
+template <bool SIGNED = false>
 __device__ __forceinline__ void external_layer(u32 (&s)[16], const u32* __restrict__ c) {
     u64 n[16];
 #pragma unroll
@@ -119,7 +125,10 @@ __device__ __forceinline__ void external_layer(u32 (&s)[16], const u32* __restri
 #pragma unroll
     for (int k = 0; k < 4; k++) sums[k] = n[k] + n[4 + k] + n[8 + k] + n[12 + k];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = bb::reduce(n[i] + sums[i & 3] + c[i]);  // < 36 p
+    for (int i = 0; i < 16; i++) {
+        const u64 t = n[i] + sums[i & 3] + c[i];  // < 71 p: 35 lazy words and a constant
+        s[i] = SIGNED ? (u32)bb::reduce_signed(t) : bb::reduce(t);
+    }
 }
 
 // One internal round: s0 <- (s0 + rc)^7, then M_I (gates/poseidon2_babybear.rs:787-802).  `rc` is scaled (PLAN.in);
@@ -144,12 +153,15 @@ __device__ __forceinline__ void internal_round(u32 (&s)[16], u32 rc) {
 // The permutation up to the final common scale kappa_final: finish every word that is used afterwards with
 // renorm() (-> Montgomery form at scale 1, e.g. the capacity words of a sponge) or canonical_out() (-> canonical value).
 __device__ __forceinline__ void permute_scaled(u32 (&s)[16]) {
-    external_layer(s, PLAN.ext[0]);
-    for (int r = 0; r < 4; r++) {
+    external_layer<true>(s, PLAN.ext[0]);
+    for (int r = 0; r < 3; r++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
-        external_layer(s, r < 3 ? PLAN.ext[r + 1] : ZERO16);
+        external_layer<true>(s, PLAN.ext[r + 1]);
     }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
+    external_layer(s, ZERO16);
     for (int r = 0; r < 13; r++) internal_round(s, PLAN.in[r]);
 #pragma unroll
     for (int i = 1; i < 16; i++) {  // lazy words back below p
@@ -158,11 +170,14 @@ __device__ __forceinline__ void permute_scaled(u32 (&s)[16]) {
     }
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = bb::add(s[i], PLAN.ext[4][i]);
-    for (int r = 4; r < 8; r++) {
+    for (int r = 4; r < 7; r++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
-        external_layer(s, r < 7 ? PLAN.ext[r + 1] : ZERO16);
+        external_layer<true>(s, PLAN.ext[r + 1]);
     }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
+    external_layer(s, ZERO16);
 }
 __device__ __forceinline__ u32 renorm(u32 x) { return bb::mul(x, PLAN.out); }
 __device__ __forceinline__ u32 canonical_out(u32 x) { return bb::mul(x, PLAN.out_canon); }
