@@ -58,6 +58,8 @@ constexpr u32 RINV = cinv(R);
 struct Plan {
     u32 ext[8][16];  // Montgomery form of kappa * EXTERNAL_CONSTANTS[r], kappa = the scale when round r's constants are added
     u32 in[13];      // Montgomery form of kappa * INTERNAL_CONSTANTS[r]
+    u32 sumc[13];    // internal round j: minus the sum of the offsets the lazy words 1..15 carry at that point (see internal_round)
+    u32 ext4[16];    // round 4's constants (ext[4]) minus the offsets left by the thirteenth internal round
     u32 fix6;        // kappa^-6 (plain) during the internal rounds: mont(s-box output, fix6) = (word 0 at the common scale) * 2^-32
     u32 out;         // Montgomery form of 1 / kappa_final: mont(word, out) = Montgomery form at scale 1
     u32 out_canon;   // 1 / kappa_final (plain): mont(word, out_canon) = the canonical value
@@ -78,7 +80,21 @@ constexpr Plan make_plan() {
     }
     for (int r = 0; r < 13; r++) p.in[r] = cmul(cmul(k, raw::INT[r] % bb::P), R);
     p.fix6 = cinv(cpow(k, 6));
-    fill_ext(4, k);  // added canonically before round 4's s-box
+    fill_ext(4, k);  // added before round 4's s-box
+    {   // offsets of the lazy words through the internal rounds: word i enters round j as (true word) + e[i]; the round stores
+        // full + (word 2^sh_i / 2^32) + ceil(p/2) (internal_round), so e[i] <- e[i] 2^sh_i / 2^32 + ceil(p/2), and the sum the
+        // round takes over the words is corrected by -sum e[i]
+        constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};
+        u32 e[15] = {};
+        for (int r = 0; r < 13; r++) {
+            u32 tot = 0;
+            for (int i = 0; i < 15; i++) tot = (u32)(((u64)tot + e[i]) % bb::P);
+            p.sumc[r] = (bb::P - tot) % bb::P;
+            for (int i = 0; i < 15; i++) e[i] = (u32)(((u64)cmul(cmul(e[i], (u32)(((u64)1 << SH[i]) % bb::P)), RINV) + (bb::P + 1) / 2) % bb::P);
+        }
+        p.ext4[0] = p.ext[4][0];
+        for (int i = 0; i < 15; i++) p.ext4[i + 1] = (u32)(((u64)p.ext[4][i + 1] + bb::P - e[i]) % bb::P);
+    }
     for (int r = 4; r < 8; r++) {
         k = cpow(k, 7);
         if (r < 7) fill_ext(r + 1, k);
@@ -115,11 +131,12 @@ __device__ __forceinline__ void external_layer(u32 (&s)[16], const u32* __restri
 #pragma unroll
     for (int b = 0; b < 16; b += 4) {
         const u64 x0 = s[b], x1 = s[b + 1], x2 = s[b + 2], x3 = s[b + 3];
-        const u64 t = x0 + x1 + x2 + x3;
-        n[b] = t + x0 + 2 * x1;
-        n[b + 1] = t + x1 + 2 * x2;
-        n[b + 2] = t + x2 + 2 * x3;
-        n[b + 3] = t + x3 + 2 * x0;
+        const u64 t01 = x0 + x1, t23 = x2 + x3, t = t01 + t23;
+        const u64 ta = t + x1, tb = t + x3;          // nine additions for the four rows
+        n[b] = ta + t01;                             // 2 x0 + 3 x1 + x2 + x3
+        n[b + 1] = ta + 2 * x2;                      // x0 + 2 x1 + 3 x2 + x3
+        n[b + 2] = tb + t23;                         // x0 + x1 + 2 x2 + 3 x3
+        n[b + 3] = tb + 2 * x0;                      // 3 x0 + x1 + x2 + 2 x3
     }
     u64 sums[4];
 #pragma unroll
@@ -134,20 +151,47 @@ __device__ __forceinline__ void external_layer(u32 (&s)[16], const u32* __restri
 // One internal round: s0 <- (s0 + rc)^7, then M_I (gates/poseidon2_babybear.rs:787-802).  `rc` is scaled (PLAN.in);
 // the s-box leaves word 0 at scale kappa^7, and y0 = (word 0 at the common scale) * 2^-32 comes out of ONE Montgomery
 // multiplication by kappa^-6.
-// Words 1..15 are LAZY inside the internal rounds: full + v_i < 2p is kept unreduced (it only feeds a Montgomery
-// reduction, which takes any 32-bit word, and the 64-bit sum); they are brought back below p once after the last round.
-__device__ __forceinline__ void internal_round(u32 (&s)[16], u32 rc) {
+// Words 1..15 are LAZY inside the internal rounds (any word below LAZY_MAX): they only feed the 64-bit sum and a Montgomery
+// reduction of the shifted word, which takes any 32-bit word.  That reduction is the signed one (bb::mul_signed's): with
+// t = s 2^k and m = lo(t) / P as a signed word, hi(t - m P) lies in (hi(t) - p/2, hi(t) + p/2]; adding `full` + ceil(p/2) first
+// makes the new word non-negative, and it all fits THREE multiply-adds per word - m = s (2^k / P) as one v_mul_lo,
+// d = s 2^k + 2^32 (full + ceil(p/2)) as one v_mad_u64_u32, d - m P as one v_mad_i64_i32, whose high word is the new s_{i+1} -
+// where shift, reduction, selection and addition took seven.  ceil(p/2) is not a multiple of p: every lazy word carries an OFFSET
+// that is a compile-time constant per (round, word); `sumc` (PLAN.sumc) takes the offsets out of the sum, and the constants of the
+// external round that follows the internal ones take out the last ones (PLAN.ext4).
+// a * b + c with a wave-uniform b (a power of two here): one v_mad_u64_u32 where the compiler builds a zero-extended pair, shifts
+// it and adds (v_mov + v_lshlrev_b64 + v_lshl_add_u64)
+__device__ __forceinline__ u64 mad_wide(u32 a, u32 b_uniform, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 d, carry_unused;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+#else
+    return (u64)a * b_uniform + c;
+#endif
+}
+static constexpr u32 HALF_P = (bb::P + 1) / 2;
+static constexpr u32 LAZY_MAX = 2 * bb::P + (1u << 15) + 1;   // full < p, + ceil(p/2), + hi(t) < 2^15, + p/2
+static_assert((u64)LAZY_MAX < ((u64)1 << 32), "lazy words must fit 32 bits");
+__device__ __forceinline__ void internal_round(u32 (&s)[16], u32 rc, u32 sumc) {
     constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};  // gates/poseidon2_babybear.rs:41-42
     // part = sum_{i>=1} s_i 2^-32: the reduction is linear, so reduce the 36-bit sum once instead of 15 words
-    u64 sum = s[1];
+    u64 sum = (u64)s[1] + sumc;
 #pragma unroll
-    for (int i = 2; i < 16; i++) sum += s[i];  // words < 2p < 2^32
+    for (int i = 2; i < 16; i++) sum = mad_wide(s[i], 1u, sum);
     const u32 part = bb::reduce(sum);
     const u32 y0 = bb::mul(sbox7(bb::add(s[0], rc)), PLAN.fix6);
     const u32 full = bb::add(part, y0);
     s[0] = bb::sub(part, y0);
+    const u64 base = (u64)(full + HALF_P) << 32;
 #pragma unroll
-    for (int i = 0; i < 15; i++) s[i + 1] = full + bb::reduce((u64)s[i + 1] << SH[i]);  // (s_{i+1} 2^-32) 2^k, < 2p
+    for (int i = 0; i < 15; i++) {
+        const u32 w = s[i + 1];
+        const int m = (int)(w * (bb::PINV << SH[i]));            // lo(w 2^k) / P mod 2^32
+        u64 d = SH[i] ? mad_wide(w, 1u << SH[i], base) : (base | w);
+        d -= (u64)((long long)m * (int)bb::P);                    // low word: zero
+        s[i + 1] = (u32)(d >> 32);
+    }
 }
 
 // The permutation up to the final common scale kappa_final: finish every word that is used afterwards with
@@ -162,14 +206,15 @@ __device__ __forceinline__ void permute_scaled(u32 (&s)[16]) {
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
     external_layer(s, ZERO16);
-    for (int r = 0; r < 13; r++) internal_round(s, PLAN.in[r]);
+    for (int r = 0; r < 13; r++) internal_round(s, PLAN.in[r], PLAN.sumc[r]);
+    // round 4's constants, for the signed s-box: word 0 is canonical, the lazy words come below p + 2^15 with one selection, and
+    // adding (constant - p) leaves every word within (-p, p + 2^15)
+    s[0] += PLAN.ext4[0] - bb::P;
 #pragma unroll
-    for (int i = 1; i < 16; i++) {  // lazy words back below p
+    for (int i = 1; i < 16; i++) {
         const u32 t = s[i] - bb::P;
-        s[i] = t < s[i] ? t : s[i];
+        s[i] = (t < s[i] ? t : s[i]) + (PLAN.ext4[i] - bb::P);
     }
-#pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = bb::add(s[i], PLAN.ext[4][i]);
     for (int r = 4; r < 7; r++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);

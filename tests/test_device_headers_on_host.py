@@ -1,0 +1,20 @@
+"""The device-side permutation header compiled for the CPU (g++, tests/host_shim) and compared with the host mirror on random and
+extreme states: the signed / lazy / offset bookkeeping of csrc/poseidon2_bb.hpp is integer arithmetic that does not need a GPU
+to be checked, and its failures would be data dependent."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_poseidon2_bb_lane_permutation_matches_host_mirror(tmp_path):
+    exe = tmp_path / "poseidon2_bb_lane"
+    shim = os.path.join(ROOT, "tests", "host_shim")
+    cmd = ["g++", "-O2", "-std=c++17", "-include", os.path.join(shim, "shim.h"), "-I", shim,
+           "-I", os.path.join(ROOT, "plonky2_goldibear_amd", "csrc"), "-o", str(exe), os.path.join(shim, "poseidon2_bb_lane.cpp")]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe), "200000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
