@@ -35,21 +35,21 @@ __host__ __device__ __forceinline__ u32 sub(u32 a, u32 b) {
 }
 __host__ __device__ __forceinline__ u32 neg(u32 a) { return a ? P - a : 0; }
 
-// t < P * 2^32  ->  t * 2^-32 mod P, canonical
+// t < P * 2^32  ->  t * 2^-32 mod P, canonical.  m = -lo(t) / P mod 2^32 makes t + m P a multiple of 2^32 below 2 P 2^32, so the
+// whole reduction step is ONE multiply-add (v_mad_u64_u32 on the device) whose high word lies in [0, 2P); min() with the word less
+// P selects the canonical one.  (A v_mul_hi_u32 and a subtraction more in the t - m P form with m = lo(t) / P.)
+static constexpr u32 NPINV = 0u - PINV;        // -P^-1 mod 2^32
 __host__ __device__ __forceinline__ u32 reduce(u64 t) {
-    u32 m = (u32)t * PINV;
-    u32 u = (u32)(((u64)m * P) >> 32);
-    u32 hi = (u32)(t >> 32);
-    u32 d = hi - u;  // hi, u < P: same selection as sub() (a 64-bit compare + s_nop + cndmask otherwise)
-    u32 e = d + P;
-    return e < d ? e : d;
+    const u32 m = (u32)t * NPINV;
+    const u32 r = (u32)((t + (u64)m * P) >> 32);
+    const u32 e = r - P;
+    return e < r ? e : r;
 }
-// t < P * 2^32 -> a word in (0, 2P) congruent to t * 2^-32: the reduction without its final selection (2 ops fewer);
+// t < P * 2^32 -> a word in [0, 2P) congruent to t * 2^-32: the reduction without its final selection;
 // good wherever the result only feeds another Montgomery product with a canonical partner or an unreduced sum
 __host__ __device__ __forceinline__ u32 reduce_lazy(u64 t) {
-    u32 m = (u32)t * PINV;
-    u32 u = (u32)(((u64)m * P) >> 32);
-    return (u32)(t >> 32) - u + P;
+    const u32 m = (u32)t * NPINV;
+    return (u32)((t + (u64)m * P) >> 32);
 }
 __host__ __device__ __forceinline__ u32 mul_lazy(u32 a, u32 b) { return reduce_lazy((u64)a * b); }  // a * b < P * 2^32
 // SIGNED Montgomery product: a, b signed words with |a|, |b| <= 1.03 P -> a word r congruent to a b 2^-32 with |r| < 0.97 P + 1.
