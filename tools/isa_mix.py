@@ -4,7 +4,7 @@ per average VALU instruction the issue-cost model of DESIGN.md section 4 gives f
 
   python tools/isa_mix.py plonky2_goldibear_amd/csrc/kernels_merkle.hip _ZN3gbk18k_gl_merkle_leavesEPKymjyPy [-DFLAG ...]
 
-Classes (gfx950, tools/microbench_valu2.hip / microbench_mulmod.hip): v_mad_u64_u32 / v_mad_i64_i32 4.5 cycles per wave64
+Classes (gfx950, tools/microbench_valu2.hip / microbench_mulmod.hip): v_mad_u64_u32 / v_mad_i64_i32 / v_mul_lo / v_mul_hi 4.5 cycles per wave64
 instruction and SIMD; v_mov / v_add_u32 / v_xor / v_perm / v_lshl_add_u32 (plain 32-bit, no carry) 2.4; every carry, select,
 64-bit add, shift op 2.9; an MFMA holds the SIMD's vector issue for 8 cycles (MI355X_MICROARCH.md) and runs on the matrix pipe."""
 import json
@@ -16,7 +16,7 @@ import tempfile
 
 COST = {"mad": 4.5, "plain32": 2.4, "other": 2.9, "mfma": 8.0}
 PLAIN32 = ("v_mov_b32", "v_mov_b64", "v_add_u32", "v_sub_u32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_perm_b32", "v_lshl_add_u32",
-           "v_lshlrev_b32", "v_lshrrev_b32", "v_add3_u32", "v_lshl_or_b32", "v_or3_b32", "v_and_or_b32", "v_bfe_u32")
+           "v_lshlrev_b32", "v_lshrrev_b32", "v_add3_u32", "v_lshl_or_b32", "v_or3_b32", "v_and_or_b32", "v_bfe_u32", "v_min_u32", "v_max_u32")
 
 
 def kernel_mix(src, symbol, flags=()):
@@ -38,7 +38,7 @@ def kernel_mix(src, symbol, flags=()):
         op = t[0]
         if op.startswith("v_mfma"):
             mix["mfma"] += 1
-        elif op.startswith("v_mad_u64_u32") or op.startswith("v_mad_i64_i32"):
+        elif op.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32")):   # 32 x 32 multipliers
             mix["mad"] += 1
         elif any(op.startswith(p) for p in PLAIN32):
             mix["plain32"] += 1

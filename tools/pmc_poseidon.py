@@ -25,8 +25,9 @@ wave_cycles = float(row["SQ_WAVE_CYCLES"])
 # issue-cost floor: the kernel's instruction mix priced with the measured per-class issue costs, as a
 # fraction of the SIMD cycles the kernel had - 1.0 would mean the VALU port never waited
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sym = "_ZN3gbk18k_gl_merkle_leavesEPKymjyPy" if field == "goldilocks" else None
-mix = kernel_mix(os.path.join(root, "plonky2_goldibear_amd", "csrc", "kernels_merkle.hip"), sym) if sym else None
+sym = "_ZN3gbk18k_gl_merkle_leavesEPKymjyPy" if field == "goldilocks" else "_ZN3gbk18k_bb_merkle_leavesEPKjmjyPj"
+src = "kernels_merkle.hip" if field == "goldilocks" else "kernels_bb.hip"
+mix = kernel_mix(os.path.join(root, "plonky2_goldibear_amd", "csrc", src), sym)
 dur_s = float(row["TotalDurationNs(under PMC)"]) * 1e-9
 floor = None
 if mix:
