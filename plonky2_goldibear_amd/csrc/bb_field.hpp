@@ -53,17 +53,18 @@ __host__ __device__ __forceinline__ u32 reduce_lazy(u64 t) {
 }
 __host__ __device__ __forceinline__ u32 mul_lazy(u32 a, u32 b) { return reduce_lazy((u64)a * b); }  // a * b < P * 2^32
 // SIGNED Montgomery product: a, b signed words with |a|, |b| <= 1.03 P -> a word r congruent to a b 2^-32 with |r| < 0.97 P + 1.
-// t = a b exactly; m = lo(t) / P mod 2^32 taken as SIGNED makes t - m P a multiple of 2^32 of magnitude < P^2 + 2^31 P, so
-// r = hi(t) - hi(m P) needs no selection at all: three multiplies and one subtraction (the unsigned form above needs its + P,
-// the canonical one + P and a min).  Closed under itself: 0.97 P < 1.03 P.  `bias` (0 or P) is added for a consumer that wants a
-// non-negative word: r + P lies in (0, 2 P).
+// t = a b exactly; m = lo(t) / P mod 2^32 taken as SIGNED makes t - m P a multiple of 2^32 of magnitude < P^2 + 2^31 P, so its
+// high word needs no selection at all and the representation is closed under itself (0.97 P < 1.03 P): a product is two
+// multiplies and one multiply-add (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32), with nothing after them - the unsigned forms
+// above end in [0, 2P), which a second product with a lazy partner would overflow.  `bias` (0 or P) is added for a consumer that
+// wants a non-negative word: r + P lies in (0, 2 P).
 __host__ __device__ __forceinline__ int mul_signed(int a, int b, u32 bias = 0) {
     const long long t = (long long)a * b;
     const int m = (int)((u32)t * PINV);
     const long long d = t - (long long)m * (int)P;   // one v_mad_i64_i32 on the device: the low word comes out zero
     return (int)((u32)(d >> 32) + bias);
 }
-// the same reduction for an unsigned 64-bit sum t < 2^32 * 0.5 P: signed word in (-0.5 P, P)
+// the same reduction for a small unsigned 64-bit sum: hi(t) - P/2 < r <= hi(t) + P/2, i.e. within +-1.03 P for t < 2^38
 __host__ __device__ __forceinline__ int reduce_signed(u64 t) {
     const int m = (int)((u32)t * PINV);
     const long long d = (long long)t - (long long)m * (int)P;

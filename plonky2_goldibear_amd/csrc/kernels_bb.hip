@@ -209,10 +209,10 @@ __global__ __launch_bounds__(256) void k_bb_merkle_leaves(const u32* __restrict_
     for (u32 c0 = 0; c0 < width; c0 += 8) {  // one loop, one inlined copy of the permutation
         if (c0) {  // the capacity words go on at scale 1; the rate words are overwritten (partially in the last absorption)
 #pragma unroll
-            for (int i = 8; i < 16; i++) s[i] = poseidon2_bb::renorm(s[i]);
+            for (int i = 8; i < 16; i++) s[i] = poseidon2_bb::renorm_lazy(s[i]);
             if (c0 + 8 > width) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) s[i] = poseidon2_bb::renorm(s[i]);
+                for (int i = 0; i < 8; i++) s[i] = poseidon2_bb::renorm_lazy(s[i]);
             }
         }
         if (c0 + 8 <= width) {
@@ -253,10 +253,10 @@ __global__ __launch_bounds__(256, 7) void k_bb_merkle_leaves_seg(const u32* __re
     for (u32 c0 = c_begin; c0 < c_end; c0 += 8) {
         if (c0) {  // the capacity words go on at scale 1; the rate words are overwritten (partially in the last absorption)
 #pragma unroll
-            for (int i = 8; i < 16; i++) s[i] = poseidon2_bb::renorm(s[i]);
+            for (int i = 8; i < 16; i++) s[i] = poseidon2_bb::renorm_lazy(s[i]);
             if (LAST && c0 + 8 > c_end) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) s[i] = poseidon2_bb::renorm(s[i]);
+                for (int i = 0; i < 8; i++) s[i] = poseidon2_bb::renorm_lazy(s[i]);
             }
         }
         if (!LAST || c0 + 8 <= c_end) {

@@ -57,7 +57,7 @@ constexpr u32 R = (u32)(((u64)1 << 32) % bb::P);
 constexpr u32 RINV = cinv(R);
 struct Plan {
     u32 ext[8][16];  // Montgomery form of kappa * EXTERNAL_CONSTANTS[r], kappa = the scale when round r's constants are added
-    u32 in[13];      // Montgomery form of kappa * INTERNAL_CONSTANTS[r]
+    u32 in[14];      // Montgomery form of kappa * INTERNAL_CONSTANTS[r]; in[13] = ext4[0], what word 0 meets after the last internal round
     u32 sumc[13];    // internal round j: minus the sum of the offsets the lazy words 1..15 carry at that point (see internal_round)
     u32 ext4[16];    // round 4's constants (ext[4]) minus the offsets left by the thirteenth internal round
     u32 fix6;        // kappa^-6 (plain) during the internal rounds: mont(s-box output, fix6) = (word 0 at the common scale) * 2^-32
@@ -93,6 +93,7 @@ constexpr Plan make_plan() {
             for (int i = 0; i < 15; i++) e[i] = (u32)(((u64)cmul(cmul(e[i], (u32)(((u64)1 << SH[i]) % bb::P)), RINV) + (bb::P + 1) / 2) % bb::P);
         }
         p.ext4[0] = p.ext[4][0];
+        p.in[13] = p.ext[4][0];
         for (int i = 0; i < 15; i++) p.ext4[i + 1] = (u32)(((u64)p.ext[4][i + 1] + bb::P - e[i]) % bb::P);
     }
     for (int r = 4; r < 8; r++) {
@@ -173,16 +174,19 @@ __device__ __forceinline__ u64 mad_wide(u32 a, u32 b_uniform, u64 c) {
 static constexpr u32 HALF_P = (bb::P + 1) / 2;
 static constexpr u32 LAZY_MAX = 2 * bb::P + (1u << 15) + 1;   // full < p, + ceil(p/2), + hi(t) < 2^15, + p/2
 static_assert((u64)LAZY_MAX < ((u64)1 << 32), "lazy words must fit 32 bits");
-__device__ __forceinline__ void internal_round(u32 (&s)[16], u32 rc, u32 sumc) {
+// Word 0 comes in as the s-box INPUT of this round (constant added: a signed word within +-p) and leaves as the next round's:
+// (part + rc_next) - y0 is one canonical addition off the s-box's dependency chain and one subtraction, where part - y0 and
+// + rc_next took two canonical operations.
+__device__ __forceinline__ void internal_round(u32 (&s)[16], u32 rc_next, u32 sumc) {
     constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};  // gates/poseidon2_babybear.rs:41-42
     // part = sum_{i>=1} s_i 2^-32: the reduction is linear, so reduce the 36-bit sum once instead of 15 words
     u64 sum = (u64)s[1] + sumc;
 #pragma unroll
     for (int i = 2; i < 16; i++) sum = mad_wide(s[i], 1u, sum);
     const u32 part = bb::reduce(sum);
-    const u32 y0 = bb::mul(sbox7(bb::add(s[0], rc)), PLAN.fix6);
+    const u32 y0 = bb::mul(sbox7(s[0]), PLAN.fix6);
     const u32 full = bb::add(part, y0);
-    s[0] = bb::sub(part, y0);
+    s[0] = bb::add(part, rc_next) - y0;                           // in (-p, p) as a signed word
     const u64 base = (u64)(full + HALF_P) << 32;
 #pragma unroll
     for (int i = 0; i < 15; i++) {
@@ -206,10 +210,10 @@ __device__ __forceinline__ void permute_scaled(u32 (&s)[16]) {
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = sbox7(s[i]);
     external_layer(s, ZERO16);
-    for (int r = 0; r < 13; r++) internal_round(s, PLAN.in[r], PLAN.sumc[r]);
-    // round 4's constants, for the signed s-box: word 0 is canonical, the lazy words come below p + 2^15 with one selection, and
-    // adding (constant - p) leaves every word within (-p, p + 2^15)
-    s[0] += PLAN.ext4[0] - bb::P;
+    s[0] = bb::add(s[0], PLAN.in[0]);
+    for (int r = 0; r < 13; r++) internal_round(s, PLAN.in[r + 1], PLAN.sumc[r]);
+    // round 4's constants, for the signed s-box: word 0 has its own already (internal_round), the lazy words come below p + 2^15 with
+    // one selection, and adding (constant - p) leaves every word within (-p, p + 2^15)
 #pragma unroll
     for (int i = 1; i < 16; i++) {
         const u32 t = s[i] - bb::P;
@@ -225,6 +229,8 @@ __device__ __forceinline__ void permute_scaled(u32 (&s)[16]) {
     external_layer(s, ZERO16);
 }
 __device__ __forceinline__ u32 renorm(u32 x) { return bb::mul(x, PLAN.out); }
+// the same, LAZY (a word in [0, 2p)): enough for words that go straight into the next permutation, whose first layer sums lazy words
+__device__ __forceinline__ u32 renorm_lazy(u32 x) { return bb::mul_lazy(x, PLAN.out); }
 __device__ __forceinline__ u32 canonical_out(u32 x) { return bb::mul(x, PLAN.out_canon); }
 
 // state: Montgomery form in, Montgomery form out (scale 1 on both sides)
