@@ -33,6 +33,9 @@ constexpr u32 W16_INV = cpow(W16, 15);
 constexpr u32 mont(u32 x) { return (u32)(((u64)x << 32) % bb::P); }
 template <bool INV, int M>
 constexpr u32 tw() { return mont(cpow(INV ? W16_INV : W16, M)); }
+// the same twiddle as a signed word of magnitude <= p/2, for the signed Montgomery product (bb::mul_signed)
+template <bool INV, int M>
+constexpr int tw_centred() { return tw<INV, M>() > bb::P / 2 ? (int)tw<INV, M>() - (int)bb::P : (int)tw<INV, M>(); }
 static_assert(cpow(W16, 16) == 1 && cpow(W16, 8) == bb::P - 1, "W16 must be a primitive 16th root of unity");
 }  // namespace bbc
 
@@ -40,7 +43,12 @@ static_assert(cpow(W16, 16) == 1 && cpow(W16, 8) == bb::P - 1, "W16 must be a pr
 template <bool INV, int M>
 __device__ __forceinline__ u32 sub_twiddle(u32 a, u32 b) {
     if constexpr (M == 0) return bb::sub(a, b);
-    else return bb::mul(a - b + bb::P, bbc::tw<INV, M>());  // a - b + p in (0, 2p): the product takes it unreduced
+    else {   // a - b as a signed word in (-p, p) times a twiddle within +-p/2: the signed product lands within +-0.74 p and one
+             // selection makes it canonical - six instructions where a - b + p and the unsigned product took seven
+        const int r = bb::mul_signed((int)(a - b), bbc::tw_centred<INV, M>());
+        const u32 e = (u32)r + bb::P;
+        return e < (u32)r ? e : (u32)r;
+    }
 }
 
 template <bool INV, int H, int J>
