@@ -357,12 +357,6 @@ __device__ __forceinline__ long long mad_i64_start(int a, u64 c_uniform) {
     asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(c_uniform));
     return d;
 }
-// some register, no instruction: the fourth dword of an MFMA B operand whose k = 12..15 meet zeros in A
-__device__ __forceinline__ int any_vgpr() {
-    int x;
-    asm("" : "=v"(x));
-    return x;
-}
 // 4 x 4 byte transpose: t[p] = [w0.b_p, w1.b_p, w2.b_p, w3.b_p] (8 v_perm_b32)
 __device__ __forceinline__ void byte_transpose4(u32 w0, u32 w1, u32 w2, u32 w3, u32 (&t)[4]) {
     const u32 a_lo = __builtin_amdgcn_perm(w1, w0, 0x05010400u);  // [w0.b0, w1.b0, w0.b1, w1.b1]
@@ -417,7 +411,10 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
     const u64* ilo = MFMA_INIT.lo + 12 * rnext;   // uniform index: scalar loads
     const u64* ihi = MFMA_INIT.hi + 12 * rnext;
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int pad = any_vgpr();
+    const int pad = amat[3];   // the fourth dword of the B operands (k = 12..15, which meet zeros in A): a defined register that costs nothing -
+                               // A's own fourth dword, zero in every lane.  (An undefined register here computes the same numbers, but a
+                               // variant of the leaf kernel built around one hashed wrongly on part of the grid - round 3, profiles/
+                               // r03_poseidon_mfma_ablations.txt - and stopped doing so with a defined operand.)
 #ifdef GB_MFMA_DEPTH4   // ablation: four MFMAs in flight (64 result registers) instead of two
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
