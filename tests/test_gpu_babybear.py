@@ -59,6 +59,18 @@ def test_from_values_matches_oracle(ctx, log_n, ncols, rate_bits, cap_height):
     gpu.free()
 
 
+@pytest.mark.parametrize("ncols", [9, 10, 15, 16, 17, 23, 24, 25, 31])
+def test_lane_per_leaf_sponge_widths_on_a_grid_of_many_workgroups(ctx, ncols):
+    """The lane-per-leaf sponge kernels at every absorption shape (whole, ragged last) on 2^17 leaves = 512 workgroups, more than
+    one per CU (tests/test_gpu_parity.py has the Goldilocks twin and the reason)."""
+    vals = _cols(ncols, 14)
+    gpu = PolynomialBatch.from_values(ctx, vals, 3, 4, field=GB_BABYBEAR)
+    cpu = B.PolynomialBatch.from_values(vals, 3, 4)
+    assert (gpu.merkle_tree.cap == cpu.cap).all()
+    assert (gpu.merkle_tree.digests == cpu.digests).all()
+    gpu.free()
+
+
 def test_from_coeffs_salts_and_edges(ctx):
     coeffs = _cols(6, 10, seed=9)
     coeffs[0, :] = 0

@@ -89,6 +89,19 @@ def test_from_values_matches_oracle(ctx, log_n, ncols, rate_bits, cap_height):
     gpu.free()
 
 
+@pytest.mark.parametrize("ncols", [5, 6, 7, 8, 9, 12, 15, 16, 17, 23, 24, 25])
+def test_lane_per_leaf_sponge_widths_on_a_grid_of_many_workgroups(ctx, ncols):
+    """The lane-per-leaf sponge kernels (trees above 2^14 leaves) at every absorption shape - ragged first, whole, ragged last -
+    on 2^17 leaves = 512 workgroups, two per CU: a kernel variant of round 3 was right in the first workgroup of every CU and
+    wrong in the second (an undefined MFMA operand), and only three shapes of this file happened to see it."""
+    vals = _cols(ncols, 14)
+    gpu = PolynomialBatch.from_values(ctx, vals, 3, 4)
+    cpu = O.PolynomialBatch.from_values(vals, 3, 4)
+    assert (gpu.merkle_tree.cap == cpu.cap).all()
+    assert (gpu.merkle_tree.digests == cpu.digests).all()
+    gpu.free()
+
+
 @pytest.mark.parametrize("log_n,ncols", [(3, 2), (10, 30), (13, 4), (16, 2)])
 def test_from_coeffs_and_salts(ctx, log_n, ncols):
     coeffs = _cols(ncols, log_n, seed=77 + log_n)
