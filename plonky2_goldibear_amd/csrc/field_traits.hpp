@@ -73,6 +73,16 @@ struct GlF {
         return gl::mul(gl::mul(x, c_form), 0xFFFFFFFE00000001ULL);  // host: x (c R) R^-1; not on any hot path
 #endif
     }
+    // sum_t term_t * c_t with wave-uniform constants c_t in constant form (the quotient kernel's alpha fold): two sums side by
+    // side, because BabyBear's form pairs them (below); here simply add(acc, mulc(term, c))
+    typedef T Acc;
+    static GB_HD Acc acc_from(T x) { return x; }
+    static GB_HD void acc_mac2(Acc& a0, Acc& a1, T term, T c0, T c1) {
+        a0 = add(a0, mulc(term, c0));
+        a1 = add(a1, mulc(term, c1));
+    }
+    static GB_HD void acc_mac(Acc& a, T term, T c) { a = add(a, mulc(term, c)); }
+    static GB_HD T acc_finish(Acc a) { return a; }
     static GB_HD T inv(T a) { return gl::inv(a); }
     static GB_HD T pow(T a, u64 e) { return gl::pow(a, e); }
     static GB_HD T generator() { return gl::GENERATOR; }
@@ -113,6 +123,42 @@ struct BbF {
     static GB_HD T mulc(T x, T c_form) { return bb::mul(x, c_form); }
     static GB_HD T chain_one(u32) { return bb::R1; }
     static GB_HD T mul_chain(T acc, T f) { return bb::mul(acc, f); }
+    // sum_t term_t * c_t (term Montgomery form, c_t wave-uniform Montgomery constants) kept UNREDUCED as a 96-bit integer: a term
+    // costs one v_mad_u64_u32 and one add-with-carry per sum instead of a Montgomery product and a canonical addition (8
+    // instructions); one reduction per sum at the end.  Two sums at a time so that each carry-out has its own scalar register and
+    // an instruction between its write and its read (VALU-written carry -> v_addc needs two wait states on this chip).
+    struct Acc {
+        u64 lo;
+        u32 hi;
+    };
+    static GB_HD Acc acc_from(T x) { return Acc{(u64)x << 32, 0u}; }   // x 2^32: the final division by 2^32 returns x
+    static GB_HD void acc_mac2(Acc& a0, Acc& a1, T term, T c0, T c1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        u64 k0, k1;
+        asm("v_mad_u64_u32 %0, %4, %6, %7, %0\n\t"
+            "v_mad_u64_u32 %2, %5, %6, %8, %2\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\t"
+            "v_addc_co_u32_e64 %3, %5, 0, %3, %5"
+            : "+v"(a0.lo), "+v"(a0.hi), "+v"(a1.lo), "+v"(a1.hi), "=&s"(k0), "=&s"(k1)
+            : "v"(term), "s"(c0), "s"(c1));
+#else
+        acc_mac(a0, term, c0);
+        acc_mac(a1, term, c1);
+#endif
+    }
+    static GB_HD void acc_mac(Acc& a, T term, T c) {
+        const u64 p = (u64)term * c, s = a.lo + p;
+        a.hi += s < p;
+        a.lo = s;
+    }
+    // (hi 2^64 + lo) / 2^32 mod p = hi 2^32 + (lo >> 32) + mont_reduce(lo & 0xffffffff), every piece canonical
+    static GB_HD T acc_finish(Acc a) {
+        const T top = bb::mul(a.hi, bb::R2);                      // hi R^2 / R = hi 2^32 mod p   (hi < 2^31: a few hundred terms)
+        const T mid = bb::mul((u32)(a.lo >> 32), bb::R1);         // x R / R = x mod p for any 32-bit x (x R1 < p 2^32)
+        const T low = bb::reduce((u64)(u32)a.lo);
+        return bb::add(bb::add(top, mid), low);
+    }
     static GB_HD T inv(T a) { return bb::inv(a); }
     static GB_HD T pow(T a, u64 e) { return bb::pow(a, e); }
     static GB_HD T generator() { return bb::to_mont(bb::GENERATOR); }

@@ -199,9 +199,15 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
     const T* pi_hash = zh_inv + R;
     const T* apow = pi_hash + F::H;                           // [c][nterms] alpha powers in constant form (F::mulc)
 
-    T acc[C];
+    // the alpha fold: acc[k2] = sum over the constraint terms of term_t alpha_k2^t, as F::Acc sums (BabyBear keeps them unreduced)
+    typename F::Acc acc[C];
 #pragma unroll
-    for (u32 k = 0; k < C; k++) acc[k] = p.ext_gates ? qv[(((size_t)k << r) + cidx) * n + il] : F::zero();
+    for (u32 k = 0; k < C; k++) acc[k] = F::acc_from(p.ext_gates ? qv[(((size_t)k << r) + cidx) * n + il] : F::zero());
+    auto fold = [&](T term, u32 tt) {
+#pragma unroll
+        for (u32 k2 = 0; k2 + 1 < C; k2 += 2) F::acc_mac2(acc[k2], acc[k2 + 1], term, apow[k2 * nterms + tt], apow[(k2 + 1) * nterms + tt]);
+        if (C & 1) F::acc_mac(acc[C - 1], term, apow[(C - 1) * nterms + tt]);
+    };
     u32 t = 0;
     // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61); L_0 on the LDE domain is a per-circuit table (k_l0_table)
     const T l0 = p.l0[j];
@@ -210,9 +216,7 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
     for (u32 k = 0; k < C; k++) zk[k] = zs[(size_t)k * N + j];
 #pragma unroll
     for (u32 k = 0; k < C; k++, t++) {
-        T term = F::mul(l0, F::sub(zk[k], F::one()));
-#pragma unroll
-        for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mulc(term, apow[k2 * nterms + t]));
+        fold(F::mul(l0, F::sub(zk[k], F::one())), t);
     }
     // partial-product checks (util/partial_products.rs:53-77); term index = C + k * nchunks + m
     const u32 num_prods = p.nchunks - 1;
@@ -265,9 +269,7 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
 #pragma unroll
         for (u32 k = 0; k < C; k++) {
             const T term = F::sub(F::mul(prev[k], np[k]), F::mul(next[k], dp[k]));
-            const u32 tt = C + k * p.nchunks + m;
-#pragma unroll
-            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mulc(term, apow[k2 * nterms + tt]));
+            fold(term, C + k * p.nchunks + m);
             prev[k] = next[k];
         }
     }
@@ -296,12 +298,11 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
                 const T kc = cs[(size_t)(p.num_selectors + cj) * N + j];
                 term = F::add(term, F::mul(f_c, F::sub(kc, wv)));
             }
-#pragma unroll
-            for (u32 k2 = 0; k2 < C; k2++) acc[k2] = F::add(acc[k2], F::mulc(term, apow[k2 * nterms + t]));
+            fold(term, t);
         }
     }
 #pragma unroll
-    for (u32 k = 0; k < C; k++) qv[(((size_t)k << r) + cidx) * n + il] = F::mul(acc[k], zh_inv[imod]);
+    for (u32 k = 0; k < C; k++) qv[(((size_t)k << r) + cidx) * n + il] = F::mul(F::acc_finish(acc[k]), zh_inv[imod]);
 }
 
 // l0[j] = L_0(x_j) = Z_H(x_j) / (n (x_j - 1)) for every LDE point in leaf order (once per circuit: the quotient kernel
