@@ -36,15 +36,27 @@ __device__ __forceinline__ typename F::E pow_split(const ExtPowTab<F>& t, u64 e)
 
 // ------------------------------------------------------------------ Z and partial products
 
-// grid (ceil(n/256), c). q[ch][m][row] = prod_{j in chunk m} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)
+// grid ceil(n/256) * c workgroups (mapping below). q[ch][m][row] = prod_{j in chunk m} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)
 template <class F>
 __global__ __launch_bounds__(256) void k_zs_quotients(ZsParams<F> p, const typename F::T* __restrict__ witness,
                                                       const typename F::T* __restrict__ sigma, const typename F::T* __restrict__ k_is,
                                                       const typename F::T* __restrict__ betas, const typename F::T* __restrict__ gammas,
                                                       typename F::T* __restrict__ q, u32* __restrict__ err) {
     typedef typename F::T T;
-    const u32 row = blockIdx.x * 256 + threadIdx.x;
-    const u32 ch = blockIdx.y;
+    // 1-D grid of nblk * num_challenges workgroups.  The challenges of one block of 256 rows read the same witness and sigma
+    // values: they are given linear ids 8 apart - the same XCD, dispatched back to back - so that all but the first find them in
+    // that XCD's L2 instead of HBM (a (rows, challenge) grid re-read 1.3 GB per challenge at 2^20 rows).
+    const u32 nb = (u32)((((size_t)1 << p.log_n) + 255) >> 8), L = blockIdx.x;
+    u32 rb, ch;
+    if ((nb & 7) == 0) {
+        const u32 group = L / (8 * p.num_challenges), in = L % (8 * p.num_challenges);
+        rb = group * 8 + (in & 7);
+        ch = in >> 3;
+    } else {
+        rb = L % nb;
+        ch = L / nb;
+    }
+    const u32 row = rb * 256 + threadIdx.x;
     const size_t n = (size_t)1 << p.log_n;
     if (row >= n) return;
     const T beta = betas[ch], gamma = gammas[ch];
@@ -645,7 +657,7 @@ void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, con
                          typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st) {
     const size_t n = (size_t)1 << p.log_n;
     const u32 nb1024 = nblk(n, 1024);
-    hipLaunchKernelGGL(k_zs_quotients<F>, dim3(nblk(n, 256), p.num_challenges), dim3(256), 0, st, p, witness, sigma, k_is, betas,
+    hipLaunchKernelGGL(k_zs_quotients<F>, dim3(nblk(n, 256) * p.num_challenges), dim3(256), 0, st, p, witness, sigma, k_is, betas,
                        gammas, q_tmp, err);
     hipLaunchKernelGGL(k_zs_scan_local<F>, dim3(nb1024, p.num_challenges), dim3(256), 0, st, p, q_tmp, zloc_tmp, totals_tmp);
     hipLaunchKernelGGL(k_zs_scan_totals<F>, dim3(p.num_challenges), dim3(1024), 0, st, totals_tmp, nb1024);
