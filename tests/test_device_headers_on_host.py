@@ -18,3 +18,17 @@ def test_poseidon2_bb_lane_permutation_matches_host_mirror(tmp_path):
     out = subprocess.run([str(exe), "200000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
+
+
+def test_bb_wide_accumulators_match_montgomery_sums(tmp_path):
+    exe = tmp_path / "bb_wide_acc"
+    shim = os.path.join(ROOT, "tests", "host_shim")
+    clang = "/opt/rocm/lib/llvm/bin/clang++"   # field_traits.hpp pulls in gl_field.hpp, whose limb code uses clang's __builtin_addc
+    if not os.path.exists(clang):
+        pytest.skip("needs the ROCm clang++ as the host compiler")
+    cmd = [clang, "-O2", "-std=c++17", "-include", os.path.join(shim, "shim.h"), "-I", shim,
+           "-I", os.path.join(ROOT, "plonky2_goldibear_amd", "csrc"), "-o", str(exe), os.path.join(shim, "bb_wide_acc.cpp")]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe), "3000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
