@@ -13,7 +13,7 @@ for v in "$@"; do
 import csv
 for r in csv.DictReader(open("gpurun_out/ab/$v.csv")):
     n = r["Name"].split("(")[0].replace("void ", "")
-    if any(k in n for k in ("lde_p", "intt", "merkle_leaves", "merkle_level", "quotient")):
+    if any(k in n for k in ("lde_p", "intt", "merkle_leaves", "merkle_level", "quotient", "eval_partial")):
         print("%-40s calls %4s avg %10.1f us" % (n[:40], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
