@@ -342,6 +342,21 @@ constexpr MfmaInitTable mfma_init_table() {
 }  // namespace raw
 __device__ static const raw::MfmaInitTable MFMA_INIT = raw::mfma_init_table();
 
+// The compiler pads MFMA -> VALU hazards with s_nop (gfx950 has no interlock: a read of a tile register is stale for 11 wait
+// states after the MFMA, a write to one is overwritten by the pipe's write-back for 8; tools/microbench_mfma_hazard.hip), but its
+// hazard recognizer does not look inside INLINE ASM - and the recombination below is made of asm v_mad_i64_i32.  Their sources
+// are never tile registers (a plain v_lshl_add_u32 reads the tile first and is padded), but their DESTINATIONS are whatever the
+// allocator finds free, and the registers of a tile that the kernel never reads (d[12..15] of a layer, most of a phase-A tile)
+// are free the moment the MFMA has issued: a result parked there is overwritten when the pipe writes the tile back.  That is
+// what round 3's "undefined operand" variant did (tools/mfma_guard.py shows twelve such writes in it, 1-5 wait states after the
+// MFMA) and what the first grouped kernels did.  GB_KEEP_TILES(d0, d1, after) keeps all sixteen registers of both tiles allocated
+// until `after` - a value computed from a padded read of the tiles - exists (without that operand the scheduler hoists the
+// statement to the MFMA itself), and tests/test_mfma_guard.py checks the assembly of every kernel for the pattern.
+#ifdef GB_EXP_NO_KEEP_TILES   // the negative case of tests/test_mfma_guard.py
+#define GB_KEEP_TILES(d0, d1, after)
+#else
+#define GB_KEEP_TILES(d0, d1, after) asm volatile("" ::"v"(d0), "v"(d1), "v"(after))
+#endif
 // a * b + c, signed 32 x 32 + 64, as ONE v_mad_i64_i32 (the compiler expands the C expression to sign-extend + shift + add)
 __device__ __forceinline__ long long mad_i64(int a, int b, long long c) {
     long long d;
@@ -411,10 +426,7 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
     const u64* ilo = MFMA_INIT.lo + 12 * rnext;   // uniform index: scalar loads
     const u64* ihi = MFMA_INIT.hi + 12 * rnext;
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int pad = amat[3];   // the fourth dword of the B operands (k = 12..15, which meet zeros in A): a defined register that costs nothing -
-                               // A's own fourth dword, zero in every lane.  (An undefined register here computes the same numbers, but a
-                               // variant of the leaf kernel built around one hashed wrongly on part of the grid - round 3, profiles/
-                               // r03_poseidon_mfma_ablations.txt - and stopped doing so with a defined operand.)
+    const int pad = amat[3];   // the fourth dword of the B operands (k = 12..15, which meet zeros in A): A's own fourth dword, zero in every lane
 #ifdef GB_MFMA_DEPTH4   // ablation: four MFMAs in flight (64 result registers) instead of two
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
@@ -432,6 +444,7 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
             if (hh == 0) lo[q] = mad_i64(t23, 65536, mad_i64_start(t01, ilo[q]));
             else hi[q] = mad_i64(t23, 65536, mad_i64_start(t01, ihi[q]));
         }
+        GB_KEEP_TILES(d[0], d[1], hh == 0 ? lo[11] : hi[11]); GB_KEEP_TILES(d[2], d[3], hh == 0 ? lo[11] : hi[11]);
     }
 #else
 #pragma unroll
@@ -449,6 +462,7 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
             else if (pp == 2) hi[q] = mad_i64_start(t, ihi[q]);
             else hi[q] = mad_i64(t, 65536, hi[q]);
         }
+        GB_KEEP_TILES(d0, d1, pp < 2 ? lo[11] : hi[11]);
     }
 #endif
     // fold_halves with its carry fix on a rare path: value = lo + 2^32 hi = (lo + (hi >> 32) EPS) + 2^32 (u32)hi, and the last

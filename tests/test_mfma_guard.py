@@ -1,0 +1,61 @@
+"""Static check of the compiled kernels for the matrix-pipe hazards gfx950 leaves to software (tools/mfma_guard.py).
+
+Root cause of round 3's "undefined MFMA operand" incident and of round 4's first grouped Poseidon kernels: the compiler's hazard
+recognizer pads VALU reads / writes of an in-flight MFMA destination tile with s_nop, but not those made by INLINE ASM - and the
+byte-plane recombination is asm v_mad_i64_i32 whose results the allocator may park in tile registers the kernel never reads.
+The product keeps every tile allocated until it has been read (GB_KEEP_TILES); this test looks at the assembly."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import mfma_guard  # noqa: E402
+
+CSRC = os.path.join(ROOT, "plonky2_goldibear_amd", "csrc")
+MICROBENCH = os.path.join(ROOT, "tools", "microbench_poseidon_groups.hip")
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (cross-compiles without a GPU)")
+
+
+def findings(src, flags=()):
+    n, out = mfma_guard.check_text(mfma_guard.compile_to_asm(src, list(flags)))
+    assert n > 0, "no kernel with MFMAs found in " + src
+    return out
+
+
+def test_guard_flags_a_build_without_the_tile_guard():
+    # three groups of three rounds + singles without GB_KEEP_TILES: the build that hashed wrongly on the GPU (profiles/r04_mfma_hazard.txt)
+    bad = findings(MICROBENCH, ["-DGB_POSEIDON_GROUP=3", "-DGB_POSEIDON_GROUP_COUNT=6", "-DGB_POSEIDON_GROUP2=0", "-DGB_EXP_NO_KEEP_TILES"])
+    assert any(kind == "WAW" for kind, *_ in bad), bad
+    good = findings(MICROBENCH, ["-DGB_POSEIDON_GROUP=3", "-DGB_POSEIDON_GROUP_COUNT=6", "-DGB_POSEIDON_GROUP2=0"])
+    assert good == []
+
+
+@pytest.mark.parametrize("flags", [(), ("-DGB_POSEIDON_OCC=3",), ("-DGB_POSEIDON_OCC=5",), ("-DGB_MFMA_DEPTH4",), ("-DGB_POSEIDON_GROUP=2",), ("-DGB_POSEIDON_GROUP=3",)])
+def test_merkle_kernels_are_clean(flags):
+    assert findings(os.path.join(CSRC, "kernels_merkle.hip"), flags) == []
+
+
+def test_prover_kernels_are_clean():
+    assert findings(os.path.join(CSRC, "kernels_prover.hip")) == []
+
+
+def test_guard_reads_registers_and_wait_states():
+    text = """
+k:
+	v_mfma_i32_32x32x32_i8 v[0:15], v[20:23], v[24:27], 0
+	s_nop 9
+	v_add_u32_e32 v40, v3, v41
+	v_mfma_i32_32x32x32_i8 v[0:15], v[20:23], v[24:27], v[0:15]
+	v_mov_b32_e32 v14, v41
+	s_nop 11
+	v_add_u32_e32 v40, v15, v41
+	v_mfma_i32_32x32x32_i8 v[16:31], v[20:23], v[60:63], 0
+	s_endpgm
+"""
+    n, out = mfma_guard.check_text(text)
+    kinds = sorted(f[0] for f in out)
+    assert n == 1 and kinds == ["RAW", "WAW", "undefined"], out
+    raw = [f for f in out if f[0] == "RAW"][0]
+    assert raw[3] == 10   # s_nop 9 = ten wait states: two short of what a read needs
