@@ -109,14 +109,27 @@ __device__ __forceinline__ u64 fold160(u32 r0, u32 r1, u32 hl, u32 hh, u32 r4) {
     u32 f1 = d1 + ch + k2;
     return (u64)f0 | ((u64)f1 << 32);
 }
-// a * b as four 32-bit limbs: four v_mad_u64_u32 for the partial products and a fifth as an ADDER - the second carry word
-// enters the top product as x * 1 + acc, one instruction on registers that are already in place, where a 64-bit add of two
-// zero-extended halves costs a v_lshl_add_u64 plus two v_mov to build its operand pairs (gfx950 issue costs, measured:
-// v_mad_u64_u32 4.5 cycles per wave, carry / select / 64-bit-add ops ~2.9 in a mixed stream, v_mov 2.4; tools/microbench_*.hip).
+// a * b as four 32-bit limbs (gfx950 issue costs, measured: v_mad_u64_u32 4.5 cycles per wave, carry / select / 64-bit-add ops
+// ~2.9 in a mixed stream, v_mov 2.4; tools/microbench_*.hip).  Rounds 2-3 (GB_MUL_FIVE_MADS): four v_mad_u64_u32 for the partial
+// products and a fifth as an ADDER - the second carry word enters the top product as x * 1 + acc.
 __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& hl, u32& hh) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GB_MUL_FIVE_MADS)
+    // Round 4: FOUR multiply-adds.  The second cross product takes the whole of p01 as its addend - a 64-bit register pair that
+    // is already in place, where the five-mad form splits p01 into two zero-extended halves (a v_mov each) - and the one carry
+    // that 64-bit sum can produce (weight 2^96) comes out in the mad's scalar carry operand and enters the top limb through a
+    // v_addc: 4 mads + 3 plain instead of 5 + 3 (v_mad_u64_u32 issues at 4.5 cycles per wave, the others at 2.4-2.9).
+    u64 m2, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(carry) : "v"(a1), "v"(b0), "v"(p01));   // a1 b0 + p01 = m2 + 2^64 [carry]
+    u64 p11 = (u64)a1 * b1 + (m2 >> 32);   // < 2^64 - 2^32: the carry still fits
+    u32 top, carry_unused_lo;
+    u64 carry_unused;
+    asm("v_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(top), "=s"(carry_unused) : "v"((u32)(p11 >> 32)), "s"(carry));
+    (void)carry_unused_lo;
+    r0 = (u32)p00; r1 = (u32)m2; hl = (u32)p11; hh = top;
+#else
     u64 p10 = (u64)a1 * b0 + (u32)p01;
     u64 p11 = (u64)a1 * b1 + (p01 >> 32);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -126,6 +139,7 @@ __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& h
     p11 += p10 >> 32;
 #endif
     r0 = (u32)p00; r1 = (u32)p10; hl = (u32)p11; hh = (u32)(p11 >> 32);
+#endif
 }
 // (x0 + 2^32 x1 + 2^64 x2 + 2^96 x3) / 2^64 mod p as SOME u64 congruent to it: Montgomery reduction with R = 2^64, for which
 // p = 2^64 - 2^32 + 1 needs no multiplication (-1/p = -(1 + 2^32) mod 2^64):  a = lo + (lo << 32), b = a - (a >> 32) - carry,

@@ -6,7 +6,7 @@
 // Digests are kept LEVEL-MAJOR on the device: level 0 = leaf digests, level k = N >> k nodes,
 // 4 x u64 per digest.  The reference's interleaved layout is produced on request only.
 #include "kernels.hpp"
-#include "poseidon_gl.hpp"
+#include "poseidon_gl_grouped.hpp"
 #include "poseidon_gl_coop.hpp"
 
 namespace gbk {
@@ -21,13 +21,23 @@ using poseidon_gl::to_mont;
 #ifndef GB_POSEIDON_OCC
 #define GB_POSEIDON_OCC 4
 #endif
-// All 30 MDS layers on the matrix pipe, the partial rounds in the reference's naive form (permute_mont_mfma_naive): 54.3 ms for the
-// 2^23 leaves x 17 permutations of a wires commitment, against 57.2 ms with only the seven full-round layers there and the partial
-// rounds in the fast sparse form (GB_POSEIDON_HYBRID, kept for the ablation) and 60.4 ms all-VALU (round 2).
-#ifdef GB_POSEIDON_HYBRID
-#define permute_mont_mfma poseidon_gl::permute_mont_mfma
+// Round 4: the 22 partial rounds run in GROUPS (poseidon_gl_grouped.hpp; GB_POSEIDON_GROUP rounds per group, default 4): one cut
+// into byte planes and one recombination per group instead of per round, the group's matrix M^G cut into G byte planes on the
+// matrix pipe, the words the group's later s-boxes see as VALU dot products - 11.3 k VALU instructions per permutation where the
+// form with 30 single layers (GB_POSEIDON_SINGLE_LAYERS: round 3's permute_mont_mfma_naive, kept for the ablation) takes 14.0 k.
+// The group operands live in LDS: every kernel fills its workgroup's table first (GB_POSEIDON_OPS, one barrier).
+#if defined(GB_POSEIDON_HYBRID)
+#define GB_POSEIDON_OPS() const poseidon_gl::v4i* gops = nullptr
+#define permute_mont_mfma(s, amat) poseidon_gl::permute_mont_mfma(s, amat)
+#elif defined(GB_POSEIDON_SINGLE_LAYERS)
+#define GB_POSEIDON_OPS() const poseidon_gl::v4i* gops = nullptr
+#define permute_mont_mfma(s, amat) poseidon_gl::permute_mont_mfma_naive(s, amat)
 #else
-#define permute_mont_mfma poseidon_gl::permute_mont_mfma_naive
+#define GB_POSEIDON_OPS()                                            \
+    __shared__ poseidon_gl::v4i gops_lds[poseidon_gl::GROUP_LDS_V4]; \
+    poseidon_gl::group_ops_init(gops_lds);                           \
+    const poseidon_gl::v4i* gops = gops_lds + (threadIdx.x & 63)
+#define permute_mont_mfma(s, amat) poseidon_gl::permute_mont_mfma_grouped(s, amat, gops)
 #endif
 // The sponge state of these kernels is kept in the permutation's Montgomery form (poseidon_gl.hpp): absorbed words go through
 // to_mont, the digest through from_mont (canonical); the capacity words never leave that form between absorptions.
@@ -38,7 +48,8 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const
     const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = j0 < num_leaves;
     const u64 j = live ? j0 : num_leaves - 1;
-    const poseidon_gl::v4i amat = mds_mfma_matrix();
+    const poseidon_gl::MdsOperand amat = mds_mfma_matrix();
+    GB_POSEIDON_OPS();
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -78,7 +89,8 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(c
     const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = j0 < num_leaves;
     const u64 j = live ? j0 : num_leaves - 1;
-    const poseidon_gl::v4i amat = mds_mfma_matrix();
+    const poseidon_gl::MdsOperand amat = mds_mfma_matrix();
+    GB_POSEIDON_OPS();
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = 0;
@@ -123,7 +135,8 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_level(const 
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < num_out;
     const u64 i = live ? i0 : num_out - 1;
-    const poseidon_gl::v4i amat = mds_mfma_matrix();
+    const poseidon_gl::MdsOperand amat = mds_mfma_matrix();
+    GB_POSEIDON_OPS();
     const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
     ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
     u64 s[12] = {to_mont(a.x), to_mont(a.y), to_mont(b.x), to_mont(b.y), to_mont(c.x), to_mont(c.y), to_mont(d.x), to_mont(d.y),
@@ -243,7 +256,8 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_poseidon_permute(co
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;
-    const poseidon_gl::v4i amat = mds_mfma_matrix();
+    const poseidon_gl::MdsOperand amat = mds_mfma_matrix();
+    GB_POSEIDON_OPS();
     u64 s[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) s[e] = to_mont(in[12 * i + e]);

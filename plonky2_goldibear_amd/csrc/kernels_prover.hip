@@ -508,7 +508,7 @@ struct Sponge;
 template <>
 struct Sponge<GlF> {
     u64 s[12];
-    poseidon_gl::v4i amat;
+    poseidon_gl::MdsOperand amat;
     __device__ __forceinline__ void init() {
         amat = poseidon_gl::mds_mfma_matrix();
 #pragma unroll

@@ -352,26 +352,39 @@ __device__ static const raw::MfmaInitTable MFMA_INIT = raw::mfma_init_table();
 // MFMA) and what the first grouped kernels did.  GB_KEEP_TILES(d0, d1, after) keeps all sixteen registers of both tiles allocated
 // until `after` - a value computed from a padded read of the tiles - exists (without that operand the scheduler hoists the
 // statement to the MFMA itself), and tests/test_mfma_guard.py checks the assembly of every kernel for the pattern.
-#ifdef GB_EXP_NO_KEEP_TILES   // the negative case of tests/test_mfma_guard.py
+#if defined(GB_EXP_NO_KEEP_TILES) || !defined(GB_MAD_ASM)   // (GB_EXP_NO_KEEP_TILES + GB_MAD_ASM: the negative case of tests/test_mfma_guard.py)
 #define GB_KEEP_TILES(d0, d1, after)
 #else
 #define GB_KEEP_TILES(d0, d1, after) asm volatile("" ::"v"(d0), "v"(d1), "v"(after))
 #endif
-// a * b + c, signed 32 x 32 + 64, as ONE v_mad_i64_i32 (the compiler expands the C expression to sign-extend + shift + add)
-__device__ __forceinline__ long long mad_i64(int a, int b, long long c) {
+// a * b + c, signed 32 x 32 + 64, as ONE v_mad_i64_i32.  Written in C so that the hazard recognizer sees the instruction; the
+// multipliers 1 and 2^16 are OPAQUE register constants (MdsOperand::one / ::k16: a volatile asm v_mov at the top of the kernel,
+// before any MFMA exists, that the optimizer cannot look into), or the compiler turns the products into sign-extend + shift + add.
+// With `one` in a VGPR the start value stays the instruction's one scalar source: v_mad_i64_i32 d, t, v_one, s[c:c+1].
+struct MdsOperand {
+    v4i a;          // this lane's share of the constant A operand (mds_mfma_matrix)
+    int one, k16;   // 1 and 65536
+};
+#ifdef GB_MAD_ASM   // round 3's form (inline asm, invisible to the hazard recognizer: needs GB_KEEP_TILES)
+__device__ __forceinline__ long long mad_i64(int a, const MdsOperand& m, long long c) {
     long long d;
     u64 carry_unused;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(b), "v"(c));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(65536), "v"(c));
     return d;
 }
-// a + c with c a UNIFORM 64-bit value: the accumulator's start value goes in as the scalar operand of the first mad (multiplier
-// 1 is an inline constant, so the one scalar source VOP3 allows on gfx950 is free for it) instead of through two v_mov
-__device__ __forceinline__ long long mad_i64_start(int a, u64 c_uniform) {
+__device__ __forceinline__ long long mad_i64_start(int a, const MdsOperand& m, u64 c_uniform) {
     long long d;
     u64 carry_unused;
     asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(c_uniform));
     return d;
 }
+#else
+__device__ __forceinline__ long long mad_i64(int a, const MdsOperand& m, long long c) { return (long long)a * (long long)m.k16 + c; }
+// a + c with c a UNIFORM 64-bit value: the accumulator's start value is the addend of a multiplication by the opaque 1
+__device__ __forceinline__ long long mad_i64_start(int a, const MdsOperand& m, u64 c_uniform) {
+    return (long long)a * (long long)m.one + (long long)c_uniform;
+}
+#endif
 // 4 x 4 byte transpose: t[p] = [w0.b_p, w1.b_p, w2.b_p, w3.b_p] (8 v_perm_b32)
 __device__ __forceinline__ void byte_transpose4(u32 w0, u32 w1, u32 w2, u32 w3, u32 (&t)[4]) {
     const u32 a_lo = __builtin_amdgcn_perm(w1, w0, 0x05010400u);  // [w0.b0, w1.b0, w0.b1, w1.b1]
@@ -384,7 +397,7 @@ __device__ __forceinline__ void byte_transpose4(u32 w0, u32 w1, u32 w2, u32 w3, 
     t[3] = __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
 }
 // This lane's share of the constant A operand (see above); call with all 64 lanes of the wave active, blockDim.x a multiple of 64.
-__device__ __forceinline__ v4i mds_mfma_matrix() {
+__device__ __forceinline__ MdsOperand mds_mfma_matrix() {
     const u32 l = threadIdx.x & 63, r = l & 31, h = l >> 5;
     const u32 hp = (r >> 2) & 1, q = (r & 3) + 4 * (r >> 3);
     v4i a = {0, 0, 0, 0};
@@ -402,10 +415,13 @@ __device__ __forceinline__ v4i mds_mfma_matrix() {
             a[g] = (int)v;
         }
     }
-    return a;
+    MdsOperand m;
+    m.a = a;
+    asm volatile("v_mov_b32 %0, 1\n\tv_mov_b32 %1, 0x10000" : "=v"(m.one), "=v"(m.k16));
+    return m;
 }
 // s <- MDS s + constants of round `rnext` (MFMA_NO_RC: none); every lane of the wave must execute this (MFMA), whatever its data.
-__device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int rnext) {
+__device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& amat, int rnext) {
     u32 w[24];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -426,7 +442,7 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
     const u64* ilo = MFMA_INIT.lo + 12 * rnext;   // uniform index: scalar loads
     const u64* ihi = MFMA_INIT.hi + 12 * rnext;
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int pad = amat[3];   // the fourth dword of the B operands (k = 12..15, which meet zeros in A): A's own fourth dword, zero in every lane
+    const int pad = amat.a[3];   // the fourth dword of the B operands (k = 12..15, which meet zeros in A): A's own fourth dword, zero in every lane
 #ifdef GB_MFMA_DEPTH4   // ablation: four MFMAs in flight (64 result registers) instead of two
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
@@ -435,14 +451,14 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
         for (int p = 0; p < 4; p++) {
             v4i b;
             b[0] = (int)pl[4 * hh + p][0]; b[1] = (int)pl[4 * hh + p][1]; b[2] = (int)pl[4 * hh + p][2]; b[3] = pad;
-            d[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat, b, zero, 0, 0, 0);
+            d[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat.a, b, zero, 0, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 12; q++) {
             const int t01 = (int)(((u32)d[1][q] << 8) + (u32)d[0][q]);
             const int t23 = (int)(((u32)d[3][q] << 8) + (u32)d[2][q]);
-            if (hh == 0) lo[q] = mad_i64(t23, 65536, mad_i64_start(t01, ilo[q]));
-            else hi[q] = mad_i64(t23, 65536, mad_i64_start(t01, ihi[q]));
+            if (hh == 0) lo[q] = mad_i64(t23, amat, mad_i64_start(t01, amat, ilo[q]));
+            else hi[q] = mad_i64(t23, amat, mad_i64_start(t01, amat, ihi[q]));
         }
         GB_KEEP_TILES(d[0], d[1], hh == 0 ? lo[11] : hi[11]); GB_KEEP_TILES(d[2], d[3], hh == 0 ? lo[11] : hi[11]);
     }
@@ -452,15 +468,15 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const v4i amat, int
         v4i b0, b1;
         b0[0] = (int)pl[2 * pp][0]; b0[1] = (int)pl[2 * pp][1]; b0[2] = (int)pl[2 * pp][2]; b0[3] = pad;
         b1[0] = (int)pl[2 * pp + 1][0]; b1[1] = (int)pl[2 * pp + 1][1]; b1[2] = (int)pl[2 * pp + 1][2]; b1[3] = pad;
-        const v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat, b0, zero, 0, 0, 0);
-        const v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat, b1, zero, 0, 0, 0);
+        const v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat.a, b0, zero, 0, 0, 0);
+        const v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat.a, b1, zero, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 12; q++) {
             const int t = (int)(((u32)d1[q] << 8) + (u32)d0[q]);
-            if (pp == 0) lo[q] = mad_i64_start(t, ilo[q]);
-            else if (pp == 1) lo[q] = mad_i64(t, 65536, lo[q]);
-            else if (pp == 2) hi[q] = mad_i64_start(t, ihi[q]);
-            else hi[q] = mad_i64(t, 65536, hi[q]);
+            if (pp == 0) lo[q] = mad_i64_start(t, amat, ilo[q]);
+            else if (pp == 1) lo[q] = mad_i64(t, amat, lo[q]);
+            else if (pp == 2) hi[q] = mad_i64_start(t, amat, ihi[q]);
+            else hi[q] = mad_i64(t, amat, hi[q]);
         }
         GB_KEEP_TILES(d0, d1, pp < 2 ? lo[11] : hi[11]);
     }
@@ -590,7 +606,7 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
 // permute_mont with the seven plain MDS layers of the full rounds on the matrix pipe (the fourth round's layer stays inside the
 // merged 12 x 11 dot-product layer of first_half, the partial rounds in their fast form).  `amat` = mds_mfma_matrix(); all 64
 // lanes of the wave must be here together.  Same function, same lazy Montgomery-form conventions as permute_mont.
-__device__ __forceinline__ void permute_mont_mfma(u64 (&s)[12], const v4i amat) {
+__device__ __forceinline__ void permute_mont_mfma(u64 (&s)[12], const MdsOperand& amat) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
     for (int k = 0; k < HALF_FULL - 1; k++) {
@@ -613,7 +629,7 @@ __device__ __forceinline__ void permute_mont_mfma(u64 (&s)[12], const v4i amat) 
 // words in the full rounds, word 0 in the partial ones - then the full MDS; output-identical to the fast form, :1196-1198) with
 // every one of the 30 MDS layers on the matrix pipe: a partial round is then one s-box + one mds_layer_mfma (~310 VALU
 // instructions) where the fast form's sparse-matrix round is ~380 with 64-bit constants.
-__device__ __forceinline__ void permute_mont_mfma_naive(u64 (&s)[12], const v4i amat) {
+__device__ __forceinline__ void permute_mont_mfma_naive(u64 (&s)[12], const MdsOperand& amat) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
     for (int r = 0; r < 2 * HALF_FULL + N_PARTIAL; r++) {

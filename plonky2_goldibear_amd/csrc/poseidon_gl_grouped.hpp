@@ -30,10 +30,21 @@ namespace grp = poseidon_gl_groups;
 #ifndef GB_POSEIDON_GROUP2
 #define GB_POSEIDON_GROUP2 ((22 - GB_POSEIDON_GROUP * GB_POSEIDON_GROUP_COUNT) >= 2 ? (22 - GB_POSEIDON_GROUP * GB_POSEIDON_GROUP_COUNT) : 0)
 #endif
+#ifndef GB_POSEIDON_PHASE_A_MFMA
+#define GB_POSEIDON_PHASE_A_MFMA 0   // 1: the words the later s-boxes see come from MFMAs too (phase A operands), 0: from VALU dot products
+#endif
 static constexpr int GROUP_G = GB_POSEIDON_GROUP, GROUP_N = GB_POSEIDON_GROUP_COUNT, GROUP_G2 = GB_POSEIDON_GROUP2;
 static constexpr int GROUP_SINGLES = N_PARTIAL - GROUP_G * GROUP_N - GROUP_G2;
 static_assert(GROUP_SINGLES >= 0 && GROUP_G >= 2 && GROUP_G <= 5 && (GROUP_G2 == 0 || (GROUP_G2 >= 2 && GROUP_G2 <= 5)), "partial-round plan");
-static constexpr int GROUP_OPS_MAIN = 2 * GROUP_G - 1, GROUP_OPS_REM = GROUP_G2 ? 2 * GROUP_G2 - 1 : 0;
+// operands a workgroup keeps in LDS: the phase-B planes, and the phase-A planes in front of them when phase A runs on the matrix pipe
+template <int G>
+struct GroupOps {
+    static constexpr int skip = GB_POSEIDON_PHASE_A_MFMA ? 0 : G - 1;            // operands of Shape<G>::ops() that are not loaded
+    static constexpr int count = G >= 2 ? 2 * G - 1 - skip : 0;
+    static constexpr int first_b = GB_POSEIDON_PHASE_A_MFMA ? G - 1 : 0;         // index of phase B's plane 0 in the table
+};
+static_assert(GB_POSEIDON_PHASE_A_MFMA || (GROUP_G <= 4 && GROUP_G2 <= 4), "row 0 of M^4 times twelve 32-bit halves does not fit 64 bits");
+static constexpr int GROUP_OPS_MAIN = GroupOps<GROUP_G>::count, GROUP_OPS_REM = GroupOps<GROUP_G2>::count;
 static constexpr int GROUP_OPS_TOTAL = GROUP_OPS_MAIN + GROUP_OPS_REM;
 static constexpr int GROUP_LDS_V4 = GROUP_OPS_TOTAL * 64;   // v4i entries a workgroup needs
 
@@ -55,7 +66,8 @@ __device__ __forceinline__ v4i group_operand_share(const uint32_t (&op)[16][4], 
 template <int G>
 __device__ __forceinline__ void group_fill_ops(v4i* lds) {
     if constexpr (G >= 2) {
-        for (u32 e = threadIdx.x; e < (u32)(2 * G - 1) * 64; e += blockDim.x) lds[e] = group_operand_share(grp::Shape<G>::ops()[e >> 6], e & 63);
+        for (u32 e = threadIdx.x; e < (u32)GroupOps<G>::count * 64; e += blockDim.x)
+            lds[e] = group_operand_share(grp::Shape<G>::ops()[GroupOps<G>::skip + (e >> 6)], e & 63);
     }
 }
 // Fill the workgroup's operand table (call once, all threads; ends in a barrier).
@@ -105,7 +117,7 @@ __device__ __forceinline__ void group_chain(v16i& d, const u32 (&pl)[8][4], cons
     constexpr int n = PHASE_B ? S::LEN_B[PLANE] : S::LEN_A[PLANE];
     if constexpr (E < n) {
         constexpr grp::Mfma m = PHASE_B ? S::SCHED_B[PLANE][E] : S::SCHED_A[PLANE][E];
-        const v4i a = ops[((PHASE_B ? S::NA : 0) + m.k) * 64];
+        const v4i a = ops[((PHASE_B ? GroupOps<G>::first_b : 0) + m.k) * 64];
         v4i b;
         if constexpr (m.comp != 0) {
             b[0] = (int)cpl[m.p][0]; b[1] = (int)cpl[m.p][1]; b[2] = (int)cpl[m.p][2]; b[3] = (int)cpl[m.p][3];
@@ -119,7 +131,13 @@ __device__ __forceinline__ void group_chain(v16i& d, const u32 (&pl)[8][4], cons
 template <int G, bool PHASE_B, int PLANE>
 __device__ __forceinline__ v16i group_plane(const u32 (&pl)[8][4], const u32 (&cpl)[8][4], const v4i* __restrict__ ops) {
     v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef GB_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(GB_EXP_SETPRIO);
+#endif
     group_chain<G, PHASE_B, PLANE, 0>(d, pl, cpl, ops);
+#ifdef GB_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return d;
 }
 
@@ -127,7 +145,7 @@ __device__ __forceinline__ v16i group_plane(const u32 (&pl)[8][4], const u32 (&c
 // G partial rounds starting with round r0 (uniform): the state comes in with round r0's constants added and leaves with those
 // of round r0 + G added.  `ops` = this lane's column of the workgroup's operand table, at the group shape's first operand.
 template <int G>
-__device__ __forceinline__ void partial_group(u64 (&s)[12], const v4i* __restrict__ ops, int r0) {
+__device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& amat, const v4i* __restrict__ ops, int r0) {
     using S = grp::Shape<G>;
     const grp::GroupInit& init = S::init();
     const int gi = r0 - HALF_FULL;
@@ -157,37 +175,62 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const v4i* __restric
     for (int p = 0; p < 8; p++)
 #pragma unroll
         for (int w = 0; w < 4; w++) cpl[p][w] = ~pl[p][w];   // only the planes a schedule complements are ever materialised
-    // ---- phase A: the words u_1 .. u_(G-1) before their constants and the d_i terms
-    long long ulo[G - 1], uhi[G - 1];
+    // ---- phase A: the words u_1 .. u_(G-1) before the d_i terms
+    u64 ulo[G - 1], uhi[G - 1];
+#if GB_POSEIDON_PHASE_A_MFMA
     {
-        const v16i d0 = group_plane<G, false, 0>(pl, cpl, ops), d1 = group_plane<G, false, 1>(pl, cpl, ops);
+        long long alo[G - 1], ahi[G - 1];
+        {
+            const v16i d0 = group_plane<G, false, 0>(pl, cpl, ops), d1 = group_plane<G, false, 1>(pl, cpl, ops);
 #pragma unroll
-        for (int j = 0; j < G - 1; j++) ulo[j] = mad_i64_start((int)(((u32)d1[j] << 8) + (u32)d0[j]), init.ulo[gi][j]);
-        GB_KEEP_TILES(d0, d1, ulo[G - 2]);
-    }
-    {
-        const v16i d0 = group_plane<G, false, 2>(pl, cpl, ops), d1 = group_plane<G, false, 3>(pl, cpl, ops);
+            for (int j = 0; j < G - 1; j++) alo[j] = mad_i64_start((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, init.ulo[gi][j]);
+            GB_KEEP_TILES(d0, d1, alo[G - 2]);
+        }
+        {
+            const v16i d0 = group_plane<G, false, 2>(pl, cpl, ops), d1 = group_plane<G, false, 3>(pl, cpl, ops);
 #pragma unroll
-        for (int j = 0; j < G - 1; j++) ulo[j] = mad_i64((int)(((u32)d1[j] << 8) + (u32)d0[j]), 65536, ulo[j]);
-        GB_KEEP_TILES(d0, d1, ulo[G - 2]);
-    }
-    {
-        const v16i d0 = group_plane<G, false, 4>(pl, cpl, ops), d1 = group_plane<G, false, 5>(pl, cpl, ops);
+            for (int j = 0; j < G - 1; j++) alo[j] = mad_i64((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, alo[j]);
+            GB_KEEP_TILES(d0, d1, alo[G - 2]);
+        }
+        {
+            const v16i d0 = group_plane<G, false, 4>(pl, cpl, ops), d1 = group_plane<G, false, 5>(pl, cpl, ops);
 #pragma unroll
-        for (int j = 0; j < G - 1; j++) uhi[j] = mad_i64_start((int)(((u32)d1[j] << 8) + (u32)d0[j]), init.uhi[gi][j]);
-        GB_KEEP_TILES(d0, d1, uhi[G - 2]);
-    }
-    {
-        const v16i d0 = group_plane<G, false, 6>(pl, cpl, ops), d1 = group_plane<G, false, 7>(pl, cpl, ops);
+            for (int j = 0; j < G - 1; j++) ahi[j] = mad_i64_start((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, init.uhi[gi][j]);
+            GB_KEEP_TILES(d0, d1, ahi[G - 2]);
+        }
+        {
+            const v16i d0 = group_plane<G, false, 6>(pl, cpl, ops), d1 = group_plane<G, false, 7>(pl, cpl, ops);
 #pragma unroll
-        for (int j = 0; j < G - 1; j++) uhi[j] = mad_i64((int)(((u32)d1[j] << 8) + (u32)d0[j]), 65536, uhi[j]);
-        GB_KEEP_TILES(d0, d1, uhi[G - 2]);
+            for (int j = 0; j < G - 1; j++) ahi[j] = mad_i64((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, ahi[j]);
+            GB_KEEP_TILES(d0, d1, ahi[G - 2]);
+        }
+#pragma unroll
+        for (int j = 0; j < G - 1; j++) {
+            ulo[j] = (u64)alo[j];
+            uhi[j] = (u64)ahi[j];
+        }
     }
+#else
+    // on the VALU: row 0 of M^j has entries below 2^(8j - 3), so the two 32-bit halves of the twelve words accumulate unreduced in
+    // 64 bits - 24 v_mad_u64_u32 per word, against 8 j MFMAs whose pipe time the kernel does not hide (profiles/r04_poseidon_groups.txt)
+#pragma unroll
+    for (int j = 1; j < G; j++) {
+        const u64 k = grp::KU[gi][j - 1];
+        u64 lo = (u32)k, hi = k >> 32;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            lo += (u64)(u32)s[i] * grp::ROW0[j][i];
+            hi += (u64)(u32)(s[i] >> 32) * grp::ROW0[j][i];
+        }
+        ulo[j - 1] = lo;
+        uhi[j - 1] = hi;
+    }
+#endif
     // ---- the s-boxes of rounds r0 + 1 .. r0 + G - 1, one after the other
     u64 dl[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 1; j < G; j++) {
-        u64 lo = (u64)ulo[j - 1], hi = (u64)uhi[j - 1];
+        u64 lo = ulo[j - 1], hi = uhi[j - 1];
 #pragma unroll
         for (int i = 1; i < j; i++) {   // d_i (M^(j-i))_00, unreduced: < 2^32 * 2^29 on top of < 2^46
             lo += (u64)(u32)dl[i - 1] * S::TRI[j - i];
@@ -221,25 +264,25 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const v4i* __restric
     {
         const v16i d0 = group_plane<G, true, 0>(pl, cpl, ops), d1 = group_plane<G, true, 1>(pl, cpl, ops);
 #pragma unroll
-        for (int q = 0; q < 12; q++) lo[q] = mad_i64_start((int)(((u32)d1[q] << 8) + (u32)d0[q]), init.olo[gi][q]);
+        for (int q = 0; q < 12; q++) lo[q] = mad_i64_start((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, init.olo[gi][q]);
         GB_KEEP_TILES(d0, d1, lo[11]);
     }
     {
         const v16i d0 = group_plane<G, true, 2>(pl, cpl, ops), d1 = group_plane<G, true, 3>(pl, cpl, ops);
 #pragma unroll
-        for (int q = 0; q < 12; q++) lo[q] = mad_i64((int)(((u32)d1[q] << 8) + (u32)d0[q]), 65536, lo[q]);
+        for (int q = 0; q < 12; q++) lo[q] = mad_i64((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, lo[q]);
         GB_KEEP_TILES(d0, d1, lo[11]);
     }
     {
         const v16i d0 = group_plane<G, true, 4>(pl, cpl, ops), d1 = group_plane<G, true, 5>(pl, cpl, ops);
 #pragma unroll
-        for (int q = 0; q < 12; q++) hi[q] = mad_i64_start((int)(((u32)d1[q] << 8) + (u32)d0[q]), init.ohi[gi][q]);
+        for (int q = 0; q < 12; q++) hi[q] = mad_i64_start((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, init.ohi[gi][q]);
         GB_KEEP_TILES(d0, d1, hi[11]);
     }
     {
         const v16i d0 = group_plane<G, true, 6>(pl, cpl, ops), d1 = group_plane<G, true, 7>(pl, cpl, ops);
 #pragma unroll
-        for (int q = 0; q < 12; q++) hi[q] = mad_i64((int)(((u32)d1[q] << 8) + (u32)d0[q]), 65536, hi[q]);
+        for (int q = 0; q < 12; q++) hi[q] = mad_i64((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, hi[q]);
         GB_KEEP_TILES(d0, d1, hi[11]);
     }
     fold_rows_rare_carry(s, lo, hi);
@@ -248,7 +291,7 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const v4i* __restric
 // The permutation with every MDS layer on the matrix pipe and the partial rounds in groups; same contract as
 // permute_mont_mfma_naive (Montgomery-form lazy residues in and out).  `amat` = mds_mfma_matrix(), `ops` = the workgroup's operand
 // table (group_ops_init) offset by this thread's lane.
-__device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const v4i amat, const v4i* __restrict__ ops) {
+__device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const MdsOperand& amat, const v4i* __restrict__ ops) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
     for (int r = 0; r < HALF_FULL; r++) {
@@ -256,8 +299,8 @@ __device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const v4
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
         mds_layer_mfma(s, amat, r + 1);
     }
-    for (int gidx = 0; gidx < GROUP_N; gidx++) partial_group<GROUP_G>(s, ops, HALF_FULL + GROUP_G * gidx);
-    if constexpr (GROUP_G2 >= 2) partial_group<GROUP_G2>(s, ops + GROUP_OPS_MAIN * 64, HALF_FULL + GROUP_G * GROUP_N);
+    for (int gidx = 0; gidx < GROUP_N; gidx++) partial_group<GROUP_G>(s, amat, ops, HALF_FULL + GROUP_G * gidx);
+    if constexpr (GROUP_G2 >= 2) partial_group<GROUP_G2>(s, amat, ops + GROUP_OPS_MAIN * 64, HALF_FULL + GROUP_G * GROUP_N);
     for (int r = HALF_FULL + N_PARTIAL - GROUP_SINGLES; r < HALF_FULL + N_PARTIAL; r++) {
         s[0] = sbox(s[0]);
         mds_layer_mfma(s, amat, r + 1);

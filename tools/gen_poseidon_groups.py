@@ -324,6 +324,21 @@ def emit():
     o.append("// accumulator start values of a group whose first round is r0 = 4 + index: the u rows (phase A) and the state rows (phase B)")
     o.append("struct GroupInit { uint64_t ulo[22][4], uhi[22][4], olo[22][12], ohi[22][12]; };")
     o.append("template <int G> struct Shape;")
+    # phase A on the VALU: u_j = sum_i ROW0[j][i] y_i + KU[r0 - 4][j - 1] + sum_{i<j} d_i TRI[j - i]
+    pw = [mpow(e) for e in range(5)]
+    o.append("static constexpr uint32_t ROW0[5][12] = {   // row 0 of M^j, exact integers (j <= 4: below 2^29)")
+    for j in range(5):
+        assert max(pw[j][0]) < (1 << 29)
+        o.append("    {" + ", ".join("%du" % v for v in pw[j][0]) + "},")
+    o.append("};")
+    o.append("// K_j of a group whose first round is r0 = 4 + index: (sum_{i=1..j} M^(j-i) rc_(r0+i) R)_0 mod p, j = 1 .. 4")
+    o.append("GB_GROUPS_DEVICE static const uint64_t KU[22][4] = {")
+    for r0 in range(N_FULL_HALF, N_FULL_HALF + N_PARTIAL):
+        jmax = min(4, N_FULL_HALF + N_PARTIAL - r0)   # rounds r0+1 .. r0+j must be partial rounds' constants or the next full round's
+        ks = Group(Shape(jmax + 1), r0).Ku if jmax >= 1 else []
+        ks = list(ks) + [0] * (4 - len(ks))
+        o.append("    {" + ", ".join("0x%xull" % v for v in ks) + "},")
+    o.append("};")
     fmt64 = lambda rows: ", ".join("{" + ", ".join("0x%xull" % v for v in r) + "}" for r in rows)
     for g in GROUP_SIZES:
         sh = SHAPES[g]

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, MB_OCC) void k_perm(const u64* __restrict__ in
     __shared__ poseidon_gl::v4i ops_lds[poseidon_gl::GROUP_LDS_V4 > 0 ? poseidon_gl::GROUP_LDS_V4 : 1];
     if (GROUPED) poseidon_gl::group_ops_init(ops_lds);
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // n is a multiple of 256
-    const poseidon_gl::v4i amat = poseidon_gl::mds_mfma_matrix();
+    const poseidon_gl::MdsOperand amat = poseidon_gl::mds_mfma_matrix();
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = poseidon_gl::to_mont(in[i * n + t]);
