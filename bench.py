@@ -125,6 +125,17 @@ def _latest_profile(pattern):
     return j
 
 
+_CIRCUITS = {}   # (field, log_n) -> build_dummy_circuit(): the K = 1 legs and the in-flight legs prove the same circuit
+
+
+def dummy_circuit_inputs(bb, log_n):
+    from plonky2_goldibear_amd import dummy_circuit as DC
+    key = (bb, log_n)
+    if key not in _CIRCUITS:
+        _CIRCUITS[key] = DC.build_dummy_circuit_bb(log_n) if bb else DC.build_dummy_circuit(log_n)
+    return _CIRCUITS[key]
+
+
 class ProveLeg:
     """One field's circuit on this rank's GPU: build() once, then timed prove() steps from a host or an HBM-resident witness."""
 
@@ -141,7 +152,7 @@ class ProveLeg:
         self.nwires, self.nrouted, self.arity_bits, self.ext_d, self.esz = (167, 41, 3, 4, 4) if bb else (135, 80, 4, 2, 8)
         self.idt = np.int32 if bb else np.int64
         self.dev = "cuda:%d" % local_rank
-        cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(log_n) if bb else DC.build_dummy_circuit(log_n)
+        cs, k_is, pi_row, _ = dummy_circuit_inputs(bb, log_n)
         cs_dev = torch.from_numpy(cs.view(self.idt)).to(self.dev)
         self.lanes = []  # one (context, circuit, host witness) per proof in flight: independent circuits, as across GPUs
         self.extra_ctx = []
@@ -301,7 +312,10 @@ class ProveLeg:
                          "achieved": _num(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": _num(achieved / HBM_PEAK_GBS if achieved else None), "traffic": traffic,
                          "traffic_source": tj and {"file": tj["profile_file"], "stale": tj["stale"]},
-                         "algorithmic_bytes": alg_bytes, "ms": _num(ntt_ms)},
+                         "algorithmic_bytes": alg_bytes, "ms": _num(ntt_ms),
+                         # the transform is VALU-issue bound, not HBM bound: 31 integer instructions per algorithmic byte (DESIGN.md
+                         # section 4) cap `frac` at 0.32 with a 2-cycle issue and at 0.217 with the measured 2.9 cycles per instruction
+                         "valu_ceiling_frac": None if bb else 0.217},
             "merkle": {"permutations": perms, "Gperm_per_s": _num(perms / (merkle_ms * 1e-3) / 1e9 if merkle_ms else None),
                        "ms": _num(merkle_ms)},
         }
@@ -386,8 +400,9 @@ def bind_rank_to_local_cpus(local_rank, local_world, device_index):
         avail = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return None
-    if local_world <= 1 or len(avail) < 2 * local_world:
-        return {"cpus": len(avail), "bound": False}
+    if local_world <= 1 or len(avail) < local_world:
+        print("bench.py rank-local %d: not bound (%d cpus for %d ranks)" % (local_rank, len(avail), local_world), file=sys.stderr)
+        return {"cpus": len(avail), "bound": False, "first": avail[0], "last": avail[-1]}
     near = [None] * local_world
     if device_index is not None:
         import torch
@@ -406,7 +421,41 @@ def bind_rank_to_local_cpus(local_rank, local_world, device_index):
     return info
 
 
-def stub_main(args, rank, world, affinity, dist):
+def init_control_plane(world, local_rank, default_backend):
+    """The data path has no collective; torch.distributed carries one barrier pair and one max per timed region.  The DEFAULT group
+    is gloo - rendezvous over TCP, nothing that can fail for GPU reasons - and, unless GB_BENCH_BACKEND says gloo, an RCCL group
+    ("nccl") is brought up beside it and tried with one all-reduce; it carries the barrier and the reductions only if that worked
+    on EVERY rank (agreed over gloo).  Otherwise the run goes on over gloo and says so - on stderr and in the line's
+    `control_plane` - instead of failing a job whose proofs need no interconnect."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from plonky2_goldibear_amd import sharding
+    want = os.environ.get("GB_BENCH_BACKEND", default_backend)
+    dist.init_process_group("gloo")
+    if want != "nccl":
+        return {"backend": "gloo", "requested": want}
+    ok, why, group = 1, None, None
+    try:
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+        t = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize()
+        if int(t.item()) != world:
+            raise RuntimeError("all_reduce over RCCL returned %r, expected %d" % (t.item(), world))
+    except Exception as e:   # noqa: BLE001 - whatever RCCL raises, the job does not need it
+        ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # gloo: do all ranks have it?
+    if int(flag.item()) == 1:
+        sharding.set_group(group)
+        return {"backend": "nccl", "requested": "nccl"}
+    print("bench.py: RCCL control plane unavailable (%s) - barrier and max-over-ranks go over gloo; the proofs use no collective"
+          % (why or "another rank failed"), file=sys.stderr)
+    return {"backend": "gloo", "requested": "nccl", "fallback_reason": why or "another rank could not bring RCCL up"}
+
+
+def stub_main(args, rank, world, affinity, dist, control_plane=None):
     """GB_BENCH_STUB=1: the multi-rank flow of main() with the GPU work replaced by a sleep (CPU tests of the launch path)"""
     from plonky2_goldibear_amd import sharding
     if os.environ.get("GB_BENCH_STUB_FAIL_RANK") == str(rank):   # test hook: a rank that dies must fail the whole run
@@ -424,7 +473,7 @@ def stub_main(args, rank, world, affinity, dist):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                           "config": {"workload": "STUB (GB_BENCH_STUB=1): no GPU work, launch-path rehearsal only"},
-                          "stub": True, "affinity": affinity}))
+                          "stub": True, "affinity": affinity, "control_plane": control_plane}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -460,6 +509,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-babybear", action="store_true", help="skip the BASELINE configs[3] leg of the default run")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident-witness leg (value_hbm_resident)")
+    ap.add_argument("--no-inflight2", action="store_true", help="skip the two-proofs-in-flight legs (value_inflight2)")
     ap.add_argument("--host-witness", action="store_true", help="(default since round 2; kept for old command lines)")
     args = ap.parse_args()
 
@@ -490,15 +540,15 @@ def main():
     if not stub:
         torch.cuda.set_device(device_index)
     local_rank = device_index
+    control_plane = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GB_BENCH_BACKEND", "gloo" if stub else "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        control_plane = init_control_plane(world, local_rank, "gloo" if stub else "nccl")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, affinity)      # every rank's CPU binding goes into the line (default group: gloo)
+        affinity = dict(affinity or {}, ranks=gathered)
     if stub:
-        return stub_main(args, rank, world, affinity, dist)
+        return stub_main(args, rank, world, affinity, dist, control_plane)
 
     from plonky2_goldibear_amd import GpuContext, PolynomialBatch, sharding
 
@@ -526,6 +576,7 @@ def main():
             out["value_no_retry"] = _num(leg.no_retry_rate() and world * leg.no_retry_rate())
             out["witnesses"] = "%d pinned seeds, cycled: every step proves a different witness" % N_WITNESSES
             out["affinity"] = affinity
+            out["control_plane"] = control_plane
         if not args.no_resident:
             dt2, scopes2, _ = leg.timed(steps, args.warmup, host=False)
             if rank == 0:
@@ -533,6 +584,15 @@ def main():
                 out["ms_per_step_hbm_resident"] = dt2 / steps * 1e3
         leg.free()
         del leg
+        second = not args.no_inflight2 and inflight == 1   # SURVEY.md 8(d) counts a stream of independent proofs: two of them in
+        if second:                                          # flight per GPU (one host thread + one stream each), host witnesses
+            leg2 = ProveLeg(args.field, log_n, args.challenges, local_rank, rank, 2, ctx)
+            dt3, _, _ = leg2.timed(steps, args.warmup, host=True)
+            if rank == 0:
+                out["value_inflight2"] = world * steps * 2 / dt3
+                out["ms_per_step_inflight2"] = dt3 / steps * 1e3    # one step = two proofs
+            leg2.free()
+            del leg2
         if args.field == "goldilocks" and world == 1 and not args.no_babybear and log_n == 20:
             # BASELINE configs[3]: the same measurements for BabyBear + Poseidon2-16 (a 31-bit field needs num_challenges = 10)
             bleg = ProveLeg("babybear", log_n, None, local_rank, rank, inflight, ctx)
@@ -549,6 +609,12 @@ def main():
                 bb["value_hbm_resident"] = steps * inflight / bdt2
                 bb["ms_per_step_hbm_resident"] = bdt2 / steps * 1e3
             bleg.free()
+            if second:
+                bleg2 = ProveLeg("babybear", log_n, None, local_rank, rank, 2, ctx)
+                bdt3, _, _ = bleg2.timed(steps, args.warmup, host=True)
+                bb["value_inflight2"] = steps * 2 / bdt3
+                bb["ms_per_step_inflight2"] = bdt3 / steps * 1e3
+                bleg2.free()
             out["babybear"] = bb
         if rank == 0 and not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the driver's contract)
             from oracle import oracle as _O

@@ -48,7 +48,12 @@ enum { GB_GOLDILOCKS = 0, GB_BABYBEAR = 1 }; /* field tag: F = Goldilocks (Posei
 
 enum {
     GB_INPUT_HOST = 0,   /* `cols` / `salts` are host pointers (the drop-in case) */
-    GB_INPUT_DEVICE = 1  /* they are device pointers on ctx's device (chained calls, benchmarks) */
+    GB_INPUT_DEVICE = 1, /* they are device pointers on ctx's device (chained calls, benchmarks) */
+    /* gb_prove only, TEST HOOK: behave as if the permutation argument had found a zero denominator (prover.rs:512-514) once the
+     * Z computation is done - return GB_ERR_PERM_ARG_ZERO and keep what gb_prove_retry builds on, exactly as the real error
+     * does.  In a 64-bit field the real error has probability ~2^-37 per 2^20-row proof: this is how the retry path of a
+     * Goldilocks circuit is exercised (tests/test_gpu_prove.py). */
+    GB_PROVE_FAIL_PERM_ARG = 0x200
 };
 
 #define GB_SALT_SIZE 4 /* fri/oracle.rs:25 */
@@ -230,10 +235,17 @@ gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uin
  * last leaf-sponge segment - true for the random wire of every stock configuration) only that wire's column is transformed again
  * and only the last absorption of every leaf sponge and the tree above are re-hashed: ~5 ms instead of ~40 at 2^20 BabyBear rows,
  * where one proof in five needs it.  Anything else - no failed attempt before it, another gb_prove* in between, a device attempt
- * retried with a host matrix, a zero-knowledge circuit - is simply the full computation.  The state of a failed attempt is held until the next
- * gb_prove* / gb_circuit_free on the circuit. */
+ * retried with a host matrix, a zero-knowledge circuit - is simply the full computation.  The state of a failed attempt (the wires
+ * commitment, the device copy of a host witness, the leaf sponges' state: ~12 GB at 2^20 Goldilocks rows) is held until the next
+ * gb_prove* / gb_circuit_free on the circuit, gb_circuit_drop_retry, gb_ctx_trim - or until an allocation on the context would
+ * otherwise fail.  A host retry trusts the kept device copy for every element but witness[wire][row]: a caller that changed anything
+ * else must call gb_prove.  (GB_RETRY_VERIFY=1 in the environment makes the library compare the whole matrix with the kept copy
+ * first - a debugging aid, one read-back of the witness - and return GB_ERR_INVALID when they differ elsewhere.) */
 gb_status gb_prove_retry(gb_circuit* c, const void* witness, uint32_t flags, uint32_t wire, uint64_t row, const uint64_t* public_inputs,
                          size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);
+/* Release what a failed attempt left behind without proving again - a caller that gives up after GB_ERR_PERM_ARG_ZERO
+ * (ProverError::TooManyPermArgFailures, prover.rs:221-225).  No-op when nothing is held. */
+gb_status gb_circuit_drop_retry(gb_circuit* c);
 /* The same for a circuit built with cfg.zero_knowledge (prover.rs:267,334,382: `blinding` = true for the wires, Zs / partial
  * products and quotient commitments).  salts: [3][GB_SALT_SIZE][N = 2^(degree_bits + rate_bits)] canonical elements in
  * LDE-point order - the columns the reference draws with F::rand_vec (fri/oracle.rs:144-148) - for those three commitments,

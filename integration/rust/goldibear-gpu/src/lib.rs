@@ -109,6 +109,7 @@ extern "C" {
                                constants_sigmas: *const c_void, k_is: *const c_void, flags: u32, out: *mut *mut gb_circuit) -> i32;
     fn gb_prove_retry(c: *mut gb_circuit, witness: *const c_void, flags: u32, wire: u32, row: u64, public_inputs: *const u64,
                       num_public_inputs: usize, proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
+    fn gb_circuit_drop_retry(c: *mut gb_circuit) -> i32;
     fn gb_prove_salted(c: *mut gb_circuit, witness: *const c_void, flags: u32, public_inputs: *const u64, num_public_inputs: usize,
                        salts: *const c_void, proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
     fn gb_verifier_create(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, gates: *const gb_gate, num_gates: u32, k_is: *const c_void,
@@ -384,6 +385,11 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         check(self.ctx.0, st)?;
         buf.truncate(len);
         Ok(ProveOutcome::Proof(buf))
+    }
+    /// Give up after `PermArgZero` (`ProverError::TooManyPermArgFailures`, prover.rs:221-225): releases what the failed attempt
+    /// left on the device for `prove_retry` (~12 GB at 2^20 Goldilocks rows).  No-op when nothing is held.
+    pub fn drop_retry(&self) -> Result<(), GpuError> {
+        check(self.ctx.0, unsafe { gb_circuit_drop_retry(self.handle) })
     }
     /// `wires_permutation_partial_products_and_zs` for every challenge (plonk/prover.rs:305-329, 449-546): the values handed to
     /// `PolynomialBatch::from_values`, Zs first.  `Ok(None)` = `ProverError::InvZeroPermArg`.

@@ -77,7 +77,10 @@ struct gb_ctx {
     DeviceBuf small;                                        // small gather staging (rows, siblings)
     hipEvent_t upload_mark = nullptr;                       // recorded on `stream` after the last host -> device copy of a commit
     bool upload_marked = false;
+    std::vector<gb_circuit*> circuits;                      // live circuits of this context: what they keep for gb_prove_retry is
+                                                            // released by gb_ctx_trim and when an allocation would fail
 };
+static void drop_all_retry_state(gb_ctx* ctx);              // prover_host.inc
 
 struct gb_batch {
     gb_ctx* ctx = nullptr;
@@ -179,9 +182,10 @@ hipError_t pool_alloc(gb_ctx* ctx, size_t bytes, void** out) {
         return hipSuccess;
     }
     hipError_t e = hipMalloc(out, bytes);
-    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
+    if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(ctx->stream);
+        drop_all_retry_state(ctx);   // what failed attempts left for gb_prove_retry goes first (it lands in the pool)
         for (auto& kv : ctx->pool) (void)hipFree(kv.second);
         ctx->pool.clear();
         e = hipMalloc(out, bytes);
@@ -719,6 +723,7 @@ gb_status gb_ctx_trim(gb_ctx* ctx) {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drop_all_retry_state(ctx);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     ctx->pool.clear();
     return GB_OK;

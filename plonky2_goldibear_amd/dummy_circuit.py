@@ -49,6 +49,46 @@ def gl_powers(base, n):
     return out
 
 
+def gl_mul7(x):
+    """7 x mod p for a canonical uint64 array: 8 x = (x << 3) + (x >> 61) 2^64 with 2^64 = 2^32 - 1, minus x - about ten array
+    operations where gl_mul takes twenty-five"""
+    with np.errstate(over="ignore"):
+        lo = x << np.uint64(3)
+        s = lo + (x >> np.uint64(61)) * _EPS
+        s = np.where(s < lo, s + _EPS, s)
+        r = s - x
+        r = np.where(s < x, r - _EPS, r)
+        return np.where(r >= _P, r - _P, r)
+
+
+def _sigma_columns(sig, sub, k_is, step, workers=None):
+    """sig[j] = k_is[j] * sub with k_is[j] = k_is[j-1] * g (cosets.rs:8-21): one multiplication by the small generator per column,
+    row blocks in parallel (numpy releases the GIL), each block staying in cache across the columns"""
+    import concurrent.futures
+    import os
+    n = sub.shape[0]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    workers = workers or max(1, min(cores, 16))
+    block = max(1 << 12, min(1 << 16, n // workers or n))
+
+    def run(lo):
+        hi = min(n, lo + block)
+        cur = sub[lo:hi].copy()      # k_is[0] = 1
+        for j in range(sig.shape[0]):
+            if j:
+                cur = step(cur)
+            sig[j, lo:hi] = cur
+    if workers == 1 or n <= block:
+        for lo in range(0, n, block):
+            run(lo)
+    else:
+        with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+            list(ex.map(run, range(0, n, block)))
+
+
 def splitmix64(seed, count):
     idx = np.arange(1, count + 1, dtype=np.uint64)
     with np.errstate(over="ignore"):
@@ -89,8 +129,7 @@ def build_dummy_circuit_bb(degree_bits, num_routed_wires=41, num_constants=2):
     k_is = np.array([pow(31, i, BB_P) for i in range(num_routed_wires)], dtype=np.uint32)
     sub = bb_powers(pow(0x1a427a41, 1 << (27 - degree_bits), BB_P), n)
     sig = cs[1 + num_constants:]
-    for j in range(num_routed_wires):
-        sig[j] = bb_mul(sub, k_is[j])
+    _sigma_columns(sig, sub, k_is, lambda x: bb_mul(x, 31))
     cls = [(pi_row, j) for j in range(8)] + [(const_row, 0)]
     for t, (row, col) in enumerate(cls):
         nrow, ncol = cls[(t + 1) % len(cls)]
@@ -123,8 +162,7 @@ def build_dummy_circuit(degree_bits, num_routed_wires=80, num_constants=2):
     k_is = np.array([pow(7, i, P) for i in range(num_routed_wires)], dtype=np.uint64)  # field/src/cosets.rs:8-21
     sub = gl_powers(pow(1753635133440165772, 1 << (32 - degree_bits), P), n)
     sig = cs[1 + num_constants:]
-    for j in range(num_routed_wires):
-        sig[j] = gl_mul(sub, k_is[j])
+    _sigma_columns(sig, sub, k_is, gl_mul7)   # k_is[j] = 7^j: 12 s of single-threaded gl_mul at 2^20 rows before round 4
     # the one copy class {(pi,0..3), (const,0)} in (row, column) order (permutation_argument.rs:108-157)
     cls = [(pi_row, 0), (pi_row, 1), (pi_row, 2), (pi_row, 3), (const_row, 0)]
     for t, (row, col) in enumerate(cls):

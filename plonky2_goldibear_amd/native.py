@@ -12,6 +12,7 @@ GB_OK, GB_ERR_INVALID, GB_ERR_HIP, GB_ERR_OOM, GB_ERR_UNSUPPORTED = 0, 1, 2, 3, 
 GB_ERR_PERM_ARG_ZERO, GB_ERR_OPENING_IN_SUBGROUP, GB_ERR_BUFFER_TOO_SMALL, GB_ERR_VERIFY = 16, 17, 18, 19
 GB_GOLDILOCKS, GB_BABYBEAR = 0, 1
 GB_INPUT_HOST, GB_INPUT_DEVICE = 0, 1
+GB_PROVE_FAIL_PERM_ARG = 0x200   # gb_prove test hook: report InvZeroPermArg once the Z computation is done (include/goldibear_gpu.h)
 GB_SALT_SIZE = 4
 
 _vp, _u32, _u64, _sz, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_int32
@@ -59,6 +60,7 @@ SIGNATURES = {
     "gb_prove_openings": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "gb_prove": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "gb_prove_retry": (_i32, [_vp, _vp, _u32, _u32, _u64, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "gb_circuit_drop_retry": (_i32, [_vp]),
     "gb_prove_salted": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
 }
 

@@ -153,6 +153,9 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
                     witness[col, row] = val
                 else:  # torch device tensor holding the same-width integer bit pattern
                     witness[col, row] = val - (1 << (8 * witness.element_size())) if val >> (8 * witness.element_size() - 1) else val
+                    # that write is on torch's current stream; the library reads the column on its own stream: order them
+                    import torch
+                    torch.cuda.current_stream(witness.device).synchronize()
                 self.perm_arg_retries = attempt
             try:
                 # the second and third attempts differ from the failed one in the random wire only: gb_prove_retry rebuilds just
@@ -160,14 +163,23 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
                 retry = (col, row) if attempt > 0 and salts is None else None
                 return self.prove_once(witness, public_inputs, salts, retry_wire=retry)
             except N.PermArgZeroError:
+                if random_wire is None:   # no retry will follow: do not keep the failed attempt's commitment on the device
+                    self.drop_retry()
                 continue
+        self.drop_retry()   # giving up: the failed attempt's wires commitment and witness copy (~12 GB at 2^20 rows) go back
         raise N.TooManyPermArgFailuresError(N.GB_ERR_PERM_ARG_ZERO, "ProverError::TooManyPermArgFailures")
 
-    def prove_once(self, witness, public_inputs=(), salts=None, retry_wire=None):
+    def drop_retry(self):
+        """release what an attempt that ended in PermArgZeroError keeps on the device for the incremental retry"""
+        if self.handle:
+            N.check(self._lib.gb_circuit_drop_retry(self.handle), self.ctx.handle)
+
+    def prove_once(self, witness, public_inputs=(), salts=None, retry_wire=None, extra_flags=0):
         """internal_prove_with_partition_witness (plonk/prover.rs:228-447); raises PermArgZeroError.  A circuit created with
         zero_knowledge=True takes `salts`: [3][4][N] canonical elements (the F::rand_vec columns of the wires / Zs / quotient
         commitments, fri/oracle.rs:144-148), in the same memory space as the witness."""
         ptr, shape, flags, keep = _as_input(witness, self.field)
+        flags |= extra_flags   # N.GB_PROVE_FAIL_PERM_ARG: the library's test hook for the retry path
         want = (self.cfg.num_wires, 1 << self.cfg.degree_bits)
         if tuple(shape) != want:
             raise N.ShapeError(N.GB_ERR_INVALID, "witness must be %r, got %r" % (want, tuple(shape)))

@@ -7,6 +7,21 @@ barrier and the max-over-ranks reduction (backend "nccl" = RCCL on the GPU node,
 import torch
 import torch.distributed as dist
 
+_GROUP = None   # the process group that carries the barrier and the reductions (None: the default group)
+
+
+def set_group(group):
+    """bench.py: the default group is gloo (a control plane that cannot fail for GPU reasons); when an RCCL group came up on every
+    rank it carries the barrier and the reductions instead."""
+    global _GROUP
+    _GROUP = group
+
+
+def _device(device):
+    if device is not None:
+        return device
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(_GROUP) == "nccl" else torch.device("cpu")
+
 
 def circuits_for_rank(num_circuits, world, rank):
     """Static partition: proof i -> device i mod world."""
@@ -15,27 +30,23 @@ def circuits_for_rank(num_circuits, world, rank):
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        dist.barrier(group=_GROUP)
 
 
 def max_over_ranks(seconds, device=None):
     """Whole-job wall time = the slowest rank's time."""
     if not (dist.is_available() and dist.is_initialized()):
         return float(seconds)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_GROUP)
     return float(t.item())
 
 
 def sum_over_ranks(value, device=None):
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_GROUP)
     return float(t.item())
 
 

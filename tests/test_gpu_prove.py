@@ -143,3 +143,48 @@ def test_repeated_proving_does_not_leak(ctx):
             free.append(torch.cuda.mem_get_info(0)[0])
     assert free[0] == free[1]
     gpu.free()
+
+
+def test_goldilocks_retry_is_incremental_and_byte_identical(ctx, monkeypatch):
+    """gb_prove_retry on a Goldilocks circuit: InvZeroPermArg has probability ~2^-40 there, so the failed attempt comes
+    from the library's test hook (GB_PROVE_FAIL_PERM_ARG: the error is reported once the Z computation is done, with the same state
+    kept).  2^16 rows = 2^19 leaves, 135 wires: the incremental path - the random wire's 64-bit element is written into the kept
+    device copy, its column transformed and re-hashed - must give the bytes of a proof from scratch, and the oracle's."""
+    import torch
+    from plonky2_goldibear_amd import native as N
+    circ = D.DummyCircuit(16, D.CircuitConfig(num_challenges=3))
+    gpu = _gpu_circuit(ctx, circ)
+    circ.set_cap(gpu.constants_sigmas_cap)
+    w0 = circ.witness(seed=11)
+    rw = (circ.cfg.num_wires - 1, circ.pi_row)
+    w = w0.copy()
+    w[rw] = np.uint64(0xFEDCBA9876543210 % D.P)   # both 32-bit halves differ from the old value
+    want = gpu.prove_once(w)
+    assert want == D.prove_cpu(circ, w)[0]
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+    assert gpu.prove_once(w, retry_wire=rw) == want                      # host witness: kept copy, one element re-written
+    # device witness: the column comes from the caller's matrix
+    d0 = torch.from_numpy(w0.view(np.int64)).cuda()
+    dw = torch.from_numpy(w.view(np.int64)).cuda()
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(d0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+    assert gpu.prove_once(dw, retry_wire=rw) == want
+    # a host retry trusts the kept copy for everything but witness[wire][row]; GB_RETRY_VERIFY=1 checks that trust
+    monkeypatch.setenv("GB_RETRY_VERIFY", "1")
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+    assert gpu.prove_once(w, retry_wire=rw) == want
+    w_other = w.copy()
+    w_other[5, 9] = 12345
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+    with pytest.raises(ShapeError):                                        # GB_ERR_INVALID: differs elsewhere
+        gpu.prove_once(w_other, retry_wire=rw)
+    monkeypatch.delenv("GB_RETRY_VERIFY")
+    # giving up releases what the failed attempt kept (gb_circuit_drop_retry): the retry after it is a full gb_prove
+    with pytest.raises(PermArgZeroError):
+        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+    gpu.drop_retry()
+    assert gpu.prove_once(w, retry_wire=rw) == want
+    gpu.free()

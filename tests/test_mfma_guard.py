@@ -3,7 +3,8 @@
 Root cause of round 3's "undefined MFMA operand" incident and of round 4's first grouped Poseidon kernels: the compiler's hazard
 recognizer pads VALU reads / writes of an in-flight MFMA destination tile with s_nop, but not those made by INLINE ASM - and the
 byte-plane recombination is asm v_mad_i64_i32 whose results the allocator may park in tile registers the kernel never reads.
-The product keeps every tile allocated until it has been read (GB_KEEP_TILES); this test looks at the assembly."""
+The product writes the recombination in C (compiler-selected v_mad_i64_i32, padded like any other instruction; the asm form
+with GB_KEEP_TILES remains as GB_MAD_ASM); this test looks at the assembly either way."""
 import os
 import sys
 
@@ -25,14 +26,17 @@ def findings(src, flags=()):
 
 
 def test_guard_flags_a_build_without_the_tile_guard():
-    # three groups of three rounds + singles without GB_KEEP_TILES: the build that hashed wrongly on the GPU (profiles/r04_mfma_hazard.txt)
-    bad = findings(MICROBENCH, ["-DGB_POSEIDON_GROUP=3", "-DGB_POSEIDON_GROUP_COUNT=6", "-DGB_POSEIDON_GROUP2=0", "-DGB_EXP_NO_KEEP_TILES"])
+    # six groups of three rounds + singles, the recombination as inline asm (round 3's form, GB_MAD_ASM) and no tile guard: the build
+    # that hashed wrongly on the GPU (profiles/r04_mfma_hazard.txt)
+    plan = ["-DGB_POSEIDON_GROUP=3", "-DGB_POSEIDON_GROUP_COUNT=6", "-DGB_POSEIDON_GROUP2=0", "-DGB_POSEIDON_PHASE_A_MFMA=1"]
+    bad = findings(MICROBENCH, plan + ["-DGB_MAD_ASM", "-DGB_EXP_NO_KEEP_TILES"])
     assert any(kind == "WAW" for kind, *_ in bad), bad
-    good = findings(MICROBENCH, ["-DGB_POSEIDON_GROUP=3", "-DGB_POSEIDON_GROUP_COUNT=6", "-DGB_POSEIDON_GROUP2=0"])
-    assert good == []
+    assert findings(MICROBENCH, plan + ["-DGB_MAD_ASM"]) == []     # asm recombination + GB_KEEP_TILES
+    assert findings(MICROBENCH, plan) == []                          # the product's form: recombination the compiler can see
 
 
-@pytest.mark.parametrize("flags", [(), ("-DGB_POSEIDON_OCC=3",), ("-DGB_POSEIDON_OCC=5",), ("-DGB_MFMA_DEPTH4",), ("-DGB_POSEIDON_GROUP=2",), ("-DGB_POSEIDON_GROUP=3",)])
+@pytest.mark.parametrize("flags", [(), ("-DGB_POSEIDON_OCC=3",), ("-DGB_POSEIDON_OCC=5",), ("-DGB_MFMA_DEPTH4", "-DGB_POSEIDON_SINGLE_LAYERS"), ("-DGB_POSEIDON_GROUP=2",),
+                                   ("-DGB_POSEIDON_GROUP=3",), ("-DGB_POSEIDON_SINGLE_LAYERS",), ("-DGB_MAD_ASM",)])
 def test_merkle_kernels_are_clean(flags):
     assert findings(os.path.join(CSRC, "kernels_merkle.hip"), flags) == []
 

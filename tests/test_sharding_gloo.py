@@ -58,13 +58,19 @@ def test_single_process_is_identity():
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench_parent(extra_env, *args):
+def _run_bench_parent(extra_env, *args, gpus=2):
     env = dict(os.environ, GB_BENCH_STUB="1", GB_BENCH_BACKEND="gloo", GB_BENCH_SHARE_DEVICE="1")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.update(extra_env)
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", *args],
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", *args],
                           env=env, capture_output=True, text=True, timeout=240)
+
+
+def _line(r):
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout + r.stderr[-2000:]
+    return json.loads(lines[0])
 
 
 def test_bench_self_launches_its_ranks():
@@ -78,7 +84,40 @@ def test_bench_self_launches_its_ranks():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["stub"] is True
     assert j["ms_per_step"] >= 4.0                      # the slower rank (2 x 2 ms per step) sets the time: max over ranks
     assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
-    assert "rank-local 0" in r.stderr and "rank-local 1" in r.stderr   # each rank printed its CPU binding
+    assert "rank-local 0" in r.stderr and "rank-local 1" in r.stderr   # each rank printed its CPU binding (or that it has none)
+    ranks = j["affinity"]["ranks"]                                      # and the line carries both
+    assert len(ranks) == 2 and all(a["cpus"] >= 1 for a in ranks)
+    if all(a["bound"] for a in ranks):
+        assert ranks[0]["last"] < ranks[1]["first"] or ranks[1]["last"] < ranks[0]["first"]
+    assert j["control_plane"] == {"backend": "gloo", "requested": "gloo"}
+
+
+def test_eight_ranks_get_disjoint_cpu_sets():
+    """the launch path at the node's size: `python bench.py --gpus 8` (stub), eight ranks, eight disjoint CPU sets carved out of
+    this process's affinity mask (16 CPUs on a GPU box: two each; fewer than eight here: not bound, and the line says so)"""
+    avail = len(os.sched_getaffinity(0))
+    r = _run_bench_parent({}, gpus=8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r)
+    ranks = j["affinity"]["ranks"]
+    assert j["n_gpus"] == 8 and len(ranks) == 8
+    if avail >= 8:
+        assert all(a["bound"] for a in ranks)
+        spans = sorted((a["first"], a["last"]) for a in ranks)
+        assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), spans        # pairwise disjoint
+        assert sum(a["cpus"] for a in ranks) <= avail
+    else:
+        assert not any(a["bound"] for a in ranks)
+
+
+def test_control_plane_falls_back_to_gloo_when_rccl_cannot_come_up():
+    """GB_BENCH_BACKEND unset = nccl requested; on a box without GPUs RCCL cannot come up: the run goes on over gloo and says so"""
+    r = _run_bench_parent({"GB_BENCH_BACKEND": "nccl"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r)
+    cp = j["control_plane"]
+    assert cp["backend"] == "gloo" and cp["requested"] == "nccl" and cp["fallback_reason"]
+    assert "RCCL control plane unavailable" in r.stderr
 
 
 def test_bench_parent_fails_when_a_rank_fails():

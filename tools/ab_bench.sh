@@ -2,6 +2,8 @@
 # A/B of library variants under tools/bin/libs/*.so on the GPU box with the bench itself (both fields, short run).
 #   gpurun -- 'bash tools/ab_bench.sh nopf pf'
 mkdir -p gpurun_out/ab
+LIB=plonky2_goldibear_amd/lib/libgoldibear_gpu.so
+cp $LIB gpurun_out/ab/.product_lib.so && trap 'cp gpurun_out/ab/.product_lib.so $LIB; rm -f gpurun_out/ab/.product_lib.so' EXIT   # the variants are copied over the product library: put it back
 for v in "$@"; do
     cp tools/bin/libs/$v.so plonky2_goldibear_amd/lib/libgoldibear_gpu.so
     timeout -k 10 200 python3 bench.py --steps ${GB_AB_STEPS:-10} --warmup 3 --no-cpu-baseline > gpurun_out/ab/bench_$v.json 2> gpurun_out/ab/bench_$v.err || exit 1

@@ -3,6 +3,8 @@
 #   gpurun -- 'bash tools/ab_kernel_times.sh base lds3'
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out/ab
+LIB=plonky2_goldibear_amd/lib/libgoldibear_gpu.so
+cp $LIB gpurun_out/ab/.product_lib.so && trap 'cp gpurun_out/ab/.product_lib.so $LIB; rm -f gpurun_out/ab/.product_lib.so' EXIT   # the variants are copied over the product library: put it back
 WL=${GB_AB_WORKLOAD:---workload commit}
 for v in "$@"; do
     cp tools/bin/libs/$v.so plonky2_goldibear_amd/lib/libgoldibear_gpu.so
