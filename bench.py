@@ -401,7 +401,8 @@ def bind_rank_to_local_cpus(local_rank, local_world, device_index):
     except AttributeError:
         return None
     if local_world <= 1 or len(avail) < local_world:
-        print("bench.py rank-local %d: not bound (%d cpus for %d ranks)" % (local_rank, len(avail), local_world), file=sys.stderr)
+        if local_world > 1:
+            print("bench.py rank-local %d: not bound (%d cpus for %d ranks)" % (local_rank, len(avail), local_world), file=sys.stderr)
         return {"cpus": len(avail), "bound": False, "first": avail[0], "last": avail[-1]}
     near = [None] * local_world
     if device_index is not None:

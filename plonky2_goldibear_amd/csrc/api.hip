@@ -420,7 +420,10 @@ struct SegKeep {
 };
 gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                  uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr,
-                 SegKeep* keep = nullptr) {
+                 SegKeep* keep = nullptr, size_t* values_mont_cols = nullptr) {
+    // values_mont_cols (BabyBear, with values_dev): in - how many leading columns of values_dev the caller reads as device-form
+    // VALUES afterwards; out - how many leading columns of values_dev ARE in device (Montgomery) form, the rest being canonical as
+    // uploaded (the inverse transform takes canonical input where its radix-16 kernels cover the shape; otherwise all of them)
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     if (!out) return fail(ctx, GB_ERR_INVALID, "null out");
     *out = nullptr;
@@ -527,8 +530,14 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
                 ok = ok && hipMemcpyAsync(vals + c0 * n, static_cast<const u32*>(cols) + c0 * n, cc * n * 4, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
                      hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
                 if (!ok) break;
-                gbk::bb_to_mont(vals + c0 * n, vals + c0 * n, cc * n, st);
-                { Scope sc(ctx, "IFFT"); gbk::bb_intt_columns(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, *bt, st); }
+                const size_t want_mont = !values_dev ? 0 : values_mont_cols ? *values_mont_cols : ncols;
+                bool direct;
+                { Scope sc(ctx, "IFFT"); direct = gbk::bb_intt_columns_canonical(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, want_mont > c0 ? want_mont - c0 : 0, *bt, st); }
+                if (!direct) {
+                    gbk::bb_to_mont(vals + c0 * n, vals + c0 * n, cc * n, st);
+                    { Scope sc(ctx, "IFFT"); gbk::bb_intt_columns(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, *bt, st); }
+                    if (values_mont_cols) *values_mont_cols = ncols;
+                }
                 { Scope sc(ctx, "FFT + blinding"); gbk::bb_lde_columns(coeffs + c0 * n, lde + c0 * N, cc, *bt, *bc, st); }
                 if (!hash_ready_segments(c0 + cc)) return cleanup(fail(ctx, GB_ERR_OOM, "sponge state"));
             }

@@ -92,6 +92,7 @@ struct BbCosetTables {
     const u32 *pow_lo, *pow_hi;
 };
 void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
+bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncols, size_t mont_cols, const BbNttTables& t, hipStream_t stream);
 void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream);
 void bb_merkle_leaves(const u32* cols, size_t col_stride, u32 width, u64 num_leaves, u32* out, hipStream_t stream);
 void bb_merkle_leaves_segment(const u32* cols, size_t col_stride, u32 c_begin, u32 c_end, u64 num_leaves, u32* state, bool last,

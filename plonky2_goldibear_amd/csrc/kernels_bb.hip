@@ -382,12 +382,22 @@ __global__ void k_bb_transpose_to_rows(const u32* __restrict__ cols, size_t col_
 static inline u32 nblk(size_t n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 
 // radix-16 register kernels (kernels_bb16.hip); return false when the shape is not covered
-bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
+bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream,
+                         u32* canonical_src = nullptr, size_t mont_cols = 0);
 bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, u32 log_split,
                    hipStream_t stream);
 // column groups sized for the Infinity Cache: ntt_knobs() (kernels_ntt.hip)
 
 static void bb_intt_group(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
+// values -> coefficients from CANONICAL values (kernels_bb16.hip, k_bb_intt16_p1<true>): no conversion pass; the first mont_cols
+// columns of `vals` are left in Montgomery form, the rest canonical.  false: shape not covered (2^16..2^20 rows are), nothing done.
+bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncols, size_t mont_cols, const BbNttTables& t, hipStream_t stream) {
+    if (t.log_n < 16 || t.log_n > 20) return false;
+    const size_t g = std::max<size_t>(1, 2 * (size_t)ntt_knobs().intt_group), n = (size_t)1 << t.log_n;
+    for (size_t c0 = 0; c0 < ncols; c0 += g)
+        bb_intt_columns_r16(nullptr, coeffs + c0 * n, scratch, std::min(g, ncols - c0), t, stream, vals + c0 * n, mont_cols > c0 ? mont_cols - c0 : 0);
+    return true;
+}
 void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
     const size_t g = 2 * (size_t)ntt_knobs().intt_group, n = (size_t)1 << t.log_n;   // 4-byte words: twice Goldilocks' columns per group
     if (g == 0 || t.log_n < 18 || ncols <= g) return bb_intt_group(src, coeffs, scratch, ncols, t, stream);

@@ -352,10 +352,16 @@ struct BbInv16Geom {
     u32 L, LB;  // LA = LC = 8, LL = LB + 8
 };
 
-// P1: grid = ncols * 2^(LL-4); tile 256 rows (a) x 16 contiguous; rows written in natural k_a order
-__global__ __launch_bounds__(THREADS) void k_bb_intt16_p1(const u32* __restrict__ src, u32* __restrict__ dst, BbInv16Geom g,
+// P1: grid = ncols * 2^(LL-4); tile 256 rows (a) x 16 contiguous; rows written in natural k_a order.
+// WB (round 4): the input is CANONICAL - the transform is linear and every twiddle product multiplies by the twiddle's value
+// (x (w R) / R), so canonical words go through it unchanged in scale and P3's last factor n^-1 R^2 instead of n^-1 R brings the
+// coefficients out in Montgomery form: no conversion pass (k_bb_to_mont: a read and a write of the whole witness).  The columns
+// somebody reads as VALUES afterwards - the routed wires, for the permutation argument - are written back in Montgomery form
+// here, each element by the one thread that has just read it (col < mont_cols).
+template <bool WB>
+__global__ __launch_bounds__(THREADS) void k_bb_intt16_p1(const u32* src, u32* __restrict__ dst, BbInv16Geom g,
                                                           const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
-                                                          const u32* __restrict__ tw_lo) {
+                                                          const u32* __restrict__ tw_lo, u32* src_mont, u32 mont_cols) {
     __shared__ u32 sh[16 * 272];
     const u32 LL = g.LB + 8;
     const u32 tiles_per_col = 1u << (LL - 4);
@@ -366,6 +372,10 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p1(const u32* __restrict_
     u32 x[16];
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) x[a1] = src[base + ((size_t)(a1 * 16 + hi4) << LL) + j];
+    if (WB && col < mont_cols) {
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) src_mont[base + ((size_t)(a1 * 16 + hi4) << LL) + j] = bb::to_mont(x[a1]);
+    }
     u32 tw[16];
     load_tw16(tw, tw4096, hi4 * 16);
     const u32 l = (tg << 4) + j;
@@ -462,21 +472,29 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p3(const u32* __restrict_
 
 // ------------------------------------------------------------------ launchers (called from kernels_ntt.hip's dispatchers)
 
-bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
+// canonical_src != nullptr: the input is canonical (= canonical_src, writable), its first mont_cols columns are overwritten with their
+// Montgomery form, the coefficients come out in Montgomery form like those of a Montgomery-form input
+bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream,
+                         u32* canonical_src, size_t mont_cols) {
     const u32 L = t.log_n;
     if (L < 16 || L > 20) return false;
     BbInv16Geom g{L, L - 16};
     const u32 LL = g.LB + 8;
     u32* p1_dst = g.LB ? coeffs : scratch;
-    hipLaunchKernelGGL(k_bb_intt16_p1, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv,
-                       t.tw_hi_inv, t.tw_lo_inv);
+    const u32 n_inv = canonical_src ? bb::to_mont(t.n_inv) : t.n_inv;   // n^-1 R^2 : n^-1 R
+    if (canonical_src)
+        hipLaunchKernelGGL(k_bb_intt16_p1<true>, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, canonical_src, p1_dst, g, t.tw4096_inv,
+                           t.tw_hi_inv, t.tw_lo_inv, canonical_src, (u32)std::min<size_t>(mont_cols, ncols));
+    else
+        hipLaunchKernelGGL(k_bb_intt16_p1<false>, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv,
+                           t.tw_hi_inv, t.tw_lo_inv, (u32*)nullptr, 0u);
     const dim3 g2((u32)(ncols << 8));
     if (g.LB == 4) hipLaunchKernelGGL(k_bb_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv);
     else if (g.LB == 3) hipLaunchKernelGGL(k_bb_intt16_p2s<3>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
     else if (g.LB == 2) hipLaunchKernelGGL(k_bb_intt16_p2s<2>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
     else if (g.LB == 1) hipLaunchKernelGGL(k_bb_intt16_p2s<1>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
     hipLaunchKernelGGL(k_bb_intt16_p3, dim3((u32)(ncols << (g.LB + 4))), dim3(THREADS), 0, stream, scratch, coeffs, g,
-                       t.tw4096_inv, t.n_inv);
+                       t.tw4096_inv, n_inv);
     return true;
 }
 
