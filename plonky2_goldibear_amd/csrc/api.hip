@@ -418,6 +418,15 @@ struct SegKeep {
     size_t bytes = 0;
     u32 start = 0;           // first column of the last segment
 };
+// Upload chunks of a host batch, in columns: 4, 4, 8, then `full`.  The GPU's per-column work (transform + leaf hashing) is slower
+// than PCIe delivers columns, so after a short ramp the upload is hidden - what is not hidden is the wait for the FIRST columns:
+// with 4 + 4 the first 8-column hashing segment starts after ~1.5 ms of a 2^20-row Goldilocks witness (4 + 12: ~3.5 ms).
+static inline size_t first_chunks(size_t c0, size_t full) {
+    static const bool legacy = getenv("GB_UPLOAD_LEGACY_CHUNKS") != nullptr;   // rounds 2-3: 4, 12, then `full` (A/B switch)
+    if (legacy) return c0 == 0 ? 4 : c0 == 4 ? full - 4 : full;
+    return c0 < 8 ? 4 : c0 < 16 ? 8 : full;
+}
+
 gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                  uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr,
                  SegKeep* keep = nullptr, size_t* values_mont_cols = nullptr) {
@@ -525,7 +534,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             hipEvent_t e0 = evs.make(ok);                           // values_dev / coeffs may be a pool block still in use on `st`
             ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
             for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
-                cc = std::min(c0 == 0 ? (size_t)4 : c0 == 4 ? per - 4 : per, ncols - c0);  // a small first chunk: the GPU starts after 1/4 of the wait
+                cc = std::min(c0 < 32 ? 2 * first_chunks(c0 / 2, per / 2) : per, ncols - c0);   // 4-byte words: the same bytes per chunk as Goldilocks' 4, 4, 8
                 hipEvent_t copied = evs.make(ok);
                 ok = ok && hipMemcpyAsync(vals + c0 * n, static_cast<const u32*>(cols) + c0 * n, cc * n * 4, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
                      hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
@@ -548,14 +557,20 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             mark_upload(ctx);
             in_dev = scr;
         }
+        bool direct_intt = false;
         if (staged) {
         } else if (flags & GB_INPUT_DEVICE_FORM) {  // prover-internal: already Montgomery words on the device
             if (hipMemcpyAsync(coeffs, in_dev, in_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+        } else if (!is_coeffs && log_n >= 16 && log_n <= 20) {
+            // canonical values on the device (a resident witness, a small host batch): the inverse transform takes them as they are
+            Scope sc(ctx, "IFFT");
+            (void)gbk::bb_intt_columns_canonical(const_cast<u32*>(in_dev), coeffs, scr + scr_bytes / 4, ncols, 0, *bt, st);
+            direct_intt = true;
         } else {
             gbk::bb_to_mont(in_dev, coeffs, ncols * n, st);
         }
-        if (!is_coeffs && !staged) {
+        if (!is_coeffs && !staged && !direct_intt) {
             Scope sc(ctx, "IFFT");
             gbk::bb_intt_columns(coeffs, coeffs, scr + scr_bytes / 4, ncols, *bt, st);
         }
@@ -611,7 +626,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         hipEvent_t e0 = evs.make(ok);                               // values_dev may be a pool block still in use on `st`
         ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
         for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
-            cc = std::min(c0 == 0 ? (size_t)4 : c0 == 4 ? CH - 4 : CH, ncols - c0);  // a small first chunk: the GPU starts after 1/4 of the wait
+            cc = std::min(first_chunks(c0, CH), ncols - c0);
             hipEvent_t copied = evs.make(ok);
             ok = ok && hipMemcpyAsync(vals + c0 * n, src + c0 * n, cc * n * sizeof(u64), hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
                  hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;

@@ -112,11 +112,18 @@ __device__ __forceinline__ u64 fold160(u32 r0, u32 r1, u32 hl, u32 hh, u32 r4) {
 // a * b as four 32-bit limbs (gfx950 issue costs, measured: v_mad_u64_u32 4.5 cycles per wave, carry / select / 64-bit-add ops
 // ~2.9 in a mixed stream, v_mov 2.4; tools/microbench_*.hip).  Rounds 2-3 (GB_MUL_FIVE_MADS): four v_mad_u64_u32 for the partial
 // products and a fifth as an ADDER - the second carry word enters the top product as x * 1 + acc.
+#ifdef GB_MUL_FIVE_MADS
+static constexpr bool MUL_FIVE_MADS_DEFAULT = true;
+#else
+static constexpr bool MUL_FIVE_MADS_DEFAULT = false;
+#endif
+template <bool FIVE = MUL_FIVE_MADS_DEFAULT>
 __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& hl, u32& hh) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GB_MUL_FIVE_MADS)
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (!FIVE) {
     // Round 4: FOUR multiply-adds.  The second cross product takes the whole of p01 as its addend - a 64-bit register pair that
     // is already in place, where the five-mad form splits p01 into two zero-extended halves (a v_mov each) - and the one carry
     // that 64-bit sum can produce (weight 2^96) comes out in the mad's scalar carry operand and enters the top limb through a
@@ -129,7 +136,9 @@ __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& h
     asm("v_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(top), "=s"(carry_unused) : "v"((u32)(p11 >> 32)), "s"(carry));
     (void)carry_unused_lo;
     r0 = (u32)p00; r1 = (u32)m2; hl = (u32)p11; hh = top;
-#else
+    return;
+  }
+#endif
     u64 p10 = (u64)a1 * b0 + (u32)p01;
     u64 p11 = (u64)a1 * b1 + (p01 >> 32);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -139,7 +148,6 @@ __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& h
     p11 += p10 >> 32;
 #endif
     r0 = (u32)p00; r1 = (u32)p10; hl = (u32)p11; hh = (u32)(p11 >> 32);
-#endif
 }
 // (x0 + 2^32 x1 + 2^64 x2 + 2^96 x3) / 2^64 mod p as SOME u64 congruent to it: Montgomery reduction with R = 2^64, for which
 // p = 2^64 - 2^32 + 1 needs no multiplication (-1/p = -(1 + 2^32) mod 2^64):  a = lo + (lo << 32), b = a - (a >> 32) - carry,
@@ -162,9 +170,10 @@ __device__ __forceinline__ u64 mont_fold(u32 x0, u32 x1, u32 x2, u32 x3) {
 // further step (mul_mont): a, t R <= p - 1 makes the product's high word xh <= (p - 1)^2 / 2^64 < p, and mont_fold returns
 // xh - b without a borrow (<= xh < p) or xh - b + p with one (in [p - b, p - 1], b <= p - 1).  So a multiplication by a table
 // value costs 5 mads + 8 carry ops where gl::mul takes 5 + 11 + 4 (fold, then canonicalise).
+template <bool FIVE = MUL_FIVE_MADS_DEFAULT>
 __device__ __forceinline__ u64 mul_mont_lazy(u64 a, u64 t_mont) {
     u32 r0, r1, hl, hh;
-    mul_limbs(a, t_mont, r0, r1, hl, hh);
+    mul_limbs<FIVE>(a, t_mont, r0, r1, hl, hh);
     return mont_fold(r0, r1, hl, hh);
 }
 // mul_mont is mul_mont_lazy under the name that states its contract: CANONICAL operands in, canonical product out.  The NTT kernels
@@ -172,7 +181,8 @@ __device__ __forceinline__ u64 mul_mont_lazy(u64 a, u64 t_mont) {
 // mul_mont), every table entry is canonical, and the running twiddles `f <- f * ratio` (computed with mul_mont_lazy) start from
 // canonical table entries and therefore stay canonical by induction.  A lazy operand (some residue >= p) would make the product a
 // non-canonical word in memory - and a Merkle leaf that differs from the reference's; keep add_lazy-style values out of these chains.
-__device__ __forceinline__ u64 mul_mont(u64 a_canonical, u64 t_mont_canonical) { return mul_mont_lazy(a_canonical, t_mont_canonical); }
+template <bool FIVE = MUL_FIVE_MADS_DEFAULT>
+__device__ __forceinline__ u64 mul_mont(u64 a_canonical, u64 t_mont_canonical) { return mul_mont_lazy<FIVE>(a_canonical, t_mont_canonical); }
 // x R mod p on the host (table builders)
 __host__ __device__ inline u64 to_mont_slow(u64 x);
 

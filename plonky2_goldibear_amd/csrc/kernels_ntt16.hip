@@ -188,6 +188,8 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
 // ------------------------------------------------------------------ LDE pass A
 // LA = 8: grid = ncols * 256, tile 256 rows (a = 16 a1 + a0) x 16 columns.  Per coset: scale by s^(4096 a),
 // two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
+// (Its products keep round 3's five-mad form, mul_mont<true>: measured 3 % faster here than the four-mad form of gl_field.hpp, which
+// wins everywhere else - same box, tools/ab_kernel_times.sh, profiles/r04_ab_kernel_times.txt.)
 // 3 waves/SIMD (<= 168 VGPRs, no spills): the tile's 16 coefficients per thread stay in registers across the coset
 // loop, so the coefficients cross HBM once (re-reading them per coset measured the same time but 7x the fetch bytes).
 // log_split > 0: the 2^rate_bits cosets of a tile are shared among 2^log_split workgroups (a column alone then fills the chip:
@@ -222,10 +224,10 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
         for (u32 a1 = 0; a1 < 16; a1++) x[a1] = ph[a1 * 16];  // s_c^(4096 a): 16 independent loads (entry 0 is 1)
         const u64 sl = pow_lo[(size_t)c * 4096 + l];
 #pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul_mont(orig[a1], x[a1]);
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul_mont<true>(orig[a1], x[a1]);
         dft16<false>(x);
 #pragma unroll
-        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul_mont(x[s], tw256[(brev4(s) * hi4) & 255]) : x[s];  // w_256^(k_a1 a0); [k_a1 slot][a0][j]
+        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul_mont<true>(x[s], tw256[(brev4(s) * hi4) & 255]) : x[s];  // w_256^(k_a1 a0); [k_a1 slot][a0][j]
         __syncthreads();
         // stage 2 thread = (k_a1 slot = hi4, j): digit a0
 #pragma unroll
@@ -233,11 +235,11 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
         dft16<false>(x);
         u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
         // output twiddle s^l w_n^(k_a l), k_a = k_a1 + 16 k': a geometric progression in k' with ratio w_n^(16 l)
-        u64 f = gl::mul_mont_lazy(sl, f0);
+        u64 f = gl::mul_mont_lazy<true>(sl, f0);
 #pragma unroll
         for (u32 k = 0; k < 16; k++) {  // k' = k: slot brev4(k), row position = brev8(k_a)
-            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul_mont(x[brev4(k)], f);
-            if (k < 15) f = gl::mul_mont_lazy(f, ratio);
+            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul_mont<true>(x[brev4(k)], f);
+            if (k < 15) f = gl::mul_mont_lazy<true>(f, ratio);
         }
         __syncthreads();
     }
