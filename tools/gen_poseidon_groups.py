@@ -208,8 +208,10 @@ class Group:
         self.cout = [(self.Kout[q] - offB[q]) % P for q in range(12)]
 
 
-def run_group(grp, s, bias_bits=None):
-    """s: Montgomery-form state entering round r0 (constants of r0 added) -> state entering round r0 + g (its constants added)"""
+def run_group(grp, s, valu_phase_a=True):
+    """s: Montgomery-form state entering round r0 (constants of r0 added) -> state entering round r0 + g (its constants added).
+    valu_phase_a: the words u_j as the device's default computes them (64-bit unreduced sums of 32-bit halves times row 0 of M^j,
+    csrc/poseidon_gl_grouped.hpp) instead of through the phase-A operands on the matrix pipe."""
     sh = grp.shape
     g = sh.g
     y = list(s)
@@ -217,11 +219,29 @@ def run_group(grp, s, bias_bits=None):
     words = y + [0] * 4
     d = []
     if g > 1:
-        lo, hi = run_phase(sh.opsA, sh.schedA, words)
+        if valu_phase_a:
+            assert g <= 4
+            lo, hi = [], []
+            for j in range(1, g):
+                k = grp.Ku[j - 1]
+                l, h = k & 0xFFFFFFFF, k >> 32
+                for i in range(12):
+                    l += (y[i] & 0xFFFFFFFF) * sh.pw[j][0][i]
+                    h += (y[i] >> 32) * sh.pw[j][0][i]
+                assert l < (1 << 62) and h < (1 << 62)     # fold_halves takes sums below 2^63 after the d_i terms
+                lo.append(l); hi.append(h)
+            cu = [0] * (g - 1)
+        else:
+            lo, hi = run_phase(sh.opsA, sh.schedA, words)
+            cu = grp.cu
         for j in range(1, g):
-            u = (lo[j - 1] + (hi[j - 1] << 32) + grp.cu[j - 1]) % P
+            l, h = lo[j - 1], hi[j - 1]
             for i in range(1, j):
-                u = (u + d[i - 1] * sh.tri[j - i]) % P
+                l += (d[i - 1] & 0xFFFFFFFF) * sh.tri[j - i]
+                h += (d[i - 1] >> 32) * sh.tri[j - i]
+            if valu_phase_a:
+                assert l < (1 << 63) and h < (1 << 63)
+            u = (l + (h << 32) + cu[j - 1]) % P
             dj = (sbox_mont(u) - u) % P
             # the device keeps lazy residues: any u64 congruent to the value; model that with a random representative
             d.append(dj + (P if dj < (1 << 64) - P and random.random() < 0.5 else 0))
@@ -237,7 +257,7 @@ def sbox_mont(x):   # x R -> x^7 R
     return pow(x * RINV % P, 7, P) * R % P
 
 
-def permute_grouped(s, sizes):
+def permute_grouped(s, sizes, valu_phase_a=False):
     """the device's permutation: Montgomery form, full rounds as single layers, partial rounds in groups of `sizes`"""
     assert sum(sizes) == N_PARTIAL
     s = [(x * R + RC[i] * R) % P for i, x in enumerate(s)]
@@ -250,7 +270,7 @@ def permute_grouped(s, sizes):
     for _ in range(N_FULL_HALF):
         s = full(s, r); r += 1
     for g in sizes:
-        s = [lazy(v) for v in run_group(Group(SHAPES[g], r), [lazy(v) for v in s])]
+        s = [lazy(v) for v in run_group(Group(SHAPES[g], r), [lazy(v) for v in s], valu_phase_a and g <= 4)]
         r += g
     for _ in range(N_FULL_HALF):
         s = full(s, r); r += 1
@@ -268,8 +288,9 @@ def check(n=6):
     for st in states:
         want = permute_naive(st)
         for sizes in plans:
-            got = permute_grouped(st, sizes)
-            assert got == want, (sizes, st)
+            for valu in (False, True):      # phase A on the matrix pipe / as VALU dot products (the product; groups of <= 4)
+                got = permute_grouped(st, sizes, valu)
+                assert got == want, (sizes, valu, st)
     return len(states) * len(plans)
 
 
