@@ -475,11 +475,20 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     // Host input of a big batch: the leaf sponges run in segments of SEG columns as the columns arrive (chunked upload below), so
     // that the hashing - most of a commitment's time - overlaps the PCIe transfer instead of waiting for its end; the sponge state
     // waits in `seg_state` between segments (kernels_merkle.hip / kernels_bb.hip: k_*_merkle_leaves).
-    // Segment sizes: 8, 8, 16, then 32 columns.  The first segments are short so that the hashing starts as soon as the second
-    // upload chunk (16 columns) has been transformed instead of idling until 32 columns have crossed PCIe (~4.6 ms of a 2^20-row
-    // Goldilocks witness); later segments are long because every boundary parks and reloads the sponge state (0.27 GB at 2^23 leaves).
+    // Segment sizes: 8, 24, 32, then 64 columns, the last segment being what is left after the last multiple of eight (at most eight
+    // columns more).  The first segment is short so that the hashing starts as soon as eight columns have been transformed (~1.5 ms of
+    // a 2^20-row Goldilocks witness) instead of idling until more have crossed PCIe; from then on the GPU is behind the upload, and
+    // segments are long because every one of them costs a kernel's ramp and tail (~0.3 ms at 2^23 leaves: T(k absorptions) = 0.3 +
+    // 2.41 k ms, measured) and a round trip of the sponge state through HBM (0.27 GB); the last one is short because it is what an
+    // InvZeroPermArg retry hashes again (gb_prove_retry).  135 columns: 8, 24, 32, 64, 7 (rounds 2-3: 8, 8, 16, 32, 32, 32, 7).
     constexpr u32 SEG = 32;
-    auto seg_size = [](u32 done) -> u32 { return done < 16 ? 8u : (done < 32 ? 16u : SEG); };
+    auto seg_size = [ncols](u32 done) -> u32 {
+        if (done < 8) return 8u;
+        if (done < 32) return 24u;
+        if (done < 64) return 32u;
+        const u32 left = (u32)ncols - done;                 // leave the last (ragged or whole) group of eight to the last segment
+        return std::max<u32>(8u, std::min<u32>(64u, left > 1 ? 8u * ((left - 1) / 8) : 8u));
+    };
     const bool segmented = !dev_in && !is_coeffs && log_N >= 19 && ncols > SEG;
     const bool keep_split = keep && dev_in && !is_coeffs && log_N >= 19 && ncols > SEG;   // same split for device input, on request
     u32 seg_done = 0;
