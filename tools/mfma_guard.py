@@ -142,12 +142,6 @@ def check_kernel(name, body):
     return findings
 
 
-def dead_lane_reuse(name, body, window=40):
-    """Informational: VALU writes into a tile's registers before any read of the tile's last MFMA result from that register -
-    the allocator parking values in dead tile registers.  Safe at >= WAW_MIN wait states; listed so that a reader can see it."""
-    return []
-
-
 def check_text(text):
     out = []
     n = 0
