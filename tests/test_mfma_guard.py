@@ -63,3 +63,19 @@ k:
     assert n == 1 and kinds == ["RAW", "WAW", "undefined"], out
     raw = [f for f in out if f[0] == "RAW"][0]
     assert raw[3] == 10   # s_nop 9 = ten wait states: two short of what a read needs
+
+
+def test_guard_follows_loop_back_edges():
+    text = """
+k:
+	v_mov_b32_e32 v20, 0
+.LBB0_1:
+	v_add_u32_e32 v40, v3, v41
+	s_nop 15
+	v_mfma_i32_32x32x32_i8 v[0:15], v[20:23], v[20:23], 0
+	s_cbranch_scc1 .LBB0_1
+	s_nop 15
+	s_endpgm
+"""
+    n, out = mfma_guard.check_text(text)
+    assert [f[0] for f in out if f[0] != "undefined"] == ["RAW"], out      # the read at the top of the loop, one wait state after the MFMA at its bottom

@@ -14,9 +14,9 @@ order and reports, per MFMA destination tile,
   * partial: an MFMA whose accumulator operand overlaps a tile in flight without being that tile,
   * undefined: an MFMA source register that no instruction of the kernel ever writes.
 
-Wait states are counted as the hazard recognizer counts them: one per instruction, s_nop N = N + 1; a label or branch does not
-reset the count (straight-line approximation: conservative for forward flow, and loops are covered because the loop body is
-scanned with the state its fall-through predecessor left).
+Wait states are counted as the hazard recognizer counts them: one per instruction, s_nop N = N + 1.  Program order is walked once (a
+forward branch does not reset the count: conservative), and every backward branch is followed once more - the top of its loop is
+scanned with the tiles that were in flight at the bottom.
 
   python3 tools/mfma_guard.py file.s [...]        # or: --lib (compiles every csrc/*.hip to assembly first)
 """
@@ -94,47 +94,74 @@ def kernels(text):
 
 def check_kernel(name, body):
     findings = []
-    inflight = []   # [tile regs set, wait states since, text of the MFMA, line no]
     written = set()
     mfma_sources = []
     lines = body.splitlines()
+    labels = {}
     for ln, line in enumerate(lines):
-        p = parse(line)
-        if p is None:
-            continue
-        op, wr, rd = p
-        ws = 1
-        if op == "s_nop":
-            ws = int(line.split(";")[0].split()[1], 0) + 1
-        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
-            ops = split_operands(line.split(";")[0].strip().split(None, 1)[1])
-            dst = set(regs_of(ops[0]))
-            a, b = set(regs_of(ops[1])), set(regs_of(ops[2]))
-            c = set(regs_of(ops[3])) if len(ops) > 3 else set()
-            mfma_sources.append((ln, line.strip(), a | b | c))
+        m = re.match(r"^(\.?[A-Za-z_][\w$.]*):", line.strip())
+        if m:
+            labels[m.group(1)] = ln
+
+    def scan(start, inflight, limit=None, collect=True):
+        """walk from line `start` with the tiles in `inflight` ([regs, wait states, MFMA text]); limit: stop once every tile is safe"""
+        back_edges = []
+        for ln in range(start, len(lines)):
+            line = lines[ln]
+            p = parse(line)
+            if p is None:
+                continue
+            op, wr, rd = p
+            ws = 1
+            if op == "s_nop":
+                ws = int(line.split(";")[0].split()[1], 0) + 1
+            if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+                ops = split_operands(line.split(";")[0].strip().split(None, 1)[1])
+                dst = set(regs_of(ops[0]))
+                a, b = set(regs_of(ops[1])), set(regs_of(ops[2]))
+                c = set(regs_of(ops[3])) if len(ops) > 3 else set()
+                if collect:
+                    mfma_sources.append((ln, line.strip(), a | b | c))
+                for t in inflight:
+                    if t[1] < RAW_MIN and c and (c & t[0]) and c != t[0]:
+                        findings.append(("partial", name, ln, t[1], line.strip(), t[2]))
+                # a new MFMA into the same or an overlapping tile supersedes the old entry for the registers it covers
+                for t in inflight:
+                    t[0] -= dst
+                inflight = [t for t in inflight if t[0]]
+                for t in inflight:
+                    t[1] += ws
+                inflight.append([set(dst), 0, line.strip()])
+                if collect:
+                    written.update(dst)
+                continue
             for t in inflight:
-                if t[1] < RAW_MIN and c and (c & t[0]) and c != t[0]:
-                    findings.append(("partial", name, ln, t[1], line.strip(), t[2]))
-            # a new MFMA into the same or an overlapping tile supersedes the old entry for the registers it covers
+                if t[0] & set(rd) and t[1] < RAW_MIN:
+                    findings.append(("RAW", name, ln, t[1], line.strip(), t[2]))
+                if t[0] & set(wr) and t[1] < WAW_MIN:
+                    findings.append(("WAW", name, ln, t[1], line.strip(), t[2]))
+            if collect:
+                written.update(wr)
+            if op.startswith("s_cbranch") or op == "s_branch":
+                target = line.split(";")[0].split()[1]
+                if collect and target in labels and labels[target] <= ln and inflight:
+                    back_edges.append((labels[target], [[set(t[0]), t[1] + ws, t[2]] for t in inflight]))
             for t in inflight:
-                t[0] -= dst
-            inflight = [t for t in inflight if t[0]]
-            inflight.append([set(dst), 0, line.strip(), ln])
-            written |= dst
-            for t in inflight[:-1]:
                 t[1] += ws
-            continue
-        for t in inflight:
-            hit_r = t[0] & set(rd)
-            hit_w = t[0] & set(wr)
-            if hit_r and t[1] < RAW_MIN:
-                findings.append(("RAW", name, ln, t[1], line.strip(), t[2]))
-            if hit_w and t[1] < WAW_MIN:
-                findings.append(("WAW", name, ln, t[1], line.strip(), t[2]))
-        written |= set(wr)
-        for t in inflight:
-            t[1] += ws
-        inflight = [t for t in inflight if t[1] < max(RAW_MIN, WAW_MIN)]
+            inflight = [t for t in inflight if t[1] < max(RAW_MIN, WAW_MIN)]
+            if limit is not None and not inflight:
+                break
+        return back_edges
+
+    # program order first; then every loop back edge: the top of the loop with the tiles that were in flight at its bottom
+    for target, state in scan(0, []):
+        scan(target, state, limit=True, collect=False)
+    seen, unique = set(), []
+    for f in findings:
+        if f not in seen:
+            seen.add(f)
+            unique.append(f)
+    findings = unique
     for ln, text, src in mfma_sources:
         undefined = sorted(r for r in src if r not in written)
         if undefined:
