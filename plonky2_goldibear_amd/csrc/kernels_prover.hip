@@ -15,7 +15,7 @@
 // field's device form (F::T); digests and everything gathered for the proof bytes are canonical.
 #include "kernels.hpp"
 #include "poseidon2_bb.hpp"
-#include "poseidon_gl.hpp"
+#include "poseidon_gl_grouped.hpp"
 
 namespace gbk {
 
@@ -502,22 +502,26 @@ __global__ __launch_bounds__(256) void k_ext_split(const typename F::E* __restri
 // Sponge over the field's permutation, rate 8, fed with DEVICE-form elements; out() gives canonical words.
 template <class F>
 struct Sponge;
-// The Goldilocks sponge runs the permutation with its MDS layers on the matrix pipe (poseidon_gl.hpp, mds_layer_mfma), like the
-// tree kernels: init() and permute() must be reached by all 64 lanes of a wave, so the kernels below clamp the index of lanes past
+// The Goldilocks sponge runs the permutation with its MDS layers on the matrix pipe and its partial rounds in groups
+// (poseidon_gl_grouped.hpp), like the tree kernels: init() and permute() must be reached by all 64 lanes of a wave, so the kernels below clamp the index of lanes past
 // the end instead of returning early.
 template <>
 struct Sponge<GlF> {
+    static constexpr int LDS_V4 = poseidon_gl::GROUP_LDS_V4;   // the workgroup's operand table of the grouped partial rounds
     u64 s[12];
     poseidon_gl::MdsOperand amat;
-    __device__ __forceinline__ void init() {
+    const poseidon_gl::v4i* gops;
+    __device__ __forceinline__ void init(poseidon_gl::v4i* lds) {   // all threads of the workgroup (fills the table, one barrier)
         amat = poseidon_gl::mds_mfma_matrix();
+        poseidon_gl::group_ops_init(lds);
+        gops = lds + (threadIdx.x & 63);
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = 0;
     }
     __device__ __forceinline__ void permute() {   // plain lazy residues in and out, as poseidon_gl::permute_lazy
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = poseidon_gl::to_mont(s[i]);
-        poseidon_gl::permute_mont_mfma_naive(s, amat);
+        poseidon_gl::permute_mont_mfma_grouped(s, amat, gops);
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = poseidon_gl::mont_fold((u32)s[i], (u32)(s[i] >> 32), 0u, 0u);
     }
@@ -526,8 +530,9 @@ struct Sponge<GlF> {
 };
 template <>
 struct Sponge<BbF> {
+    static constexpr int LDS_V4 = 1;   // none needed
     u32 s[16];
-    __device__ __forceinline__ void init() {
+    __device__ __forceinline__ void init(poseidon_gl::v4i*) {
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = 0;
     }
@@ -556,8 +561,9 @@ __global__ __launch_bounds__(256) void k_fri_leaves(const typename F::T* __restr
             for (u32 d = 0; d < D; d++) o[D * k + d] = (T)F::dec(a[(size_t)d * len + k]);
         return;
     }
+    __shared__ poseidon_gl::v4i sponge_lds[Sponge<F>::LDS_V4];
     Sponge<F> sp;
-    sp.init();
+    sp.init(sponge_lds);
     for (u32 k0 = 0; k0 < arity; k0 += PER) {
 #pragma unroll
         for (u32 k = 0; k < PER; k++)
@@ -601,8 +607,9 @@ __global__ __launch_bounds__(256) void k_pow_grind(PowState<F> st, u64 start, u6
     const bool live = g0 < count;
     const u64 g = live ? g0 : count - 1;           // no early exit (wave-wide permutation)
     u64 cand = start + g;
+    __shared__ poseidon_gl::v4i sponge_lds[Sponge<F>::LDS_V4];
     Sponge<F> sp;
-    sp.init();
+    sp.init(sponge_lds);
     // runtime position, static register indexing
 #pragma unroll
     for (int i = 0; i < (int)F::SPONGE_W; i++) sp.set_canonical(i, (u32)i == st.pos ? (typename F::T)cand : st.s[i]);
