@@ -290,8 +290,8 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
 
 // The permutation with every MDS layer on the matrix pipe and the partial rounds in groups; same contract as
 // permute_mont_mfma_naive (Montgomery-form lazy residues in and out).  `amat` = mds_mfma_matrix(), `ops` = the workgroup's operand
-// table (group_ops_init) offset by this thread's lane.
-__device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const MdsOperand& amat, const v4i* __restrict__ ops) {
+// table (group_ops_init) offset by this thread's lane.  capacity_only: see mds_layer_mfma<Q0>.
+__device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const MdsOperand& amat, const v4i* __restrict__ ops, bool capacity_only = false) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
     for (int r = 0; r < HALF_FULL; r++) {
@@ -305,11 +305,16 @@ __device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const Md
         s[0] = sbox(s[0]);
         mds_layer_mfma(s, amat, r + 1);
     }
-    for (int r = HALF_FULL + N_PARTIAL; r < 2 * HALF_FULL + N_PARTIAL; r++) {
+    for (int r = HALF_FULL + N_PARTIAL; r + 1 < 2 * HALF_FULL + N_PARTIAL; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        mds_layer_mfma(s, amat, r + 1 < 2 * HALF_FULL + N_PARTIAL ? r + 1 : MFMA_NO_RC);
+        mds_layer_mfma(s, amat, r + 1);
     }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+    // capacity_only (uniform): a full absorption follows and overwrites words 0..7 - only words 8..11 of the output are produced
+    if (capacity_only) mds_layer_mfma<8>(s, amat, MFMA_NO_RC);
+    else mds_layer_mfma<0>(s, amat, MFMA_NO_RC);
 }
 
 }  // namespace poseidon_gl
