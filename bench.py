@@ -160,6 +160,8 @@ class ProveLeg:
             lctx = ctx if li == 0 else GpuContext(local_rank)
             if li:
                 self.extra_ctx.append(lctx)
+                for k, v in getattr(ProveLeg, "lib_options", ()):
+                    lctx.set_option(k, v)
             if bb:  # build(): once per circuit
                 circuit = CircuitData.babybear(lctx, log_n, cs_dev, k_is, num_challenges=challenges)
                 wit = DC.dummy_witness_bb(log_n, pi_row, seed=rank * inflight + li)
@@ -183,11 +185,25 @@ class ProveLeg:
         del cs, cs_dev
         torch.cuda.synchronize()
 
-    def set_witness(self, host):
-        """host=True: page-locked host memory, as a host that wants the PCIe rate allocates it (hipHostMalloc); False: HBM."""
+    def to_p3_words(self, a):
+        """canonical values -> the words the reference's field types hold in memory (GB_INPUT_P3_REPR): p3-baby-bear's Montgomery
+        word x 2^32 mod p; p3-goldilocks keeps a u64 representative, for which the canonical one is as good as any"""
+        if not self.bb:
+            return a
+        return ((a.astype(np.uint64) << np.uint64(32)) % np.uint64(2013265921)).astype(np.uint32)
+
+    def set_witness(self, where):
+        """"pinned": one contiguous block of page-locked host memory, as a host that wants the PCIe rate allocates it (hipHostMalloc);
+        "hbm": already resident on the device; "vecs": the layout the reference itself has - MatrixWitness.wire_values is Vec<Vec<F>>
+        (iop/witness.rs:277-279): num_wires separately malloc'ed, PAGEABLE columns holding the field type's in-memory words,
+        handed over as a pointer table (gb_prove_cols + GB_INPUT_P3_REPR) and staged by the library's own page-locked ring."""
+        self.where = where
         for lane in self.lanes:
+            if where == "vecs":
+                lane[3] = [np.array(self.to_p3_words(col), copy=True) for col in lane[2]]
+                continue
             t = self.torch.from_numpy(lane[2].view(self.idt))
-            lane[3] = t.pin_memory().numpy().view(lane[2].dtype) if host else t.to(self.dev)
+            lane[3] = t.pin_memory().numpy().view(lane[2].dtype) if where == "pinned" else t.to(self.dev)
         self.torch.cuda.synchronize()
 
     def next_witness(self):
@@ -197,11 +213,14 @@ class ProveLeg:
         self.step_no += 1
         for li, lane in enumerate(self.lanes):
             row = self.rows[li][k]
-            if isinstance(lane[3], np.ndarray):
+            if isinstance(lane[3], list):
+                for col, v in zip(lane[3], self.to_p3_words(row)):
+                    col[self.pi_row] = v
+            elif isinstance(lane[3], np.ndarray):
                 lane[3][:, self.pi_row] = row
             else:
                 lane[3][:, self.pi_row] = self.torch.from_numpy(row.view(self.idt)).to(self.dev)
-        if not isinstance(self.lanes[0][3], np.ndarray):
+        if self.where == "hbm":
             self.torch.cuda.synchronize()
 
     def step(self):
@@ -209,14 +228,15 @@ class ProveLeg:
         t0 = time.perf_counter()
         if self.inflight == 1:
             lctx, circuit, _, wit = self.lanes[0]
-            self.proof = circuit.prove(wit, random_wire=self.random_wire, rng=self.rng[0])
+            self.proof = circuit.prove(wit, random_wire=self.random_wire, rng=self.rng[0], p3_repr=self.where == "vecs")
             self.retries += circuit.perm_arg_retries
             self.step_log.append((time.perf_counter() - t0, circuit.perm_arg_retries))
         else:
             out, ret = [None] * self.inflight, [0] * self.inflight
 
             def run(i):
-                out[i] = self.lanes[i][1].prove(self.lanes[i][3], random_wire=self.random_wire, rng=self.rng[i])
+                out[i] = self.lanes[i][1].prove(self.lanes[i][3], random_wire=self.random_wire, rng=self.rng[i],
+                                                p3_repr=self.where == "vecs")
                 ret[i] = self.lanes[i][1].perm_arg_retries
             ts = [threading.Thread(target=run, args=(i,)) for i in range(self.inflight)]
             for t in ts:
@@ -235,10 +255,10 @@ class ProveLeg:
         self.torch.cuda.synchronize()
         sharding.barrier()
 
-    def timed(self, steps, warmup, host):
+    def timed(self, steps, warmup, where):
         """W untimed steps, then exactly K steps between barriers; returns (seconds = max over ranks, scopes, retries)."""
         from plonky2_goldibear_amd import sharding
-        self.set_witness(host)
+        self.set_witness(where)
         self.rng = [np.random.default_rng(1234 + self.rank * self.inflight + i) for i in range(self.inflight)]
         self.step_no, self.step_log = 0, []
         for _ in range(warmup):
@@ -488,6 +508,9 @@ def workload_name(leg, witness):
 
 
 HOST_W = "in page-locked host memory, handed over every step"
+VECS_W = ("the reference's own layout (MatrixWitness.wire_values: Vec<Vec<F>>, iop/witness.rs:277-279): %d separately malloc'ed PAGEABLE "
+          "numpy columns holding the field type's in-memory words, handed over every step as a table of %d pointers "
+          "(gb_prove_cols, GB_INPUT_P3_REPR) and staged through the library's page-locked ring by its copy threads")
 N_WITNESSES = 16   # pinned witness seeds a leg cycles through
 
 
@@ -511,6 +534,9 @@ def main():
     ap.add_argument("--no-babybear", action="store_true", help="skip the BASELINE configs[3] leg of the default run")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident-witness leg (value_hbm_resident)")
     ap.add_argument("--no-inflight2", action="store_true", help="skip the two-proofs-in-flight legs (value_inflight2)")
+    ap.add_argument("--no-vecs", action="store_true", help="skip the Vec<Vec<F>> legs (value_vec_of_vecs)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="KEY=VALUE",
+                    help="gb_ctx_set_option on every context of the run (copy_threads, lde_group, intt_group, ...), repeatable")
     ap.add_argument("--host-witness", action="store_true", help="(default since round 2; kept for old command lines)")
     args = ap.parse_args()
 
@@ -555,12 +581,16 @@ def main():
 
     log_n, rate_bits, cap_height = args.log_n, 3, 4
     ctx = GpuContext(local_rank)
+    lib_options = [(kv.split("=", 1)[0], int(kv.split("=", 1)[1])) for kv in args.lib_option]
+    for k, v in lib_options:
+        ctx.set_option(k, v)
+    ProveLeg.lib_options = lib_options
     out = None
     if args.workload == "prove":
         inflight = max(1, args.inflight)
         steps = args.steps
         leg = ProveLeg(args.field, log_n, args.challenges, local_rank, rank, inflight, ctx)
-        dt, scopes, retries = leg.timed(steps, args.warmup, host=True)
+        dt, scopes, retries = leg.timed(steps, args.warmup, "pinned")
         if rank == 0:
             out = {
                 "metric": "proofs/s", "value": world * steps * inflight / dt, "unit": "proofs/s", "n_gpus": world, "steps": steps,
@@ -579,16 +609,23 @@ def main():
             out["affinity"] = affinity
             out["control_plane"] = control_plane
         if not args.no_resident:
-            dt2, scopes2, _ = leg.timed(steps, args.warmup, host=False)
+            dt2, scopes2, _ = leg.timed(steps, args.warmup, "hbm")
             if rank == 0:
                 out["value_hbm_resident"] = world * steps * inflight / dt2
                 out["ms_per_step_hbm_resident"] = dt2 / steps * 1e3
+        if not args.no_vecs:
+            dtv, scopesv, _ = leg.timed(steps, args.warmup, "vecs")
+            if rank == 0:
+                out["value_vec_of_vecs"] = world * steps * inflight / dtv
+                out["ms_per_step_vec_of_vecs"] = dtv / steps * 1e3
+                out["vec_of_vecs"] = VECS_W % (leg.nwires, leg.nwires)
+                out["scopes_ms_per_step_vec_of_vecs"] = {k: v[0] / steps for k, v in scopesv.items() if v[1]}
         leg.free()
         del leg
         second = not args.no_inflight2 and inflight == 1   # SURVEY.md 8(d) counts a stream of independent proofs: two of them in
         if second:                                          # flight per GPU (one host thread + one stream each), host witnesses
             leg2 = ProveLeg(args.field, log_n, args.challenges, local_rank, rank, 2, ctx)
-            dt3, _, _ = leg2.timed(steps, args.warmup, host=True)
+            dt3, _, _ = leg2.timed(steps, args.warmup, "pinned")
             if rank == 0:
                 out["value_inflight2"] = world * steps * 2 / dt3
                 out["ms_per_step_inflight2"] = dt3 / steps * 1e3    # one step = two proofs
@@ -597,7 +634,7 @@ def main():
         if args.field == "goldilocks" and world == 1 and not args.no_babybear and log_n == 20:
             # BASELINE configs[3]: the same measurements for BabyBear + Poseidon2-16 (a 31-bit field needs num_challenges = 10)
             bleg = ProveLeg("babybear", log_n, None, local_rank, rank, inflight, ctx)
-            bdt, bscopes, bret = bleg.timed(steps, args.warmup, host=True)
+            bdt, bscopes, bret = bleg.timed(steps, args.warmup, "pinned")
             bb = {"metric": "proofs/s", "value": steps * inflight / bdt, "ms_per_step": bdt / steps * 1e3, "dtype": "u32",
                   "config": {"workload": workload_name(bleg, HOST_W), "witness": HOST_W}}
             bb.update(bleg.report(steps, bscopes, inflight, bret))
@@ -606,13 +643,18 @@ def main():
             bb["perm_arg_retries"] = bret     # at their natural rate: `value` has the re-done proofs inside, value_no_retry has not
             bb["value_no_retry"] = _num(bleg.no_retry_rate())
             if not args.no_resident:
-                bdt2, _, _ = bleg.timed(steps, args.warmup, host=False)
+                bdt2, _, _ = bleg.timed(steps, args.warmup, "hbm")
                 bb["value_hbm_resident"] = steps * inflight / bdt2
                 bb["ms_per_step_hbm_resident"] = bdt2 / steps * 1e3
+            if not args.no_vecs:
+                bdtv, _, _ = bleg.timed(steps, args.warmup, "vecs")
+                bb["value_vec_of_vecs"] = steps * inflight / bdtv
+                bb["ms_per_step_vec_of_vecs"] = bdtv / steps * 1e3
+                bb["vec_of_vecs"] = VECS_W % (bleg.nwires, bleg.nwires)
             bleg.free()
             if second:
                 bleg2 = ProveLeg("babybear", log_n, None, local_rank, rank, 2, ctx)
-                bdt3, _, _ = bleg2.timed(steps, args.warmup, host=True)
+                bdt3, _, _ = bleg2.timed(steps, args.warmup, "pinned")
                 bb["value_inflight2"] = steps * 2 / bdt3
                 bb["ms_per_step_inflight2"] = bdt3 / steps * 1e3
                 bleg2.free()

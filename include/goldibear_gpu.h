@@ -15,7 +15,9 @@
  *    which is how independent proofs shard one-per-GPU;
  *  - field elements are canonical little-endian u64 (Goldilocks) / u32 (BabyBear);
  *  - matrices are COLUMN-MAJOR [ncols][n]: the layout of Vec<PolynomialValues<F>>
- *    (iop/witness.rs:277-284) with the per-column Vecs laid end to end;
+ *    (iop/witness.rs:277-284) with the per-column Vecs laid end to end; the *_cols entry points take the columns where the
+ *    reference has them - ncols separately allocated arrays (`const void* const* cols`, cols[i] = n elements), pageable or
+ *    page-locked, no flattening copy on the host side;
  *  - gb_batch is an opaque device-resident handle; nothing large is copied back unless asked;
  *  - host input buffers (`cols`, `salts`, `witness`, `constants_sigmas`, ...) belong to the caller again as soon as the call
  *    returns (the reference moves its Vecs in): gb_commit_* wait for their uploads - not for the kernels behind them - before
@@ -46,14 +48,15 @@ enum {
 
 enum { GB_GOLDILOCKS = 0, GB_BABYBEAR = 1 }; /* field tag: F = Goldilocks (Poseidon-12) | BabyBear (Poseidon2-16) */
 
+/* `flags` of the entry points that take field-element matrices; any other bit is GB_ERR_INVALID */
 enum {
-    GB_INPUT_HOST = 0,   /* `cols` / `salts` are host pointers (the drop-in case) */
+    GB_INPUT_HOST = 0,   /* `cols` / `salts` / `witness` are host pointers (the drop-in case) */
     GB_INPUT_DEVICE = 1, /* they are device pointers on ctx's device (chained calls, benchmarks) */
-    /* gb_prove only, TEST HOOK: behave as if the permutation argument had found a zero denominator (prover.rs:512-514) once the
-     * Z computation is done - return GB_ERR_PERM_ARG_ZERO and keep what gb_prove_retry builds on, exactly as the real error
-     * does.  In a 64-bit field the real error has probability ~2^-37 per 2^20-row proof: this is how the retry path of a
-     * Goldilocks circuit is exercised (tests/test_gpu_prove.py). */
-    GB_PROVE_FAIL_PERM_ARG = 0x200
+    /* host inputs only: the elements are the reference's field types AS THEY LIE IN MEMORY (Cargo.toml:17-24 - p3-goldilocks:
+     * any u64 representative of the value, not necessarily below p; p3-baby-bear / p3-monty-31: the Montgomery word
+     * x * 2^32 mod p), so a Vec<F> is handed over without an as_canonical_*() pass.  Without it elements are canonical.
+     * Applies to `cols` / `witness` / `salts`; results (proof bytes, accessors) are canonical either way. */
+    GB_INPUT_P3_REPR = 2
 };
 
 #define GB_SALT_SIZE 4 /* fri/oracle.rs:25 */
@@ -68,6 +71,27 @@ gb_status gb_ctx_synchronize(gb_ctx* ctx);
 gb_status gb_ctx_trim(gb_ctx* ctx);
 /* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
 gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out);
+/* Tuning and debugging switches; none changes a result.  Unknown key / value out of range: GB_ERR_INVALID.
+ *   "copy_threads"   threads of the context that stage PAGEABLE host columns into the library's page-locked ring (below):
+ *                    default 4; 0 = the calling thread copies; -1 = no ring, hipMemcpyAsync straight from pageable memory
+ *   "retry_verify"   1: gb_prove_retry first compares the caller's whole matrix with the copy the failed attempt kept and
+ *                    returns GB_ERR_INVALID if they differ in more than witness[wire][row] (one read-back of the witness)
+ *   "upload_legacy_chunks", "lde_group", "pa_log_split", "intt_group"   A/B switches of DESIGN.md section 4 (the last three
+ *                    are process-wide) */
+gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value);
+
+/* ---- host memory ---------------------------------------------------------------------------
+ * The reference's inputs are pageable Vecs (MatrixWitness.wire_values: Vec<Vec<F>>, iop/witness.rs:277-279;
+ * Vec<PolynomialValues<F>>, fri/oracle.rs:68-75).  Every host input may be pageable: big batches are staged through a
+ * page-locked ring the context owns (256 MiB, allocated at the first such call) by its copy threads, column by column, while
+ * the columns before are transformed and hashed.  A host that can place its columns itself skips that copy: memory from
+ * gb_host_alloc (hipHostMalloc) or registered with gb_host_register (hipHostRegister; unregister before freeing it) is read by
+ * the copy engine directly - e.g. an allocator for the witness columns.  Registration costs about as much as one copy: it pays
+ * for buffers that are reused. */
+gb_status gb_host_alloc(gb_ctx* ctx, size_t bytes, void** out);
+gb_status gb_host_free(gb_ctx* ctx, void* p);
+gb_status gb_host_register(gb_ctx* ctx, void* p, size_t bytes);
+gb_status gb_host_unregister(gb_ctx* ctx, void* p);
 
 /* ---- timing: the reference's timed!() scopes (util/proving_process_info.rs:196-212) ---------
  * With profiling on, each commit records HIP events on ctx's stream around the scopes
@@ -92,6 +116,14 @@ gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t
 gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n,
                            uint32_t rate_bits, uint32_t cap_height, const void* salts, uint32_t flags,
                            gb_batch** out);
+/* The same two constructors over the reference's own layout: cols[i] points to column i (n elements), each column its own
+ * allocation - `values: Vec<PolynomialValues<F>>` / `polynomials: Vec<PolynomialCoeffs<F>>` (fri/oracle.rs:68-75, :93-100)
+ * with cols[i] = values[i].values.as_ptr().  Host columns may be pageable (staged by the library, see "host memory") or
+ * page-locked; with GB_INPUT_DEVICE they are device pointers.  `salts` stays one block of GB_SALT_SIZE columns. */
+gb_status gb_commit_values_cols(gb_ctx* ctx, uint32_t field, const void* const* cols, size_t ncols, uint32_t log_n,
+                                uint32_t rate_bits, uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out);
+gb_status gb_commit_coeffs_cols(gb_ctx* ctx, uint32_t field, const void* const* cols, size_t ncols, uint32_t log_n,
+                                uint32_t rate_bits, uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out);
 gb_status gb_batch_free(gb_batch* b);
 
 /* shape queries: .polynomials.len(), .degree_log, .rate_bits, .blinding (oracle.rs:35-39) */
@@ -239,10 +271,18 @@ gb_status gb_prove(gb_circuit* c, const void* witness, uint32_t flags, const uin
  * commitment, the device copy of a host witness, the leaf sponges' state: ~12 GB at 2^20 Goldilocks rows) is held until the next
  * gb_prove* / gb_circuit_free on the circuit, gb_circuit_drop_retry, gb_ctx_trim - or until an allocation on the context would
  * otherwise fail.  A host retry trusts the kept device copy for every element but witness[wire][row]: a caller that changed anything
- * else must call gb_prove.  (GB_RETRY_VERIFY=1 in the environment makes the library compare the whole matrix with the kept copy
- * first - a debugging aid, one read-back of the witness - and return GB_ERR_INVALID when they differ elsewhere.) */
+ * else must call gb_prove.  (gb_ctx_set_option(ctx, "retry_verify", 1) makes the library compare the whole matrix with the kept
+ * copy first - a debugging aid, one read-back of the witness - and return GB_ERR_INVALID when they differ elsewhere.) */
 gb_status gb_prove_retry(gb_circuit* c, const void* witness, uint32_t flags, uint32_t wire, uint64_t row, const uint64_t* public_inputs,
                          size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);
+/* gb_prove / gb_prove_retry / gb_prove_salted over MatrixWitness.wire_values as the reference holds it (iop/witness.rs:277-279:
+ * Vec<Vec<F>>): wire_cols[w] points to the n = 2^degree_bits values of wire w, every column its own (pageable or page-locked)
+ * allocation - wire_cols[w] = witness.wire_values[w].as_ptr(), no flattening copy.  Same results, same errors. */
+gb_status gb_prove_cols(gb_circuit* c, const void* const* wire_cols, uint32_t flags, const uint64_t* public_inputs,
+                        size_t num_public_inputs, void* proof_out, size_t proof_cap, size_t* proof_len);
+gb_status gb_prove_retry_cols(gb_circuit* c, const void* const* wire_cols, uint32_t flags, uint32_t wire, uint64_t row,
+                              const uint64_t* public_inputs, size_t num_public_inputs, void* proof_out, size_t proof_cap,
+                              size_t* proof_len);
 /* Release what a failed attempt left behind without proving again - a caller that gives up after GB_ERR_PERM_ARG_ZERO
  * (ProverError::TooManyPermArgFailures, prover.rs:221-225).  No-op when nothing is held. */
 gb_status gb_circuit_drop_retry(gb_circuit* c);
@@ -254,6 +294,8 @@ gb_status gb_circuit_drop_retry(gb_circuit* c);
  * blind_and_pad) are the builder's business and part of `witness`. */
 gb_status gb_prove_salted(gb_circuit* c, const void* witness, uint32_t flags, const uint64_t* public_inputs,
                           size_t num_public_inputs, const void* salts, void* proof_out, size_t proof_cap, size_t* proof_len);
+gb_status gb_prove_salted_cols(gb_circuit* c, const void* const* wire_cols, uint32_t flags, const uint64_t* public_inputs,
+                               size_t num_public_inputs, const void* salts, void* proof_out, size_t proof_cap, size_t* proof_len);
 
 /* verify() of a proof produced for this circuit (plonk/verifier.rs:17-128, fri/verifier.rs:67-250,
  * plonk/get_challenges.rs:26-101), restated for the dummy gate set and run on the HOST like the reference's verifier: the
@@ -294,6 +336,9 @@ gb_status gb_verifier_create(gb_ctx* ctx, const gb_circuit_config* cfg, const gb
  * challenge's Z first, then each challenge's partial products.  GB_ERR_PERM_ARG_ZERO = ProverError::InvZeroPermArg (:512-514). */
 gb_status gb_zs_partial_products(gb_circuit* c, const void* witness, uint32_t flags, const void* betas, const void* gammas,
                                  void* values_out);
+/* the same with the witness as separately allocated columns (only wire_cols[0 .. num_routed_wires) are read) */
+gb_status gb_zs_partial_products_cols(gb_circuit* c, const void* const* wire_cols, uint32_t flags, const void* betas,
+                                      const void* gammas, void* values_out);
 /* compute_quotient_polys (plonk/prover.rs:712-926) followed by the split into degree-n chunks (:345-376).  wires and
  * zs_partial_products are the commitments of the same proof (gb_commit_values of the witness / of gb_zs_partial_products' output),
  * made on this circuit's context; public_inputs_hash: [H]; betas, gammas, alphas: [num_challenges].  chunks_out:

@@ -1,9 +1,13 @@
 //! Safe wrappers over the C ABI of `libgoldibear_gpu.so` (`include/goldibear_gpu.h`).
 //!
-//! This is the shim the reference crate would depend on under a `gpu-mi355x` feature: field elements
-//! cross the boundary as canonical little-endian words (`u64` Goldilocks, `u32` BabyBear), which is what
-//! `as_canonical_u64()` / `as_canonical_u32()` give.  Written against the header; not compiled in this repository
-//! (the build image has no Rust toolchain).
+//! This is the shim the reference crate would depend on under a `gpu-mi355x` feature.  Field elements
+//! cross the boundary either as canonical little-endian words (`u64` Goldilocks, `u32` BabyBear - what
+//! `as_canonical_u64()` / `as_canonical_u32()` give; `Repr::Canonical`) or exactly as the reference's field types lie
+//! in memory (`Repr::P3InMemory` = `GB_INPUT_P3_REPR`: p3-goldilocks' possibly non-canonical `u64`, p3-baby-bear's
+//! Montgomery `u32`), in which case a `Vec<F>` is handed over without any conversion pass.  Matrices are taken where the
+//! reference has them: the `*_columns` methods bind the `*_cols` entry points, which read `Vec<Vec<F>>` /
+//! `Vec<PolynomialValues<F>>` column by column from pageable memory - no flattening copy on the host.
+//! Written against the header; not compiled in this repository (the build image has no Rust toolchain).
 use std::ffi::{c_char, c_void, CStr};
 use std::ptr;
 
@@ -21,6 +25,7 @@ pub const GB_ERR_VERIFY: i32 = 19;
 pub const GB_GOLDILOCKS: u32 = 0;
 pub const GB_BABYBEAR: u32 = 1;
 pub const GB_INPUT_HOST: u32 = 0;
+pub const GB_INPUT_P3_REPR: u32 = 2;
 pub const GB_MAX_FRI_LAYERS: usize = 32;
 
 #[repr(C)]
@@ -73,10 +78,46 @@ pub struct gb_challenger_state {
     pub output_len: u32,
 }
 
+/// How the words of a host matrix encode field elements (`flags` of the entry points that take matrices).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Repr {
+    /// canonical values (`as_canonical_u64()` / `as_canonical_u32()`)
+    Canonical,
+    /// the reference's field types as they lie in memory (`GB_INPUT_P3_REPR`): `transmute`-compatible with `Vec<F>`
+    P3InMemory,
+}
+impl Repr {
+    fn flags(self) -> u32 {
+        match self {
+            Repr::Canonical => GB_INPUT_HOST,
+            Repr::P3InMemory => GB_INPUT_HOST | GB_INPUT_P3_REPR,
+        }
+    }
+}
+
 extern "C" {
     fn gb_ctx_create(device: i32, out: *mut *mut gb_ctx) -> i32;
     fn gb_ctx_destroy(ctx: *mut gb_ctx) -> i32;
     fn gb_last_error(ctx: *const gb_ctx) -> *const c_char;
+    fn gb_ctx_set_option(ctx: *mut gb_ctx, key: *const c_char, value: i64) -> i32;
+    fn gb_host_alloc(ctx: *mut gb_ctx, bytes: usize, out: *mut *mut c_void) -> i32;
+    fn gb_host_free(ctx: *mut gb_ctx, p: *mut c_void) -> i32;
+    fn gb_host_register(ctx: *mut gb_ctx, p: *mut c_void, bytes: usize) -> i32;
+    fn gb_host_unregister(ctx: *mut gb_ctx, p: *mut c_void) -> i32;
+    fn gb_commit_values_cols(ctx: *mut gb_ctx, field: u32, cols: *const *const c_void, ncols: usize, log_n: u32, rate_bits: u32,
+                             cap_height: u32, salts: *const c_void, flags: u32, out: *mut *mut gb_batch) -> i32;
+    fn gb_commit_coeffs_cols(ctx: *mut gb_ctx, field: u32, cols: *const *const c_void, ncols: usize, log_n: u32, rate_bits: u32,
+                             cap_height: u32, salts: *const c_void, flags: u32, out: *mut *mut gb_batch) -> i32;
+    fn gb_prove_cols(c: *mut gb_circuit, wire_cols: *const *const c_void, flags: u32, public_inputs: *const u64,
+                     num_public_inputs: usize, proof_out: *mut c_void, proof_cap: usize, proof_len: *mut usize) -> i32;
+    fn gb_prove_retry_cols(c: *mut gb_circuit, wire_cols: *const *const c_void, flags: u32, wire: u32, row: u64,
+                           public_inputs: *const u64, num_public_inputs: usize, proof_out: *mut c_void, proof_cap: usize,
+                           proof_len: *mut usize) -> i32;
+    fn gb_prove_salted_cols(c: *mut gb_circuit, wire_cols: *const *const c_void, flags: u32, public_inputs: *const u64,
+                            num_public_inputs: usize, salts: *const c_void, proof_out: *mut c_void, proof_cap: usize,
+                            proof_len: *mut usize) -> i32;
+    fn gb_zs_partial_products_cols(c: *mut gb_circuit, wire_cols: *const *const c_void, flags: u32, betas: *const c_void,
+                                   gammas: *const c_void, values_out: *mut c_void) -> i32;
     fn gb_commit_values(ctx: *mut gb_ctx, field: u32, cols: *const c_void, ncols: usize, log_n: u32, rate_bits: u32,
                         cap_height: u32, salts: *const c_void, flags: u32, out: *mut *mut gb_batch) -> i32;
     fn gb_commit_coeffs(ctx: *mut gb_ctx, field: u32, cols: *const c_void, ncols: usize, log_n: u32, rate_bits: u32,
@@ -154,6 +195,79 @@ impl GpuContext {
         check(ptr::null(), unsafe { gb_ctx_create(device, &mut h) })?;
         Ok(GpuContext(h))
     }
+    /// Tuning / debugging switches (`gb_ctx_set_option`): "copy_threads", "retry_verify", ...; none changes a result.
+    pub fn set_option(&self, key: &str, value: i64) -> Result<(), GpuError> {
+        let k = std::ffi::CString::new(key).map_err(|_| GpuError { status: GB_ERR_INVALID, message: "key holds a NUL".into() })?;
+        check(self.0, unsafe { gb_ctx_set_option(self.0, k.as_ptr(), value) })
+    }
+    /// Page-locked memory for `len` words (hipHostMalloc): columns built here go to the copy engine without the library's staging
+    /// copy.  The natural use is an allocator for the witness columns (`MatrixWitness.wire_values`).
+    pub fn host_alloc<W: Copy + Default>(&self, len: usize) -> Result<PinnedBuf<'_, W>, GpuError> {
+        let mut p = ptr::null_mut();
+        check(self.0, unsafe { gb_host_alloc(self.0, len * std::mem::size_of::<W>(), &mut p) })?;
+        let buf = PinnedBuf { ctx: self, ptr: p as *mut W, len };
+        unsafe { std::slice::from_raw_parts_mut(buf.ptr, len) }.fill(W::default());
+        Ok(buf)
+    }
+    /// Page-lock an existing buffer in place (hipHostRegister) for as long as the guard lives; pays for buffers that are reused.
+    pub fn host_register<'a, W>(&'a self, buf: &'a mut [W]) -> Result<Registered<'a, W>, GpuError> {
+        check(self.0, unsafe { gb_host_register(self.0, buf.as_mut_ptr() as *mut c_void, std::mem::size_of_val(buf)) })?;
+        Ok(Registered { ctx: self, buf })
+    }
+}
+/// `len` words of page-locked host memory owned by the library's allocator (`gb_host_alloc` / `gb_host_free`).
+pub struct PinnedBuf<'c, W> {
+    ctx: &'c GpuContext,
+    ptr: *mut W,
+    len: usize,
+}
+impl<'c, W> std::ops::Deref for PinnedBuf<'c, W> {
+    type Target = [W];
+    fn deref(&self) -> &[W] {
+        unsafe { std::slice::from_raw_parts(self.ptr, self.len) }
+    }
+}
+impl<'c, W> std::ops::DerefMut for PinnedBuf<'c, W> {
+    fn deref_mut(&mut self) -> &mut [W] {
+        unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+impl<'c, W> Drop for PinnedBuf<'c, W> {
+    fn drop(&mut self) {
+        unsafe { gb_host_free(self.ctx.0, self.ptr as *mut c_void) };
+    }
+}
+/// A caller's buffer page-locked in place (`gb_host_register`); unregistered on drop.
+pub struct Registered<'a, W> {
+    ctx: &'a GpuContext,
+    buf: &'a mut [W],
+}
+impl<'a, W> std::ops::Deref for Registered<'a, W> {
+    type Target = [W];
+    fn deref(&self) -> &[W] {
+        self.buf
+    }
+}
+impl<'a, W> std::ops::DerefMut for Registered<'a, W> {
+    fn deref_mut(&mut self) -> &mut [W] {
+        self.buf
+    }
+}
+impl<'a, W> Drop for Registered<'a, W> {
+    fn drop(&mut self) {
+        unsafe { gb_host_unregister(self.ctx.0, self.buf.as_mut_ptr() as *mut c_void) };
+    }
+}
+
+/// The pointer table of the `*_cols` entry points: one pointer per separately allocated column, every column `n` words long.
+/// Nothing is copied: `columns[i]` is `values[i].values.as_slice()` / `witness.wire_values[i].as_slice()`.
+fn column_table<W, C: AsRef<[W]>>(what: &str, columns: &[C], n: usize) -> Result<Vec<*const c_void>, GpuError> {
+    let mut table = Vec::with_capacity(columns.len());
+    for (i, c) in columns.iter().enumerate() {
+        need(&format!("{what}[{i}]"), c.as_ref().len(), n)?;
+        table.push(c.as_ref().as_ptr() as *const c_void);
+    }
+    Ok(table)
 }
 impl Drop for GpuContext {
     fn drop(&mut self) {
@@ -203,6 +317,37 @@ impl<'c, W: Copy + Default> GpuPolynomialBatch<'c, W> {
             f(ctx.0, field_tag::<W>(), cols.as_ptr() as *const c_void, num_polys, degree_log, rate_bits, cap_height, sp, GB_INPUT_HOST, &mut h)
         })?;
         Ok(Self { ctx, handle: h, num_polys, degree_log, rate_bits, cap_height, blinding: salts.is_some(), _w: std::marker::PhantomData })
+    }
+    /// `PolynomialBatch::from_values` (oracle.rs:68-90) over `values: Vec<PolynomialValues<F>>` AS IT IS: `columns[i]` =
+    /// `values[i].values` - separately allocated, pageable - handed over as a pointer table (`gb_commit_values_cols`).
+    pub fn from_value_columns<C: AsRef<[W]>>(ctx: &'c GpuContext, columns: &[C], rate_bits: u32, cap_height: u32, salts: Option<&[W]>,
+                                             repr: Repr) -> Result<Self, GpuError> {
+        Self::commit_columns(ctx, columns, rate_bits, cap_height, salts, repr, false)
+    }
+    /// `PolynomialBatch::from_coeffs` (oracle.rs:93-123) over `polynomials: Vec<PolynomialCoeffs<F>>` (`gb_commit_coeffs_cols`)
+    pub fn from_coeff_columns<C: AsRef<[W]>>(ctx: &'c GpuContext, columns: &[C], rate_bits: u32, cap_height: u32, salts: Option<&[W]>,
+                                             repr: Repr) -> Result<Self, GpuError> {
+        Self::commit_columns(ctx, columns, rate_bits, cap_height, salts, repr, true)
+    }
+    fn commit_columns<C: AsRef<[W]>>(ctx: &'c GpuContext, columns: &[C], rate_bits: u32, cap_height: u32, salts: Option<&[W]>,
+                                     repr: Repr, coeffs: bool) -> Result<Self, GpuError> {
+        assert!(!columns.is_empty());   // oracle.rs:101
+        let n = columns[0].as_ref().len();
+        assert!(n.is_power_of_two());
+        let degree_log = n.trailing_zeros();
+        let table = column_table("columns", columns, n)?;
+        if let Some(s) = salts {
+            need("salts", s.len(), 4 * (n << rate_bits))?;
+        }
+        let sp = salts.map_or(ptr::null(), |s| s.as_ptr() as *const c_void);
+        let f = if coeffs { gb_commit_coeffs_cols } else { gb_commit_values_cols };
+        let mut h = ptr::null_mut();
+        // the columns (and salts) are the caller's again when the call returns: the library has staged or uploaded them
+        check(ctx.0, unsafe {
+            f(ctx.0, field_tag::<W>(), table.as_ptr(), table.len(), degree_log, rate_bits, cap_height, sp, repr.flags(), &mut h)
+        })?;
+        Ok(Self { ctx, handle: h, num_polys: columns.len(), degree_log, rate_bits, cap_height, blinding: salts.is_some(),
+                  _w: std::marker::PhantomData })
     }
     fn hash_len() -> usize {
         if std::mem::size_of::<W>() == 8 { 4 } else { 8 }
@@ -385,6 +530,78 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         check(self.ctx.0, st)?;
         buf.truncate(len);
         Ok(ProveOutcome::Proof(buf))
+    }
+    fn finish_proof(&self, st: i32, mut buf: Vec<u8>, len: usize) -> Result<ProveOutcome, GpuError> {
+        if st == GB_ERR_PERM_ARG_ZERO {
+            return Ok(ProveOutcome::PermArgZero);
+        }
+        check(self.ctx.0, st)?;
+        buf.truncate(len);
+        Ok(ProveOutcome::Proof(buf))
+    }
+    /// `internal_prove_with_partition_witness` (plonk/prover.rs:228-447) from `MatrixWitness.wire_values` AS IT IS
+    /// (iop/witness.rs:277-279: `Vec<Vec<F>>`): `wire_values[w]` = the n values of wire w, every column its own pageable
+    /// allocation, handed over as a pointer table (`gb_prove_cols`) - no flattened copy of the 1 GiB witness.
+    pub fn prove_columns<C: AsRef<[W]>>(&self, wire_values: &[C], public_inputs: &[u64], repr: Repr) -> Result<ProveOutcome, GpuError> {
+        need("wire_values", wire_values.len(), self.config.num_wires as usize)?;
+        need("public_inputs", public_inputs.len(), self.config.num_public_inputs as usize)?;
+        let table = column_table("wire_values", wire_values, 1usize << self.config.degree_bits)?;
+        let mut buf = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        let st = unsafe {
+            gb_prove_cols(self.handle, table.as_ptr(), repr.flags(), public_inputs.as_ptr(), public_inputs.len(),
+                          buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
+        };
+        self.finish_proof(st, buf, len)
+    }
+    /// `prove_retry` over the same columns with `wire_values[wire][row]` (the circuit's `random_wire`) re-drawn
+    pub fn prove_retry_columns<C: AsRef<[W]>>(&self, wire_values: &[C], wire: usize, row: usize, public_inputs: &[u64], repr: Repr)
+                                              -> Result<ProveOutcome, GpuError> {
+        need("wire_values", wire_values.len(), self.config.num_wires as usize)?;
+        need("public_inputs", public_inputs.len(), self.config.num_public_inputs as usize)?;
+        let table = column_table("wire_values", wire_values, 1usize << self.config.degree_bits)?;
+        let mut buf = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        let st = unsafe {
+            gb_prove_retry_cols(self.handle, table.as_ptr(), repr.flags(), wire as u32, row as u64, public_inputs.as_ptr(),
+                                public_inputs.len(), buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
+        };
+        self.finish_proof(st, buf, len)
+    }
+    /// `prove_salted` over separately allocated wire columns; `salts` = [3][4][N] words in the same representation
+    pub fn prove_salted_columns<C: AsRef<[W]>>(&self, wire_values: &[C], public_inputs: &[u64], salts: &[W], repr: Repr)
+                                               -> Result<ProveOutcome, GpuError> {
+        need("wire_values", wire_values.len(), self.config.num_wires as usize)?;
+        need("public_inputs", public_inputs.len(), self.config.num_public_inputs as usize)?;
+        need("salts", salts.len(), 12usize << (self.config.degree_bits + self.config.rate_bits))?;
+        let table = column_table("wire_values", wire_values, 1usize << self.config.degree_bits)?;
+        let mut buf = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        let st = unsafe {
+            gb_prove_salted_cols(self.handle, table.as_ptr(), repr.flags(), public_inputs.as_ptr(), public_inputs.len(),
+                                 salts.as_ptr() as *const c_void, buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len)
+        };
+        self.finish_proof(st, buf, len)
+    }
+    /// `zs_partial_products` from the witness columns (only the routed ones are read); the result is canonical
+    pub fn zs_partial_products_columns<C: AsRef<[W]>>(&self, wire_values: &[C], betas: &[W], gammas: &[W], repr: Repr)
+                                                      -> Result<Option<Vec<W>>, GpuError> {
+        let c = &self.config;
+        need("wire_values", wire_values.len(), c.num_wires as usize)?;
+        need("betas", betas.len(), c.num_challenges as usize)?;
+        need("gammas", gammas.len(), c.num_challenges as usize)?;
+        let table = column_table("wire_values", wire_values, 1usize << c.degree_bits)?;
+        let chunks = (c.num_routed_wires + c.max_quotient_degree_factor - 1) / c.max_quotient_degree_factor;
+        let mut out = vec![W::default(); (c.num_challenges * chunks) as usize << c.degree_bits];
+        let st = unsafe {
+            gb_zs_partial_products_cols(self.handle, table.as_ptr(), repr.flags(), betas.as_ptr() as *const c_void,
+                                        gammas.as_ptr() as *const c_void, out.as_mut_ptr() as *mut c_void)
+        };
+        if st == GB_ERR_PERM_ARG_ZERO {
+            return Ok(None);
+        }
+        check(self.ctx.0, st)?;
+        Ok(Some(out))
     }
     /// Give up after `PermArgZero` (`ProverError::TooManyPermArgFailures`, prover.rs:221-225): releases what the failed attempt
     /// left on the device for `prove_retry` (~12 GB at 2^20 Goldilocks rows).  No-op when nothing is held.

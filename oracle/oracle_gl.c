@@ -20,6 +20,10 @@
 #define HOUT 4
 
 double gbo_last_cs_commit_seconds = 0.0; /* set by the dummy-circuit provers (prover_impl.h) */
+/* the cap of the constants/sigmas commitment the last prover call made ITSELF (prover_impl.h), canonical words of the field: lets
+ * a test compare the GPU's build()-time cap with the oracle's own before it seeds the oracle's transcript with it */
+unsigned char gbo_last_cs_cap[8192];
+size_t gbo_last_cs_cap_bytes = 0;
 #define N_PARTIAL 22
 #define HALF_FULL 4
 

@@ -291,6 +291,14 @@ def prove_cpu(circ, witness, public_inputs=(), salts=None, dump=None):
     if rc != 0:
         raise RuntimeError("oracle prover failed: rc=%d" % rc)
     prove_cpu.last_cs_commit_seconds = C.c_double.in_dll(L, "gbo_last_cs_commit_seconds").value  # build() share of the call
+    nb = C.c_size_t.in_dll(L, "gbo_last_cs_cap_bytes").value   # the cap of the constants/sigmas commitment the prover made itself
+    raw = (C.c_ubyte * 8192).in_dll(L, "gbo_last_cs_cap")
+    prove_cpu.last_cs_cap = np.frombuffer(bytes(raw[:nb]), dtype=F.dtype).reshape(-1, F.hout).copy() if nb else None
+    # A cap handed over with set_cap() (the GPU's, in the -m gpu tests) seeds the transcript through circuit_digest: it must be the
+    # cap of the commitment this prover made ITSELF from constants_sigmas - otherwise cap and digest would be GPU-vs-GPU.
+    if prove_cpu.last_cs_cap is not None and circ.constants_sigmas_cap is not None:
+        assert (np.asarray(circ.constants_sigmas_cap) == prove_cpu.last_cs_cap).all(), \
+            "constants_sigmas_cap given to set_cap() differs from the oracle prover's own constants/sigmas commitment"
     return out[: out_len.value].tobytes(), dbg
 
 

@@ -31,6 +31,8 @@
 #endif
 
 extern double gbo_last_cs_commit_seconds; /* defined in oracle_gl.c */
+extern unsigned char gbo_last_cs_cap[8192];
+extern size_t gbo_last_cs_cap_bytes;
 
 #ifndef GBO_CIRCUIT_CFG_DEFINED
 #define GBO_CIRCUIT_CFG_DEFINED
@@ -163,6 +165,9 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
     double t_cs = omp_get_wtime();
     if ((rc = batch_commit(&cs, constants_sigmas, ncs, lg, r, capH, 0, NULL))) return rc;
     gbo_last_cs_commit_seconds = omp_get_wtime() - t_cs;
+    gbo_last_cs_cap_bytes = ((size_t)HOUT << capH) * sizeof(F_T);
+    if (gbo_last_cs_cap_bytes <= sizeof gbo_last_cs_cap) memcpy(gbo_last_cs_cap, cs.cap, gbo_last_cs_cap_bytes);
+    else gbo_last_cs_cap_bytes = 0;
     GBO_SCOPE("constants/sigmas commit (build() work)");
     if ((rc = batch_commit(&wires, witness, nw, lg, r, capH, 0, salts))) return rc;          /* prover.rs:261-272 */
 

@@ -4,18 +4,22 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <exception>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
-#include <algorithm>
+#include <set>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
-#include <array>
-#include <set>
 #include <vector>
 
 #include "bb_field.hpp"
@@ -55,6 +59,8 @@ struct BbCosetSet {
     std::vector<void*> owned;
 };
 
+struct Stager;   // page-locked staging ring + copy threads for pageable host columns (below)
+
 }  // namespace
 
 struct gb_ctx {
@@ -79,6 +85,11 @@ struct gb_ctx {
     bool upload_marked = false;
     std::vector<gb_circuit*> circuits;                      // live circuits of this context: what they keep for gb_prove_retry is
                                                             // released by gb_ctx_trim and when an allocation would fail
+    Stager* stager = nullptr;                               // made on first use by a pageable host input
+    // gb_ctx_set_option
+    int copy_threads = 4;                                   // "copy_threads": -1 = no staging ring (hipMemcpyAsync straight from pageable memory)
+    bool upload_legacy_chunks = false;                      // "upload_legacy_chunks": rounds 2-3 upload chunking 4, 12, 16, ... (A/B)
+    bool retry_verify = false;                              // "retry_verify": gb_prove_retry compares the whole matrix with the kept copy
 };
 static void drop_all_retry_state(gb_ctx* ctx);              // prover_host.inc
 
@@ -391,6 +402,191 @@ gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u32 shift_mont, b
 
 // internal flag (not part of the C ABI): device input already in the field's device form (BabyBear: Montgomery)
 static constexpr uint32_t GB_INPUT_DEVICE_FORM = 0x100;
+static constexpr uint32_t GB_PUBLIC_INPUT_FLAGS = GB_INPUT_DEVICE | GB_INPUT_P3_REPR;   // what a caller may pass
+
+// A matrix of input columns as the caller holds it: one contiguous [ncols][n] block (`base`), or ncols separately allocated
+// columns (`ptrs`) - the reference's Vec<PolynomialValues<F>> (fri/oracle.rs:68-75) and MatrixWitness.wire_values: Vec<Vec<F>>
+// (iop/witness.rs:277-279).
+struct ColSrc {
+    const void* base = nullptr;
+    const void* const* ptrs = nullptr;
+    ColSrc() {}
+    ColSrc(const void* b) : base(b) {}   // NOLINT: the contiguous form converts implicitly
+    static ColSrc columns(const void* const* p) { ColSrc s; s.ptrs = p; return s; }
+    const char* col(size_t c, size_t col_bytes) const {
+        return ptrs ? static_cast<const char*>(ptrs[c]) : static_cast<const char*>(base) + c * col_bytes;
+    }
+    explicit operator bool() const { return base || ptrs; }
+};
+
+// hipHostMalloc / hipHostRegister memory (gb_host_alloc, gb_host_register): the copy engine reads it directly
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+bool all_pinned(const ColSrc& src, size_t ncols, size_t col_bytes) {
+    if (!src.ptrs) return is_pinned_host(src.base) && is_pinned_host(static_cast<const char*>(src.base) + ncols * col_bytes - 1);
+    for (size_t c = 0; c < ncols; c++)
+        if (!src.ptrs[c] || !is_pinned_host(src.ptrs[c])) return false;
+    return true;
+}
+
+// ---- pageable host columns ------------------------------------------------------------------------------------------------------
+// hipMemcpyAsync from pageable memory is a synchronous copy that the runtime stages itself, on the calling thread.  A context
+// instead owns a page-locked ring (SLOTS slots) and a few copy threads: the columns of an upload chunk are copied into a slot in
+// pieces (column 0 first), and the thread that drives the commit issues the host -> device copy of every column from the ring as
+// soon as its last piece has landed - while the copy engine moves the slot before and the GPU transforms and hashes the chunk
+// before.  The caller's columns are read by the time the call returns; the ring is the library's.
+struct Stager {
+    static constexpr unsigned SLOTS = 4;
+    static constexpr size_t PIECE = (size_t)1 << 20, SLOT_MIN = (size_t)64 << 20;
+    struct Piece { const char* src; char* dst; size_t bytes; u32 col; };
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    u64 generation = 0;      // guarded by m
+    unsigned parked = 0;     // workers waiting for a job (guarded by m)
+    bool stop = false;
+    std::vector<Piece> pieces;                       // the job in flight: written only while every worker is parked
+    std::atomic<size_t> next{0};
+    std::unique_ptr<std::atomic<u32>[]> remaining;   // pieces left per column of the job
+    size_t remaining_cap = 0;
+    char* ring = nullptr;
+    size_t slot_bytes = 0;
+    unsigned slot = 0;
+    hipEvent_t slot_done[SLOTS] = {};
+    bool slot_used[SLOTS] = {};
+
+    explicit Stager(unsigned nthreads) {
+        for (unsigned i = 0; i < nthreads; i++) workers.emplace_back([this] { work(); });
+    }
+    ~Stager() {
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+        for (unsigned i = 0; i < SLOTS; i++)
+            if (slot_done[i]) { (void)hipEventSynchronize(slot_done[i]); (void)hipEventDestroy(slot_done[i]); }
+        if (ring) (void)hipHostFree(ring);
+    }
+    void work() {
+        std::unique_lock<std::mutex> lk(m);
+        u64 seen = 0;
+        for (;;) {
+            parked++;
+            cv_done.notify_all();
+            cv_work.wait(lk, [&] { return stop || generation != seen; });
+            parked--;
+            if (stop) return;
+            seen = generation;
+            lk.unlock();
+            run_pieces();
+            lk.lock();
+        }
+    }
+    void run_pieces() {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= pieces.size()) return;
+            const Piece& p = pieces[i];
+            std::memcpy(p.dst, p.src, p.bytes);
+            if (remaining[p.col].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> g(m);
+                cv_done.notify_all();
+            }
+        }
+    }
+    bool reserve(size_t need, hipStream_t copy_stream) {   // slots of at least `need` bytes
+        if (slot_bytes >= need) return true;
+        if (ring) {
+            if (hipStreamSynchronize(copy_stream) != hipSuccess) return false;
+            (void)hipHostFree(ring);
+            ring = nullptr; slot_bytes = 0;
+            std::fill(slot_used, slot_used + SLOTS, false);
+        }
+        const size_t sb = std::max(need, SLOT_MIN);
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sb * SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ring = static_cast<char*>(p);
+        slot_bytes = sb;
+        return true;
+    }
+    // columns [c0, c0 + cc) of `src` -> dst (device, contiguous [cc][col_bytes]) through the ring, on `copy_stream`
+    bool upload(const ColSrc& src, size_t c0, size_t cc, size_t col_bytes, char* dst, hipStream_t copy_stream) {
+        if (!reserve(col_bytes, copy_stream)) return false;
+        const size_t per_slot = std::max<size_t>(1, slot_bytes / col_bytes);
+        for (size_t b0 = 0; b0 < cc; b0 += per_slot) {
+            const size_t bc = std::min(per_slot, cc - b0);
+            const unsigned s = slot;
+            slot = (slot + 1) % SLOTS;
+            if (slot_used[s] && hipEventSynchronize(slot_done[s]) != hipSuccess) return false;   // the copy engine has left the slot
+            char* base = ring + (size_t)s * slot_bytes;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_done.wait(lk, [&] { return parked == workers.size(); });   // nobody is still inside the job before
+                pieces.clear();
+                if (remaining_cap < bc) { remaining.reset(new std::atomic<u32>[bc]); remaining_cap = bc; }
+                for (size_t c = 0; c < bc; c++) {
+                    const char* sp = src.col(c0 + b0 + c, col_bytes);
+                    u32 np = 0;
+                    for (size_t o = 0; o < col_bytes; o += PIECE, np++)
+                        pieces.push_back(Piece{sp + o, base + c * col_bytes + o, std::min(PIECE, col_bytes - o), (u32)c});
+                    remaining[c].store(np, std::memory_order_relaxed);
+                }
+                next.store(0, std::memory_order_relaxed);
+                generation++;
+            }
+            cv_work.notify_all();
+            if (workers.empty()) run_pieces();   // "copy_threads" = 0: the calling thread copies
+            auto drain = [&] {   // an error return must not leave a worker reading the caller's columns
+                std::unique_lock<std::mutex> lk(m);
+                cv_done.wait(lk, [&] { return next.load(std::memory_order_relaxed) >= pieces.size() && parked == workers.size(); });
+                return false;
+            };
+            for (size_t c = 0; c < bc;) {
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv_done.wait(lk, [&] { return remaining[c].load(std::memory_order_acquire) == 0; });
+                }
+                size_t e = c + 1;   // every further column that is staged already goes into the same copy
+                while (e < bc && remaining[e].load(std::memory_order_acquire) == 0) e++;
+                if (hipMemcpyAsync(dst + (b0 + c) * col_bytes, base + c * col_bytes, (e - c) * col_bytes, hipMemcpyHostToDevice,
+                                   copy_stream) != hipSuccess)
+                    return drain();
+                c = e;
+            }
+            if (!slot_done[s] && hipEventCreateWithFlags(&slot_done[s], hipEventDisableTiming) != hipSuccess) { slot_done[s] = nullptr; return false; }
+            if (hipEventRecord(slot_done[s], copy_stream) != hipSuccess) return false;
+            slot_used[s] = true;
+        }
+        return true;
+    }
+};
+
+// Host columns [c0, c0 + cc) -> dst (device, contiguous) on the context's copy stream.  Page-locked sources go straight to the copy
+// engine (one copy for a contiguous block, one per column otherwise); pageable ones through the staging ring, small ones excepted.
+bool upload_columns(gb_ctx* ctx, const ColSrc& src, bool pinned, size_t c0, size_t cc, size_t col_bytes, void* dst) {
+    char* d = static_cast<char*>(dst);
+    const bool ring = !pinned && ctx->copy_threads >= 0 && cc * col_bytes >= ((size_t)2 << 20);
+    if (ring) {
+        if (!ctx->stager) ctx->stager = new (std::nothrow) Stager((unsigned)ctx->copy_threads);
+        if (ctx->stager && ctx->stager->upload(src, c0, cc, col_bytes, d, ctx->copy_stream)) return true;
+        (void)hipGetLastError();   // no ring (out of page-locked memory?): the runtime's own pageable path still works
+    }
+    if (!src.ptrs) return hipMemcpyAsync(d, src.col(c0, col_bytes), cc * col_bytes, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess;
+    for (size_t c = 0; c < cc; c++)
+        if (hipMemcpyAsync(d + c * col_bytes, src.col(c0 + c, col_bytes), col_bytes, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess)
+            return false;
+    return true;
+}
+// the same on an arbitrary stream for inputs that are not chunked (small batches, coefficients): plain copies
+bool copy_columns(const ColSrc& src, size_t ncols, size_t col_bytes, void* dst, hipMemcpyKind kind, hipStream_t st) {
+    char* d = static_cast<char*>(dst);
+    if (!src.ptrs) return hipMemcpyAsync(d, src.base, ncols * col_bytes, kind, st) == hipSuccess;
+    for (size_t c = 0; c < ncols; c++)
+        if (hipMemcpyAsync(d + c * col_bytes, src.ptrs[c], col_bytes, kind, st) != hipSuccess) return false;
+    return true;
+}
 
 inline size_t hout(u32 field) { return field == GB_GOLDILOCKS ? 4 : 8; }
 inline size_t esize(u32 field) { return field == GB_GOLDILOCKS ? 8 : 4; }
@@ -421,13 +617,12 @@ struct SegKeep {
 // Upload chunks of a host batch, in columns: 4, 4, 8, then `full`.  The GPU's per-column work (transform + leaf hashing) is slower
 // than PCIe delivers columns, so after a short ramp the upload is hidden - what is not hidden is the wait for the FIRST columns:
 // with 4 + 4 the first 8-column hashing segment starts after ~1.5 ms of a 2^20-row Goldilocks witness (4 + 12: ~3.5 ms).
-static inline size_t first_chunks(size_t c0, size_t full) {
-    static const bool legacy = getenv("GB_UPLOAD_LEGACY_CHUNKS") != nullptr;   // rounds 2-3: 4, 12, then `full` (A/B switch)
+static inline size_t first_chunks(size_t c0, size_t full, bool legacy) {   // legacy (rounds 2-3, A/B option): 4, 12, then `full`
     if (legacy) return c0 == 0 ? 4 : c0 == 4 ? full - 4 : full;
     return c0 < 8 ? 4 : c0 < 16 ? 8 : full;
 }
 
-gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                  uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr,
                  SegKeep* keep = nullptr, size_t* values_mont_cols = nullptr) {
     // values_mont_cols (BabyBear, with values_dev): in - how many leading columns of values_dev the caller reads as device-form
@@ -439,6 +634,13 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     if (field != GB_GOLDILOCKS && field != GB_BABYBEAR) return fail(ctx, GB_ERR_INVALID, "unknown field tag");
     if (ncols == 0) return fail(ctx, GB_ERR_INVALID, "from_values/from_coeffs needs at least one polynomial (oracle.rs:101)");
     if (!cols) return fail(ctx, GB_ERR_INVALID, "null cols");
+    if (cols.ptrs)
+        for (size_t c = 0; c < ncols; c++)
+            if (!cols.ptrs[c]) return fail(ctx, GB_ERR_INVALID, "null column pointer");
+    // GB_INPUT_P3_REPR: the elements are the in-memory words of the reference's field types (p3-goldilocks: any u64 representative;
+    // p3-baby-bear / p3-monty-31: x 2^32 mod p) - a host-memory convention
+    const bool p3 = (flags & GB_INPUT_P3_REPR) != 0;
+    if (p3 && (flags & GB_INPUT_DEVICE)) return fail(ctx, GB_ERR_INVALID, "GB_INPUT_P3_REPR describes host memory; device inputs are canonical");
     if (log_n + rate_bits > (field == GB_GOLDILOCKS ? 32u : 27u))
         return fail(ctx, GB_ERR_INVALID, "LDE size exceeds the field's two-adicity (32 Goldilocks / 27 BabyBear)");
     if (cap_height > log_n + rate_bits)
@@ -472,6 +674,18 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
 
     gb_status s;
     hipStream_t st = ctx->stream;
+    // separately allocated DEVICE columns: gathered into one block, then the contiguous path
+    struct GatherGuard {
+        gb_ctx* ctx; void* p = nullptr; size_t bytes = 0;
+        ~GatherGuard() { if (p) pool_free(ctx, p, bytes); }   // stream-ordered reuse: every reader is enqueued before the next taker
+    } gather{ctx};
+    if (dev_in && cols.ptrs) {
+        gather.bytes = ncols * n * es;
+        if (pool_alloc(ctx, gather.bytes, &gather.p) != hipSuccess) { gather.p = nullptr; return cleanup(fail(ctx, GB_ERR_OOM, "hipMalloc column gather")); }
+        if (!copy_columns(cols, ncols, n * es, gather.p, hipMemcpyDeviceToDevice, st)) return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+        cols = ColSrc(gather.p);
+    }
+    const bool pinned = !dev_in && all_pinned(cols, ncols, n * es);
     // Host input of a big batch: the leaf sponges run in segments of SEG columns as the columns arrive (chunked upload below), so
     // that the hashing - most of a commitment's time - overlaps the PCIe transfer instead of waiting for its end; the sponge state
     // waits in `seg_state` between segments (kernels_merkle.hip / kernels_bb.hip: k_*_merkle_leaves).
@@ -530,7 +744,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         const size_t in_bytes = ncols * n * 4, scr_bytes = std::max(in_bytes, (size_t)nsalt * N * 4);
         if ((s = ensure(ctx, ctx->scratch, 2 * scr_bytes))) return cleanup(s);
         u32* scr = (u32*)ctx->scratch.p;
-        const u32* in_dev = static_cast<const u32*>(cols);
+        const u32* in_dev = static_cast<const u32*>(cols.base);
         const bool staged = !dev_in && !is_coeffs && log_n >= 12 && ncols >= 4;
         if (staged) {
             // column chunks: H2D straight into values_dev / the coefficient block (copy stream) -> Montgomery form in place ->
@@ -543,14 +757,22 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             hipEvent_t e0 = evs.make(ok);                           // values_dev / coeffs may be a pool block still in use on `st`
             ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
             for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
-                cc = std::min(c0 < 32 ? 2 * first_chunks(c0 / 2, per / 2) : per, ncols - c0);   // 4-byte words: the same bytes per chunk as Goldilocks' 4, 4, 8
+                cc = std::min(c0 < 32 ? 2 * first_chunks(c0 / 2, per / 2, ctx->upload_legacy_chunks) : per, ncols - c0);   // 4-byte words: the same bytes per chunk as Goldilocks' 4, 4, 8
                 hipEvent_t copied = evs.make(ok);
-                ok = ok && hipMemcpyAsync(vals + c0 * n, static_cast<const u32*>(cols) + c0 * n, cc * n * 4, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
+                ok = ok && upload_columns(ctx, cols, pinned, c0, cc, n * 4, vals + c0 * n) &&
                      hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
                 if (!ok) break;
                 const size_t want_mont = !values_dev ? 0 : values_mont_cols ? *values_mont_cols : ncols;
                 bool direct;
-                { Scope sc(ctx, "IFFT"); direct = gbk::bb_intt_columns_canonical(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, want_mont > c0 ? want_mont - c0 : 0, *bt, st); }
+                if (p3) {   // Montgomery words as they are in the host's memory: nothing to convert
+                    Scope sc(ctx, "IFFT");
+                    gbk::bb_intt_columns(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, *bt, st);
+                    if (values_mont_cols) *values_mont_cols = ncols;
+                    direct = true;
+                } else {
+                    Scope sc(ctx, "IFFT");
+                    direct = gbk::bb_intt_columns_canonical(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, want_mont > c0 ? want_mont - c0 : 0, *bt, st);
+                }
                 if (!direct) {
                     gbk::bb_to_mont(vals + c0 * n, vals + c0 * n, cc * n, st);
                     { Scope sc(ctx, "IFFT"); gbk::bb_intt_columns(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, *bt, st); }
@@ -561,14 +783,14 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
             }
             if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
         } else if (!dev_in) {
-            if (hipMemcpyAsync(scr, cols, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+            if (!copy_columns(cols, ncols, n * 4, scr, hipMemcpyHostToDevice, st))
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
             mark_upload(ctx);
             in_dev = scr;
         }
         bool direct_intt = false;
         if (staged) {
-        } else if (flags & GB_INPUT_DEVICE_FORM) {  // prover-internal: already Montgomery words on the device
+        } else if ((flags & GB_INPUT_DEVICE_FORM) || p3) {  // already Montgomery words on the device (prover-internal; a host's p3 words)
             if (hipMemcpyAsync(coeffs, in_dev, in_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
         } else if (!is_coeffs && log_n >= 16 && log_n <= 20) {
@@ -592,6 +814,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
                     if (hipMemcpyAsync(scr, salts, (size_t)nsalt * N * 4, hipMemcpyHostToDevice, st) != hipSuccess)
                         return cleanup(fail(ctx, GB_ERR_HIP, "copy of salts failed"));
                     mark_upload(ctx);
+                    if (p3) gbk::bb_from_mont(scr, scr, (size_t)nsalt * N, st);   // the salt columns are F::rand_vec words too
                     sdev = scr;
                 }
                 gbk::bb_bitrev_copy_to_mont(sdev, lde + ncols * N, log_N, nsalt, st);
@@ -623,7 +846,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
     if ((s = gl_tables_for(ctx, log_n, &tabs))) return cleanup(s);
     if ((s = gl_cosets_for(ctx, log_n, rate_bits, gl::GENERATOR, false, &cos))) return cleanup(s);
 
-    const u64* src = static_cast<const u64*>(cols);
+    const u64* src = static_cast<const u64*>(cols.base);
     const bool staged = !dev_in && !is_coeffs && log_n >= 12;
     if (staged) {
         // column chunks: H2D into values_dev on the copy stream, then (main stream, behind an event) inverse NTT and LDE of the chunk
@@ -635,11 +858,12 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         hipEvent_t e0 = evs.make(ok);                               // values_dev may be a pool block still in use on `st`
         ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
         for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
-            cc = std::min(first_chunks(c0, CH), ncols - c0);
+            cc = std::min(first_chunks(c0, CH, ctx->upload_legacy_chunks), ncols - c0);
             hipEvent_t copied = evs.make(ok);
-            ok = ok && hipMemcpyAsync(vals + c0 * n, src + c0 * n, cc * n * sizeof(u64), hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
+            ok = ok && upload_columns(ctx, cols, pinned, c0, cc, n * sizeof(u64), vals + c0 * n) &&
                  hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
             if (!ok) break;
+            if (p3) gbk::gl_canonicalize(vals + c0 * n, cc * n, st);   // p3-goldilocks keeps any u64 representative in memory
             { Scope sc(ctx, "IFFT"); gbk::gl_intt_columns(vals + c0 * n, b->coeffs + c0 * n, (u64*)ctx->scratch.p, cc, *tabs, st); }
             { Scope sc(ctx, "FFT + blinding"); gbk::gl_lde_columns(b->coeffs + c0 * n, b->lde + c0 * N, cc, *tabs, *cos, st); }
             if (!hash_ready_segments(c0 + cc)) return cleanup(fail(ctx, GB_ERR_OOM, "sponge state"));
@@ -647,10 +871,10 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
         if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
     } else if (!dev_in || is_coeffs) {
         // host input, or coefficients the batch must own a copy of
-        if (hipMemcpyAsync(b->coeffs, cols, ncols * n * sizeof(u64), dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                           st) != hipSuccess)
+        if (!copy_columns(cols, ncols, n * sizeof(u64), b->coeffs, dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st))
             return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
         if (!dev_in) mark_upload(ctx);
+        if (p3) gbk::gl_canonicalize(b->coeffs, ncols * n, st);
         src = b->coeffs;
     }
     if (!is_coeffs && !staged) {
@@ -670,6 +894,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, ui
                 if (hipMemcpyAsync(ctx->scratch.p, salts, nsalt * N * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess)
                     return cleanup(fail(ctx, GB_ERR_HIP, "copy of salts failed"));
                 mark_upload(ctx);
+                if (p3) gbk::gl_canonicalize((u64*)ctx->scratch.p, (size_t)nsalt * N, st);
                 sdev = (const u64*)ctx->scratch.p;
             }
             gbk::u64_bitrev_copy(sdev, b->lde + ncols * N, log_N, nsalt, st);
@@ -738,6 +963,8 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     if (ctx->small.p) hipFree(ctx->small.p);
     if (ctx->upload_mark) hipEventDestroy(ctx->upload_mark);
     for (auto& kv : ctx->pool) hipFree(kv.second);
+    if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
+    delete ctx->stager;   // joins the copy threads, frees the page-locked ring
     hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
@@ -805,18 +1032,106 @@ gb_status gb_ctx_scope_reset(gb_ctx* ctx) {
     return GB_OK;
 }
 
-gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
-    gb_status s = commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, false, out);
+static gb_status commit_entry(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out) {
+    if (ctx && (flags & ~GB_PUBLIC_INPUT_FLAGS)) {
+        if (out) *out = nullptr;
+        return fail(ctx, GB_ERR_INVALID, "unknown bits in flags");
+    }
+    gb_status s = commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, is_coeffs, out);
     if (!(flags & GB_INPUT_DEVICE)) s = finish_host_commit(ctx, s, out);   // `cols` / `salts` are the caller's again on return
     return s;
 }
 
+gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+    return commit_entry(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, false, out);
+}
+
 gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                            uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
-    gb_status s = commit(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags & GB_INPUT_DEVICE, true, out);
-    if (!(flags & GB_INPUT_DEVICE)) s = finish_host_commit(ctx, s, out);
-    return s;
+    return commit_entry(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, true, out);
+}
+
+// Vec<PolynomialValues<F>> / Vec<PolynomialCoeffs<F>> as the reference holds them: ncols separately allocated columns
+gb_status gb_commit_values_cols(gb_ctx* ctx, uint32_t field, const void* const* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                                uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+    return commit_entry(ctx, field, ColSrc::columns(cols), ncols, log_n, rate_bits, cap_height, salts, flags, false, out);
+}
+
+gb_status gb_commit_coeffs_cols(gb_ctx* ctx, uint32_t field, const void* const* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                                uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+    return commit_entry(ctx, field, ColSrc::columns(cols), ncols, log_n, rate_bits, cap_height, salts, flags, true, out);
+}
+
+// ---- page-locked host memory for a host that builds its columns where the copy engine can read them
+gb_status gb_host_alloc(gb_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return fail(ctx, GB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (!bytes) return fail(ctx, GB_ERR_INVALID, "zero-sized allocation");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GB_ERR_OOM, "hipHostMalloc failed (page-locked memory is limited by RLIMIT_MEMLOCK and physical memory)");
+    }
+    *out = p;
+    return GB_OK;
+}
+
+gb_status gb_host_free(gb_ctx* ctx, void* p) {
+    if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
+    if (!p) return GB_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostFree(p));
+    return GB_OK;
+}
+
+gb_status gb_host_register(gb_ctx* ctx, void* p, size_t bytes) {
+    if (!ctx || !p || !bytes) return fail(ctx, GB_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GB_ERR_HIP, "hipHostRegister failed (already registered, or RLIMIT_MEMLOCK)");
+    }
+    return GB_OK;
+}
+
+gb_status gb_host_unregister(gb_ctx* ctx, void* p) {
+    if (!ctx || !p) return fail(ctx, GB_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));   // no upload of this context is still reading it
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GB_ERR_INVALID, "hipHostUnregister failed (not a registered range)");
+    }
+    return GB_OK;
+}
+
+// Tuning and debugging switches (none changes a result).  Per context unless noted.
+gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return fail(ctx, GB_ERR_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "copy_threads") {
+        if (value < -1 || value > 64) return fail(ctx, GB_ERR_INVALID, "copy_threads must be -1 (no staging ring), 0 (calling thread) .. 64");
+        if (ctx->stager && (int)value != ctx->copy_threads) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+            delete ctx->stager;
+            ctx->stager = nullptr;
+        }
+        ctx->copy_threads = (int)value;
+    } else if (k == "upload_legacy_chunks") {
+        ctx->upload_legacy_chunks = value != 0;
+    } else if (k == "retry_verify") {
+        ctx->retry_verify = value != 0;
+    } else if (k == "lde_group" || k == "pa_log_split" || k == "intt_group") {   // process-wide (kernels_ntt.hip)
+        if (value < 0 || value > 4096) return fail(ctx, GB_ERR_INVALID, "option value out of range");
+        gbk::NttKnobs& kn = gbk::ntt_knobs_mut();
+        (k == "lde_group" ? kn.lde_group : k == "pa_log_split" ? kn.pa_log_split : kn.intt_group) = (u32)value;
+    } else {
+        return fail(ctx, GB_ERR_INVALID, "unknown option: " + k);
+    }
+    return GB_OK;
 }
 
 gb_status gb_batch_free(gb_batch* b) {

@@ -39,17 +39,21 @@ struct GlCosetTables {
 };
 
 // Column groups of the multi-pass transforms (kernels_ntt.hip): 0 = one launch per pass over all columns.  Defaults are the
-// measured optimum; GB_LDE_GROUP / GB_PA_LOG_SPLIT / GB_INTT_GROUP (environment, read once) override them for ablations.
+// measured optimum; gb_ctx_set_option("lde_group" / "pa_log_split" / "intt_group") overrides them for ablations.
 struct NttKnobs {
     u32 lde_group;     // Goldilocks columns per PA -> PB group (BabyBear: twice as many)
     u32 pa_log_split;  // log2 of the workgroups that share a PA tile's cosets
     u32 intt_group;    // Goldilocks columns per inverse-transform group (BabyBear: twice as many)
 };
 const NttKnobs& ntt_knobs();
+NttKnobs& ntt_knobs_mut();
 
 // values on H_n (natural order) -> coefficients (natural order), in `coeffs` [ncols][n].
 // `scratch` must hold ncols*n elements. src may equal coeffs.
 void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
+
+// any u64 representative -> the canonical one, in place (GB_INPUT_P3_REPR: p3-goldilocks' in-memory words)
+void gl_canonicalize(u64* p, size_t count, hipStream_t stream);
 
 // coefficients [ncols][n] -> LDE [ncols][N] in LEAF order: lde[c][j] = P_c(7 * w_N^bitrev_logN(j))
 // (fri/oracle.rs:108-109 order, no transpose / bit-reverse pass needed afterwards).

@@ -222,6 +222,19 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb(const u64* __restrict__ c
     for (u32 t = threadIdx.x; t < te; t += THREADS) p[t] = sh[t];
 }
 
+// x -> x mod p for any u64 x (x < 2p: one conditional subtraction), 2 elements per thread
+__global__ __launch_bounds__(256) void k_gl_canonicalize(u64* __restrict__ p, size_t count) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i + 1 < count) {
+        ulonglong2 v = *reinterpret_cast<ulonglong2*>(p + i);
+        v.x = v.x >= gl::P ? v.x - gl::P : v.x;
+        v.y = v.y >= gl::P ? v.y - gl::P : v.y;
+        *reinterpret_cast<ulonglong2*>(p + i) = v;
+    } else if (i < count) {
+        p[i] = p[i] >= gl::P ? p[i] - gl::P : p[i];
+    }
+}
+
 // ------------------------------------------------------------------ host launchers
 
 // radix-16 register kernels (kernels_ntt16.hip); return false when the shape is not covered
@@ -229,6 +242,11 @@ bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols
 bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, u32 log_split,
                    hipStream_t stream);
 void gl_lde_pb_r16(u64* lde, size_t ntiles, const GlNttTables& t, hipStream_t stream);
+
+void gl_canonicalize(u64* p, size_t count, hipStream_t stream) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_gl_canonicalize, dim3((u32)((count + 511) / 512)), dim3(256), 0, stream, p, count);
+}
 
 static InvGeom inv_geom(u32 L) {
     InvGeom g;
@@ -251,15 +269,12 @@ static InvGeom inv_geom(u32 L) {
 // passes do NOT gain from it - they are bound by VALU issue and latency, not by HBM, and small groups only add launch tails
 // (8.55 ms with all columns per launch, 8.7-14.5 ms in groups of 16..1) - so the LDE default stays "all columns"; the three
 // memory-bound passes of the inverse transform gain 8 % in groups of 16 columns (1.49 -> 1.36 ms).  The knobs remain for ablations
-// (environment, read once).
-static u32 ntt_knob(const char* name, u32 dflt) {
-    const char* s = getenv(name);
-    return s && *s ? (u32)atoi(s) : dflt;
-}
-const NttKnobs& ntt_knobs() {
-    static const NttKnobs k{ntt_knob("GB_LDE_GROUP", 0), ntt_knob("GB_PA_LOG_SPLIT", 0), ntt_knob("GB_INTT_GROUP", 16)};
+// (gb_ctx_set_option).
+NttKnobs& ntt_knobs_mut() {   // gb_ctx_set_option("lde_group" / "pa_log_split" / "intt_group"): process-wide
+    static NttKnobs k{0, 0, 16};
     return k;
 }
+const NttKnobs& ntt_knobs() { return ntt_knobs_mut(); }
 
 static void gl_intt_group(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
 

@@ -12,11 +12,12 @@ GB_OK, GB_ERR_INVALID, GB_ERR_HIP, GB_ERR_OOM, GB_ERR_UNSUPPORTED = 0, 1, 2, 3, 
 GB_ERR_PERM_ARG_ZERO, GB_ERR_OPENING_IN_SUBGROUP, GB_ERR_BUFFER_TOO_SMALL, GB_ERR_VERIFY = 16, 17, 18, 19
 GB_GOLDILOCKS, GB_BABYBEAR = 0, 1
 GB_INPUT_HOST, GB_INPUT_DEVICE = 0, 1
-GB_PROVE_FAIL_PERM_ARG = 0x200   # gb_prove test hook: report InvZeroPermArg once the Z computation is done (include/goldibear_gpu.h)
+GB_INPUT_P3_REPR = 2   # host elements are the reference's field types as they lie in memory (p3 words), not canonical values
 GB_SALT_SIZE = 4
 
 _vp, _u32, _u64, _sz, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_int32
 _pvp = C.POINTER(C.c_void_p)
+_cols = C.POINTER(C.c_void_p)   # const void* const*: one pointer per separately allocated column
 
 # name -> (restype, argtypes); kept in step with include/goldibear_gpu.h (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -29,6 +30,13 @@ SIGNATURES = {
     "gb_ctx_set_profiling": (_i32, [_vp, _i32]),
     "gb_ctx_scope_ms": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "gb_ctx_scope_reset": (_i32, [_vp]),
+    "gb_ctx_set_option": (_i32, [_vp, C.c_char_p, C.c_int64]),
+    "gb_host_alloc": (_i32, [_vp, _sz, _pvp]),
+    "gb_host_free": (_i32, [_vp, _vp]),
+    "gb_host_register": (_i32, [_vp, _vp, _sz]),
+    "gb_host_unregister": (_i32, [_vp, _vp]),
+    "gb_commit_values_cols": (_i32, [_vp, _u32, _cols, _sz, _u32, _u32, _u32, _vp, _u32, _pvp]),
+    "gb_commit_coeffs_cols": (_i32, [_vp, _u32, _cols, _sz, _u32, _u32, _u32, _vp, _u32, _pvp]),
     "gb_commit_values": (_i32, [_vp, _u32, _vp, _sz, _u32, _u32, _u32, _vp, _u32, _pvp]),
     "gb_commit_coeffs": (_i32, [_vp, _u32, _vp, _sz, _u32, _u32, _u32, _vp, _u32, _pvp]),
     "gb_batch_free": (_i32, [_vp]),
@@ -62,6 +70,14 @@ SIGNATURES = {
     "gb_prove_retry": (_i32, [_vp, _vp, _u32, _u32, _u64, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "gb_circuit_drop_retry": (_i32, [_vp]),
     "gb_prove_salted": (_i32, [_vp, _vp, _u32, _vp, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "gb_prove_cols": (_i32, [_vp, _cols, _u32, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "gb_prove_retry_cols": (_i32, [_vp, _cols, _u32, _u32, _u64, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "gb_prove_salted_cols": (_i32, [_vp, _cols, _u32, _vp, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "gb_zs_partial_products_cols": (_i32, [_vp, _cols, _u32, _vp, _vp, _vp]),
+}
+# include/goldibear_gpu_test_hooks.h: exports for the test suite, outside the product ABI
+TEST_HOOK_SIGNATURES = {
+    "gb_test_arm_perm_arg_failure": (_i32, [_vp]),
 }
 
 _lib = None
@@ -85,7 +101,7 @@ def load():
         # this library's NEEDED libamdhip64.so.7 to the copy torch already loaded.
         import torch  # noqa: F401
         lib = C.CDLL(path)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(TEST_HOOK_SIGNATURES.items()):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         _lib = lib

@@ -78,6 +78,34 @@ class GpuContext:
     def scope_reset(self):
         N.check(self._lib.gb_ctx_scope_reset(self.handle), self.handle)
 
+    def set_option(self, key, value):
+        """gb_ctx_set_option: "copy_threads", "retry_verify", and the A/B switches of DESIGN.md section 4"""
+        N.check(self._lib.gb_ctx_set_option(self.handle, key.encode(), int(value)), self.handle)
+
+    # page-locked host memory (include/goldibear_gpu.h, "host memory"): what a host uses to place its columns where the copy
+    # engine reads them directly
+    def host_alloc(self, shape, dtype):
+        """gb_host_alloc -> a numpy array over page-locked memory; give it back with host_free(array)"""
+        count = int(np.prod(shape))
+        p = C.c_void_p()
+        N.check(self._lib.gb_host_alloc(self.handle, count * np.dtype(dtype).itemsize, C.byref(p)), self.handle)
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._host_blocks = getattr(self, "_host_blocks", {})
+        self._host_blocks[a.ctypes.data] = p
+        return a
+
+    def host_free(self, array):
+        p = getattr(self, "_host_blocks", {}).pop(array.ctypes.data)
+        N.check(self._lib.gb_host_free(self.handle, p), self.handle)
+
+    def host_register(self, array):
+        """gb_host_register: page-lock an existing (contiguous) array in place"""
+        N.check(self._lib.gb_host_register(self.handle, array.ctypes.data, array.nbytes), self.handle)
+
+    def host_unregister(self, array):
+        N.check(self._lib.gb_host_unregister(self.handle, array.ctypes.data), self.handle)
+
     def pow_grind(self, sponge_state, witness_pos, min_leading_zeros, field=N.GB_GOLDILOCKS):
         """fri_proof_of_work (fri/prover.rs:136-188): minimum nonce for the given duplex state."""
         st = np.ascontiguousarray(sponge_state, dtype=_dtype(field))
@@ -108,6 +136,32 @@ def _as_input(x, field=N.GB_GOLDILOCKS):
     assert x.is_cuda and x.is_contiguous() and x.element_size() == np.dtype(dt).itemsize, \
         "device input must be a contiguous CUDA tensor of the field's word size"
     return x.data_ptr(), tuple(x.shape), N.GB_INPUT_DEVICE, x
+
+
+def is_column_list(x):
+    """a list / tuple of separately allocated 1-D columns: the reference's Vec<PolynomialValues<F>> / Vec<Vec<F>>"""
+    return isinstance(x, (list, tuple)) and len(x) > 0 and all(hasattr(c, "shape") and len(c.shape) == 1 for c in x)
+
+
+def _as_columns(cols, field=N.GB_GOLDILOCKS):
+    """list of 1-D numpy arrays (host; pageable or page-locked) or 1-D torch CUDA tensors -> (const void* const* array,
+    (ncols, n), flags, keepalive): the pointer table of the *_cols entry points, nothing is copied or flattened"""
+    dt = _dtype(field)
+    n = int(cols[0].shape[0])
+    ptrs, keep = (C.c_void_p * len(cols))(), []
+    dev = hasattr(cols[0], "data_ptr")
+    for i, c in enumerate(cols):
+        if int(c.shape[0]) != n:
+            raise N.ShapeError(N.GB_ERR_INVALID, "columns differ in length")
+        if dev:
+            assert c.is_cuda and c.is_contiguous() and c.element_size() == np.dtype(dt).itemsize
+            ptrs[i] = c.data_ptr()
+        else:
+            if c.dtype != dt or not c.flags.c_contiguous:
+                raise N.ShapeError(N.GB_ERR_INVALID, "columns must be contiguous arrays of the field's word type")
+            ptrs[i] = c.ctypes.data
+        keep.append(c)
+    return ptrs, (len(cols), n), (N.GB_INPUT_DEVICE if dev else N.GB_INPUT_HOST), keep
 
 
 class MerkleTree:
@@ -164,8 +218,12 @@ class PolynomialBatch:
         _live_batches.add(self)
 
     @classmethod
-    def _commit(cls, fn_name, ctx, cols, rate_bits, cap_height, salts, field):
-        ptr, shape, flags, keep = _as_input(cols, field)
+    def _commit(cls, fn_name, ctx, cols, rate_bits, cap_height, salts, field, p3_repr=False):
+        if is_column_list(cols):   # Vec<PolynomialValues<F>>: separately allocated columns, handed over as pointers
+            ptr, shape, flags, keep = _as_columns(cols, field)
+            fn_name += "_cols"
+        else:
+            ptr, shape, flags, keep = _as_input(cols, field)
         if len(shape) != 2:
             raise N.ShapeError(N.GB_ERR_INVALID, "expected a [num_polys][n] matrix")
         ncols, n = shape
@@ -178,20 +236,24 @@ class PolynomialBatch:
             if tuple(sshape) != (N.GB_SALT_SIZE, n << rate_bits) or sflags != flags:
                 raise N.ShapeError(N.GB_ERR_INVALID, "salts must be [4][n << rate_bits] in the same memory space as the columns")
         h = C.c_void_p()
+        if p3_repr:
+            flags |= N.GB_INPUT_P3_REPR
         st = getattr(ctx._lib, fn_name)(ctx.handle, field, ptr, ncols, log_n, rate_bits, cap_height, sptr, flags, C.byref(h))
         N.check(st, ctx.handle)
         del keep, skeep
         return cls(ctx, h)
 
     @classmethod
-    def from_values(cls, ctx, values, rate_bits, cap_height, salts=None, field=N.GB_GOLDILOCKS):
-        """PolynomialBatch::from_values (oracle.rs:68-90). blinding == (salts is not None)."""
-        return cls._commit("gb_commit_values", ctx, values, rate_bits, cap_height, salts, field)
+    def from_values(cls, ctx, values, rate_bits, cap_height, salts=None, field=N.GB_GOLDILOCKS, p3_repr=False):
+        """PolynomialBatch::from_values (oracle.rs:68-90). blinding == (salts is not None).  `values`: a [num_polys][n] matrix, or
+        a list of separately allocated columns (the reference's Vec<PolynomialValues<F>>; gb_commit_values_cols).  p3_repr: host
+        elements are the reference's in-memory words (GB_INPUT_P3_REPR) instead of canonical values."""
+        return cls._commit("gb_commit_values", ctx, values, rate_bits, cap_height, salts, field, p3_repr)
 
     @classmethod
-    def from_coeffs(cls, ctx, coeffs, rate_bits, cap_height, salts=None, field=N.GB_GOLDILOCKS):
+    def from_coeffs(cls, ctx, coeffs, rate_bits, cap_height, salts=None, field=N.GB_GOLDILOCKS, p3_repr=False):
         """PolynomialBatch::from_coeffs (oracle.rs:93-123)."""
-        return cls._commit("gb_commit_coeffs", ctx, coeffs, rate_bits, cap_height, salts, field)
+        return cls._commit("gb_commit_coeffs", ctx, coeffs, rate_bits, cap_height, salts, field, p3_repr)
 
     def free(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None) and not self._borrowed:

@@ -13,7 +13,7 @@ import weakref
 import numpy as np
 
 from . import native as N
-from .polynomial_batch import _as_input, _dtype, _live_contexts  # noqa: F401
+from .polynomial_batch import _as_columns, _as_input, _dtype, _live_contexts, is_column_list  # noqa: F401
 
 _live_circuits = weakref.WeakSet()
 
@@ -133,12 +133,14 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
 
     MAX_PERM_ARG_RETRIES = 3  # plonk/prover.rs:183
 
-    def prove(self, witness, public_inputs=(), random_wire=None, rng=None, salts=None):
+    def prove(self, witness, public_inputs=(), random_wire=None, rng=None, salts=None, p3_repr=False):
         """prove_with_partition_witness (plonk/prover.rs:160-226): the retry loop around the proof proper.  When the
         permutation argument hits a zero denominator (ProverError::InvZeroPermArg - with a 31-bit field and 2^20 rows
         about one proof in five) the reference overwrites `random_wire` (circuit_builder.rs:1073-1075: the last wire of the
         PublicInputGate row, given here as (column, row)) with a fresh F::rand() and tries again, at most 3 attempts.
-        `witness` is modified in place in that case, like the reference's `witness.wire_values`."""
+        `witness` is modified in place in that case, like the reference's `witness.wire_values`.  `witness`: the [num_wires][n]
+        matrix, or MatrixWitness.wire_values as the reference holds it - a list of num_wires separately allocated columns
+        (gb_prove_cols).  p3_repr: host elements are the reference's in-memory words (GB_INPUT_P3_REPR)."""
         self.perm_arg_retries = 0
         for attempt in range(self.MAX_PERM_ARG_RETRIES):
             if attempt > 0:
@@ -149,19 +151,28 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
                 col, row = random_wire
                 p = 0xFFFFFFFF00000001 if self.field == N.GB_GOLDILOCKS else 2013265921
                 val = int(rng.integers(0, p, dtype=np.uint64))
-                if isinstance(witness, np.ndarray):
+                if p3_repr and self.field == N.GB_BABYBEAR:
+                    val = (val << 32) % p   # the Montgomery word of p3's BabyBear
+                if is_column_list(witness) and isinstance(witness[col], np.ndarray):
+                    witness[col][row] = val
+                elif isinstance(witness, np.ndarray):
                     witness[col, row] = val
-                else:  # torch device tensor holding the same-width integer bit pattern
-                    witness[col, row] = val - (1 << (8 * witness.element_size())) if val >> (8 * witness.element_size() - 1) else val
+                else:  # torch device tensor(s) holding the same-width integer bit pattern
+                    t = witness[col] if is_column_list(witness) else witness
+                    sval = val - (1 << (8 * t.element_size())) if val >> (8 * t.element_size() - 1) else val
+                    if is_column_list(witness):
+                        t[row] = sval
+                    else:
+                        t[col, row] = sval
                     # that write is on torch's current stream; the library reads the column on its own stream: order them
                     import torch
-                    torch.cuda.current_stream(witness.device).synchronize()
+                    torch.cuda.current_stream(t.device).synchronize()
                 self.perm_arg_retries = attempt
             try:
                 # the second and third attempts differ from the failed one in the random wire only: gb_prove_retry rebuilds just
                 # that column of the wires commitment where the library kept the rest (no salts)
                 retry = (col, row) if attempt > 0 and salts is None else None
-                return self.prove_once(witness, public_inputs, salts, retry_wire=retry)
+                return self.prove_once(witness, public_inputs, salts, retry_wire=retry, p3_repr=p3_repr)
             except N.PermArgZeroError:
                 if random_wire is None:   # no retry will follow: do not keep the failed attempt's commitment on the device
                     self.drop_retry()
@@ -174,12 +185,20 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
         if self.handle:
             N.check(self._lib.gb_circuit_drop_retry(self.handle), self.ctx.handle)
 
-    def prove_once(self, witness, public_inputs=(), salts=None, retry_wire=None, extra_flags=0):
+    def arm_perm_arg_failure(self):
+        """TEST HOOK (include/goldibear_gpu_test_hooks.h): the next prove_once raises PermArgZeroError once its Z computation is
+        done, keeping what gb_prove_retry builds on - the only way to drive the retry path of a 64-bit field"""
+        N.check(self._lib.gb_test_arm_perm_arg_failure(self.handle), self.ctx.handle)
+
+    def prove_once(self, witness, public_inputs=(), salts=None, retry_wire=None, p3_repr=False):
         """internal_prove_with_partition_witness (plonk/prover.rs:228-447); raises PermArgZeroError.  A circuit created with
         zero_knowledge=True takes `salts`: [3][4][N] canonical elements (the F::rand_vec columns of the wires / Zs / quotient
         commitments, fri/oracle.rs:144-148), in the same memory space as the witness."""
-        ptr, shape, flags, keep = _as_input(witness, self.field)
-        flags |= extra_flags   # N.GB_PROVE_FAIL_PERM_ARG: the library's test hook for the retry path
+        cols = is_column_list(witness)
+        ptr, shape, flags, keep = _as_columns(witness, self.field) if cols else _as_input(witness, self.field)
+        lib, sfx = self._lib, "_cols" if cols else ""
+        if p3_repr:
+            flags |= N.GB_INPUT_P3_REPR
         want = (self.cfg.num_wires, 1 << self.cfg.degree_bits)
         if tuple(shape) != want:
             raise N.ShapeError(N.GB_ERR_INVALID, "witness must be %r, got %r" % (want, tuple(shape)))
@@ -189,18 +208,18 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
         n = C.c_size_t()
         pis_ptr = pis.ctypes.data if pis.size else None
         if salts is None and retry_wire is not None:   # (wire, row): the one element re-drawn since the attempt that failed
-            st = self._lib.gb_prove_retry(self.handle, ptr, flags, int(retry_wire[0]), int(retry_wire[1]), pis_ptr, pis.size,
-                                          self._proof_buf.ctypes.data, self._proof_buf.size, C.byref(n))
+            st = getattr(lib, "gb_prove_retry" + sfx)(self.handle, ptr, flags, int(retry_wire[0]), int(retry_wire[1]), pis_ptr, pis.size,
+                                                      self._proof_buf.ctypes.data, self._proof_buf.size, C.byref(n))
         elif salts is None:
-            st = self._lib.gb_prove(self.handle, ptr, flags, pis_ptr, pis.size, self._proof_buf.ctypes.data, self._proof_buf.size,
-                                    C.byref(n))
+            st = getattr(lib, "gb_prove" + sfx)(self.handle, ptr, flags, pis_ptr, pis.size, self._proof_buf.ctypes.data,
+                                                self._proof_buf.size, C.byref(n))
         else:
             sptr, sshape, sflags, skeep = _as_input(np.reshape(salts, (3 * N.GB_SALT_SIZE, -1)) if isinstance(salts, np.ndarray)
                                                     else salts.reshape(3 * N.GB_SALT_SIZE, -1), self.field)
-            if tuple(sshape) != (3 * N.GB_SALT_SIZE, 1 << (self.cfg.degree_bits + self.cfg.rate_bits)) or sflags != flags:
+            if tuple(sshape) != (3 * N.GB_SALT_SIZE, 1 << (self.cfg.degree_bits + self.cfg.rate_bits)) or sflags != (flags & N.GB_INPUT_DEVICE):
                 raise N.ShapeError(N.GB_ERR_INVALID, "salts must be [3][4][N] in the same memory space as the witness")
-            st = self._lib.gb_prove_salted(self.handle, ptr, flags, pis_ptr, pis.size, sptr, self._proof_buf.ctypes.data,
-                                           self._proof_buf.size, C.byref(n))
+            st = getattr(lib, "gb_prove_salted" + sfx)(self.handle, ptr, flags, pis_ptr, pis.size, sptr, self._proof_buf.ctypes.data,
+                                                       self._proof_buf.size, C.byref(n))
             del skeep
         N.check(st, self.ctx.handle)
         del keep
@@ -226,23 +245,29 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
             raise N.ShapeError(N.GB_ERR_INVALID, "expected num_challenges field elements")
         return a
 
-    def zs_partial_products(self, witness, betas, gammas):
+    def zs_partial_products(self, witness, betas, gammas, p3_repr=False):
         """wires_permutation_partial_products_and_zs for every challenge (plonk/prover.rs:305-329, 449-546) ->
         [num_challenges * (1 + num_partial_products)][n] values, Zs first; host array for a host witness, device tensor for a
         device one.  Raises PermArgZeroError (InvZeroPermArg)."""
-        ptr, shape, flags, keep = _as_input(witness, self.field)
+        cols = is_column_list(witness)
+        ptr, shape, flags, keep = _as_columns(witness, self.field) if cols else _as_input(witness, self.field)
         n = 1 << self.cfg.degree_bits
         if tuple(shape) != (self.cfg.num_wires, n):
             raise N.ShapeError(N.GB_ERR_INVALID, "witness must be [num_wires][n]")
         b, g = self._challenges(betas), self._challenges(gammas)
-        if flags == N.GB_INPUT_DEVICE:
+        dev = flags == N.GB_INPUT_DEVICE
+        if p3_repr:
+            flags |= N.GB_INPUT_P3_REPR
+        if dev:
             import torch
-            out = torch.empty((self._nzs(), n), dtype=witness.dtype, device=witness.device)
+            w0 = witness[0] if cols else witness
+            out = torch.empty((self._nzs(), n), dtype=w0.dtype, device=w0.device)
             optr = out.data_ptr()
         else:
             out = np.empty((self._nzs(), n), dtype=self._dt)
             optr = out.ctypes.data
-        N.check(self._lib.gb_zs_partial_products(self.handle, ptr, flags, b.ctypes.data, g.ctypes.data, optr), self.ctx.handle)
+        fn = self._lib.gb_zs_partial_products_cols if cols else self._lib.gb_zs_partial_products
+        N.check(fn(self.handle, ptr, flags, b.ctypes.data, g.ctypes.data, optr), self.ctx.handle)
         del keep
         return out
 

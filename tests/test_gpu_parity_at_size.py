@@ -39,7 +39,11 @@ def _gpu_circuit(ctx, circ, tag):
 
 
 @pytest.mark.parametrize("field_name,degree_bits,num_challenges", [
-    ("goldilocks", 16, 3), ("babybear", 16, 7), ("goldilocks", 18, 3), ("babybear", 18, 8),
+    ("goldilocks", 14, 2), ("babybear", 15, 7),      # 2^14 / 2^15 rows: k_*_lde_pa_small<K>, the LDS radix-2 inverse transform
+    ("goldilocks", 16, 3), ("babybear", 16, 7),
+    ("goldilocks", 17, 3), ("babybear", 17, 8),      # 2^17 / 2^19 rows: the mixed radix-2/4/8 middle passes, k_*_lde_pa16xs<K>
+    ("goldilocks", 18, 3), ("babybear", 18, 8),
+    ("goldilocks", 19, 3), ("babybear", 19, 9),
     ("goldilocks", 20, 3), ("babybear", 20, 10),
 ])
 def test_proof_bytes_match_oracle_at_size(ctx, field_name, degree_bits, num_challenges):
@@ -49,8 +53,9 @@ def test_proof_bytes_match_oracle_at_size(ctx, field_name, degree_bits, num_chal
         F, tag, cfg = BB, N.GB_BABYBEAR, D.CircuitConfig.babybear(num_challenges)
     circ = D.DummyCircuit(degree_bits, cfg, F=F)
     gpu = _gpu_circuit(ctx, circ, tag)
-    # the oracle prover commits constants||sigmas itself (the build() share); only the digest is taken from the GPU cap here,
-    # and the proof bytes below depend on the oracle's own commitment through the openings and the query rounds
+    # the oracle prover commits constants||sigmas itself (the build() share); the GPU's cap only spares the Python side a second
+    # CPU commitment for the digest - prove_cpu() asserts that it IS the cap of the oracle's own commitment (cap and digest are
+    # oracle-pinned, not GPU-vs-GPU), and the proof bytes depend on the oracle's commitment through the openings and the queries
     circ.set_cap(gpu.constants_sigmas_cap)
     assert (gpu.circuit_digest == circ.circuit_digest).all()
     w = circ.witness(seed=degree_bits)
@@ -58,7 +63,13 @@ def test_proof_bytes_match_oracle_at_size(ctx, field_name, degree_bits, num_chal
     want, _ = D.prove_cpu(circ, w)
     assert len(got) == len(want)
     assert got == want, "first differing byte at %d" % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    assert (gpu.constants_sigmas_cap == D.prove_cpu.last_cs_cap).all()    # (what prove_cpu asserted, spelled out)
     assert gpu.verify(got)
+    if degree_bits in (16, 20):
+        # the same proof through the column-pointer ABI: MatrixWitness.wire_values as the reference holds it (iop/witness.rs:277-279),
+        # num_wires separately allocated pageable columns -> gb_prove_cols, staged by the library's page-locked ring
+        cols = [np.array(c, copy=True) for c in w]
+        assert gpu.prove(cols) == want
     gpu.free()
     ctx.trim()
 

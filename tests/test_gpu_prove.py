@@ -147,8 +147,8 @@ def test_repeated_proving_does_not_leak(ctx):
 
 def test_goldilocks_retry_is_incremental_and_byte_identical(ctx, monkeypatch):
     """gb_prove_retry on a Goldilocks circuit: InvZeroPermArg has probability ~2^-40 there, so the failed attempt comes
-    from the library's test hook (GB_PROVE_FAIL_PERM_ARG: the error is reported once the Z computation is done, with the same state
-    kept).  2^16 rows = 2^19 leaves, 135 wires: the incremental path - the random wire's 64-bit element is written into the kept
+    from the library's test hook (gb_test_arm_perm_arg_failure, include/goldibear_gpu_test_hooks.h: the error is reported once the
+    Z computation is done, with the same state kept).  2^16 rows = 2^19 leaves, 135 wires: the incremental path - the random wire's 64-bit element is written into the kept
     device copy, its column transformed and re-hashed - must give the bytes of a proof from scratch, and the oracle's."""
     import torch
     from plonky2_goldibear_amd import native as N
@@ -162,29 +162,34 @@ def test_goldilocks_retry_is_incremental_and_byte_identical(ctx, monkeypatch):
     want = gpu.prove_once(w)
     assert want == D.prove_cpu(circ, w)[0]
     with pytest.raises(PermArgZeroError):
-        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+        gpu.arm_perm_arg_failure()
+        gpu.prove_once(w0)
     assert gpu.prove_once(w, retry_wire=rw) == want                      # host witness: kept copy, one element re-written
     # device witness: the column comes from the caller's matrix
     d0 = torch.from_numpy(w0.view(np.int64)).cuda()
     dw = torch.from_numpy(w.view(np.int64)).cuda()
     with pytest.raises(PermArgZeroError):
-        gpu.prove_once(d0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+        gpu.arm_perm_arg_failure()
+        gpu.prove_once(d0)
     assert gpu.prove_once(dw, retry_wire=rw) == want
-    # a host retry trusts the kept copy for everything but witness[wire][row]; GB_RETRY_VERIFY=1 checks that trust
-    monkeypatch.setenv("GB_RETRY_VERIFY", "1")
+    # a host retry trusts the kept copy for everything but witness[wire][row]; the option "retry_verify" checks that trust
+    ctx.set_option("retry_verify", 1)
     with pytest.raises(PermArgZeroError):
-        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+        gpu.arm_perm_arg_failure()
+        gpu.prove_once(w0)
     assert gpu.prove_once(w, retry_wire=rw) == want
     w_other = w.copy()
     w_other[5, 9] = 12345
     with pytest.raises(PermArgZeroError):
-        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+        gpu.arm_perm_arg_failure()
+        gpu.prove_once(w0)
     with pytest.raises(ShapeError):                                        # GB_ERR_INVALID: differs elsewhere
         gpu.prove_once(w_other, retry_wire=rw)
-    monkeypatch.delenv("GB_RETRY_VERIFY")
+    ctx.set_option("retry_verify", 0)
     # giving up releases what the failed attempt kept (gb_circuit_drop_retry): the retry after it is a full gb_prove
     with pytest.raises(PermArgZeroError):
-        gpu.prove_once(w0, extra_flags=N.GB_PROVE_FAIL_PERM_ARG)
+        gpu.arm_perm_arg_failure()
+        gpu.prove_once(w0)
     gpu.drop_retry()
     assert gpu.prove_once(w, retry_wire=rw) == want
     gpu.free()

@@ -10,7 +10,7 @@ HEADER = os.path.join(ROOT, "include", "goldibear_gpu.h")
 SHIM = os.path.join(ROOT, "integration", "rust", "goldibear-gpu", "src", "lib.rs")
 
 # canonical spelling of the types that cross the boundary
-C_SCALARS = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
+C_SCALARS = {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
              "char": "c_char", "void": "c_void", "gb_status": "i32", "uint8_t": "u8"}
 OPAQUE = {"gb_ctx", "gb_batch", "gb_circuit", "gb_circuit_config", "gb_gate", "gb_challenger_state"}
 
@@ -123,6 +123,27 @@ def test_every_shim_declaration_matches_the_header():
             assert rt[0] == ht[0] and rt[2] == ht[2], "%s: parameter %d (%s) is %r, header %r" % (name, i, hn, rt, ht)
             if ht[2] == 1:   # single pointers: `const T*` <-> `*const T`
                 assert rt[1] == ht[1], "%s: parameter %d (%s) constness differs" % (name, i, hn)
+
+
+def test_shim_takes_matrices_as_separately_allocated_columns():
+    """the reference's witness is Vec<Vec<F>> and from_values takes Vec<PolynomialValues<F>> (iop/witness.rs:277-279,
+    fri/oracle.rs:68-75): the shim binds the column-pointer entry points with a `*const *const c_void` table and its safe wrappers
+    build that table from the columns' own pointers - no flattening copy (flat_map / concat / extend_from_slice) anywhere"""
+    shim = shim_functions()
+    for name in ("gb_commit_values_cols", "gb_commit_coeffs_cols", "gb_prove_cols", "gb_prove_retry_cols", "gb_prove_salted_cols",
+                 "gb_zs_partial_products_cols", "gb_host_alloc", "gb_host_register", "gb_ctx_set_option"):
+        assert name in shim, name
+    assert shim["gb_prove_cols"][1][1][1] == ("c_void", True, 2) and shim["gb_commit_values_cols"][1][2][1] == ("c_void", True, 2)
+    src = open(SHIM).read()
+    body = src[src.index("fn column_table"):]
+    assert "as_ref().as_ptr()" in body
+    for wrapper, call in (("fn prove_columns", "gb_prove_cols("), ("fn prove_retry_columns", "gb_prove_retry_cols("),
+                          ("fn commit_columns", "gb_commit_values_cols"), ("fn zs_partial_products_columns", "gb_zs_partial_products_cols(")):
+        assert wrapper in src and call in src[src.index(wrapper):src.index(wrapper) + 2500], wrapper
+    code = re.sub(r"//[^\n]*", "", src)
+    for flatten in ("flat_map", ".concat()", "extend_from_slice", ".flatten()"):
+        assert flatten not in code, "the shim flattens a matrix with " + flatten
+    assert "GB_INPUT_P3_REPR" in src and "P3InMemory" in src
 
 
 def test_repr_c_structs_match_field_for_field():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Ablation of the column-group knobs of the NTT passes (kernels_ntt.hip: GB_LDE_GROUP, GB_PA_LOG_SPLIT, GB_INTT_GROUP) on the
+"""Ablation of the column-group knobs of the NTT passes (kernels_ntt.hip; gb_ctx_set_option lde_group / pa_log_split / intt_group) on the
 commit workload (from_values of the wires matrix, input resident in HBM): one bench.py process per setting, IFFT / FFT scopes.
 
   gpurun -- 'python3 tools/sweep_ntt_groups.py goldilocks > gpurun_out/sweep_gl.txt'
@@ -15,11 +15,10 @@ cols = "167" if field == "babybear" else "135"
 quick = len(sys.argv) > 2 and sys.argv[2] == "quick"
 
 
-def run(env):
-    e = dict(os.environ)
-    e.update({k: str(v) for k, v in env.items()})
+def run(opts):
     out = subprocess.run([sys.executable, "bench.py", "--workload", "commit", "--field", field, "--cols", cols, "--steps", "4",
-                          "--warmup", "1", "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=300)
+                          "--warmup", "1", "--no-cpu-baseline"] + ["--lib-option=%s=%s" % kv for kv in opts.items()],
+                         env=dict(os.environ), capture_output=True, text=True, timeout=300)
     for line in out.stdout.splitlines():
         if line.startswith("{"):
             j = json.loads(line)
@@ -33,11 +32,11 @@ settings = [{}]
 groups = (1, 2, 4) if quick else (1, 2, 3, 4, 8, 16)
 splits = (0, 2) if quick else (0, 1, 2, 3)
 for g, sp in itertools.product(groups, splits):
-    settings.append({"GB_LDE_GROUP": g, "GB_PA_LOG_SPLIT": sp})
-settings.append({"GB_PA_LOG_SPLIT": 1})
-settings.append({"GB_PA_LOG_SPLIT": 3})
+    settings.append({"lde_group": g, "pa_log_split": sp})
+settings.append({"pa_log_split": 1})
+settings.append({"pa_log_split": 3})
 for g in ((4, 8) if quick else (1, 2, 4, 8, 16)):
-    settings.append({"GB_INTT_GROUP": g})
+    settings.append({"intt_group": g})
 for st in settings:
     r = run(st)
     name = " ".join("%s=%s" % kv for kv in sorted(st.items())) or "(all columns per launch)"
