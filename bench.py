@@ -173,7 +173,7 @@ class ProveLeg:
         # a lane is the lane's buffer with that row re-written from seed k - N_WITNESSES pinned seeds, cycled, so that a field with a
         # natural InvZeroPermArg rate (BabyBear: ~1 proof in 5 at 2^20 rows) shows it in `perm_arg_retries` and pays for it in `value`
         self.pi_row = pi_row
-        gen = DC.dummy_witness_bb if bb else DC.dummy_witness
+        gen = self._gen = DC.dummy_witness_bb if bb else DC.dummy_witness
         self.rows = [[np.ascontiguousarray(gen(3, 0, seed=(rank * inflight + li) * N_WITNESSES + k)[:, 0]) for k in range(N_WITNESSES)]
                      for li in range(inflight)]
         self.step_no = 0
@@ -285,6 +285,47 @@ class ProveLeg:
     def verify_last(self):
         """outside the timed region: the library's own host-side verifier (gb_verify) on lane 0's last proof"""
         return bool(self.lanes[0][1].verify(self.proof)) if self.proof is not None else None
+
+    def _prove_seed(self, seed):
+        """lane 0's witness with the PublicInputGate row of pinned seed `seed` (rank 0's numbering), proved outside the timed region"""
+        lctx, circuit, _, wit = self.lanes[0]
+        gen = self._gen
+        row = np.ascontiguousarray(gen(3, 0, seed=seed)[:, 0])
+        if isinstance(wit, list):
+            for col, v in zip(wit, self.to_p3_words(row)):
+                col[self.pi_row] = v
+        elif isinstance(wit, np.ndarray):
+            wit[:, self.pi_row] = row
+        else:
+            wit[:, self.pi_row] = self.torch.from_numpy(row.view(self.idt)).to(self.dev)
+            self.torch.cuda.synchronize()
+        return circuit.prove(wit, random_wire=self.random_wire, rng=np.random.default_rng(99), p3_repr=self.where == "vecs")
+
+    def verify_all_witnesses(self):
+        """every one of the N_WITNESSES distinct witnesses of the run proved once more and checked by gb_verify (host side, outside
+        the timed region) -> number verified"""
+        ok = 0
+        for k in range(N_WITNESSES):
+            proof = self._prove_seed(self.rank * self.inflight * N_WITNESSES + k)
+            ok += bool(self.lanes[0][1].verify(proof))
+        return ok
+
+    def golden_check(self):
+        """Byte parity of the line itself: tests/golden/bench_proof_sha256.json holds the SHA-256 of the proof the CPU ORACLE prover
+        produces for this very circuit and witness seed (tests/golden/make_bench_proof_golden.py, run in the build container);
+        the GPU's proof of the same witness must hash to it.  None when the file has no entry for this shape."""
+        import hashlib
+        try:
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_proof_sha256.json"))).get("%s_2p%d" % (self.field, self.log_n))
+        except OSError:
+            g = None
+        if not g or g["num_challenges"] != self.challenges:
+            return None, None
+        proof = self._prove_seed(g["witness_seed"])
+        retried = self.lanes[0][1].perm_arg_retries
+        got = hashlib.sha256(proof).hexdigest()
+        return (got == g["sha256"] and not retried), {"file": "tests/golden/bench_proof_sha256.json", "witness_seed": g["witness_seed"],
+                                                      "sha256": g["sha256"], "gpu_sha256": got, "proof_len": len(proof)}
 
     def counts(self, rate_bits=3, cap_height=4):
         """algorithmic NTT bytes and Poseidon permutations of one proof"""
@@ -442,38 +483,128 @@ def bind_rank_to_local_cpus(local_rank, local_world, device_index):
     return info
 
 
-def init_control_plane(world, local_rank, default_backend):
+def _first_line(e):
+    lines = [l for l in str(e).splitlines() if l.strip()]
+    return "%s: %s" % (type(e).__name__, lines[0].strip() if lines else "")
+
+
+def _rccl_precondition(local_rank, stub):
+    """what must hold on THIS rank before it may enter an RCCL call; None = fine, else the reason (cheap, local, cannot hang)"""
+    import torch
+    if os.environ.get("GB_BENCH_FAKE_RCCL"):      # CPU tests of this function: a gloo group stands in for the RCCL one
+        return None
+    if stub or not torch.cuda.is_available():
+        return "no GPU visible to this rank"
+    if not 0 <= local_rank < torch.cuda.device_count():
+        return "device index %d out of range (%d devices)" % (local_rank, torch.cuda.device_count())
+    if os.environ.get("GB_BENCH_SHARE_DEVICE"):
+        return "ranks share a device (GB_BENCH_SHARE_DEVICE): RCCL needs one device per rank"
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") != "0":
+        return "HSA_ENABLE_IPC_MODE_LEGACY must be 0 on this host driver (dmabuf IPC only)"
+    return None
+
+
+def init_control_plane(world, rank, local_rank, default_backend, stub=False):
     """The data path has no collective; torch.distributed carries one barrier pair and one max per timed region.  The DEFAULT group
     is gloo - rendezvous over TCP, nothing that can fail for GPU reasons - and, unless GB_BENCH_BACKEND says gloo, an RCCL group
-    ("nccl") is brought up beside it and tried with one all-reduce; it carries the barrier and the reductions only if that worked
-    on EVERY rank (agreed over gloo).  Otherwise the run goes on over gloo and says so - on stderr and in the line's
-    `control_plane` - instead of failing a job whose proofs need no interconnect."""
+    ("nccl") is brought up beside it; it carries the barrier and the reductions only if it came up on EVERY rank.  A job whose proofs
+    need no interconnect must not die of its control plane, whichever way RCCL fails:
+      1. every rank checks a cheap LOCAL precondition and the ranks agree over gloo - no rank enters an RCCL call unless all pass;
+      2. group creation and one probe all-reduce run in a helper thread under a bounded wait (GB_BENCH_RCCL_TIMEOUT seconds, default
+         90): a rank that raises reports at once, a rank whose peers never arrive stops waiting; torch's watchdog is told not to
+         abort the process over a timed-out collective (TORCH_NCCL_ASYNC_ERROR_HANDLING=0);
+      3. the outcome is agreed over gloo (MIN); on failure the half-built group is destroyed where that cannot hang, the run goes on
+         over gloo and says so - on stderr and in the line's `control_plane`."""
     import datetime
     import torch
     import torch.distributed as dist
     from plonky2_goldibear_amd import sharding
     want = os.environ.get("GB_BENCH_BACKEND", default_backend)
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     dist.init_process_group("gloo")
     if want != "nccl":
         return {"backend": "gloo", "requested": want}
-    ok, why, group = 1, None, None
-    try:
-        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
-        t = torch.ones(1, device=torch.device("cuda", local_rank))
-        dist.all_reduce(t, group=group)
-        torch.cuda.synchronize()
-        if int(t.item()) != world:
-            raise RuntimeError("all_reduce over RCCL returned %r, expected %d" % (t.item(), world))
-    except Exception as e:   # noqa: BLE001 - whatever RCCL raises, the job does not need it
-        ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-    flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # gloo: do all ranks have it?
-    if int(flag.item()) == 1:
-        sharding.set_group(group)
-        return {"backend": "nccl", "requested": "nccl"}
-    print("bench.py: RCCL control plane unavailable (%s) - barrier and max-over-ranks go over gloo; the proofs use no collective"
-          % (why or "another rank failed"), file=sys.stderr)
-    return {"backend": "gloo", "requested": "nccl", "fallback_reason": why or "another rank could not bring RCCL up"}
+
+    def all_agree(ok, why):
+        """MIN over the ranks of `ok` (gloo) and every rank's reason"""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        whys = [None] * world
+        dist.all_gather_object(whys, why)
+        return int(flag.item()) == 1, whys
+
+    def fall_back(whys, extra=None):
+        reason = "; ".join("rank %d: %s" % (r, w) for r, w in enumerate(whys) if w) or "another rank could not bring RCCL up"
+        print("bench.py: RCCL control plane unavailable (%s) - barrier and max-over-ranks go over gloo; the proofs use no collective"
+              % reason, file=sys.stderr)
+        cp = {"backend": "gloo", "requested": "nccl", "fallback_reason": reason}
+        cp.update(extra or {})
+        return cp
+
+    pre = _rccl_precondition(local_rank, stub)
+    ok, whys = all_agree(pre is None, pre)
+    if not ok:
+        return fall_back(whys, {"failed_at": "precondition"})
+
+    fake = bool(os.environ.get("GB_BENCH_FAKE_RCCL"))
+    timeout = float(os.environ.get("GB_BENCH_RCCL_TIMEOUT", "90"))
+    res = {}
+
+    def bring_up():
+        try:
+            if os.environ.get("GB_BENCH_RCCL_FAIL_RANK") == str(rank):       # test hook: this rank's RCCL raises, its peers wait
+                raise RuntimeError("RCCL bring-up failed on this rank (GB_BENCH_RCCL_FAIL_RANK)")
+            res["group"] = group = dist.new_group(backend="gloo" if fake else "nccl", timeout=datetime.timedelta(seconds=timeout))
+            t = torch.ones(1) if fake else torch.ones(1, device=torch.device("cuda", local_rank))
+            work = dist.all_reduce(t, group=group, async_op=True)
+            work.wait()
+            if not fake:
+                torch.cuda.synchronize()
+            if int(t.item()) != world:
+                raise RuntimeError("all_reduce over RCCL returned %r, expected %d" % (t.item(), world))
+            res["ok"] = True
+        except Exception as e:   # noqa: BLE001 - whatever RCCL raises, the job does not need it
+            res["why"] = _first_line(e)
+
+    # new_group() is itself a collective over the default group: every rank must call it, also the one that is about to fail
+    if os.environ.get("GB_BENCH_RCCL_FAIL_RANK") == str(rank):
+        res["group"] = dist.new_group(backend="gloo" if fake else "nccl", timeout=datetime.timedelta(seconds=timeout))
+        res["why"] = "RuntimeError: RCCL bring-up failed on this rank (GB_BENCH_RCCL_FAIL_RANK)"
+        helper = None
+    else:
+        helper = threading.Thread(target=bring_up, daemon=True)
+        helper.start()
+        helper.join(timeout)
+    stuck = helper is not None and helper.is_alive()
+    if stuck:
+        res.setdefault("why", "RCCL bring-up still waiting after %.0f s (a peer never arrived)" % timeout)
+    ok, whys = all_agree(bool(res.get("ok")) and not stuck, res.get("why"))
+    if ok:
+        sharding.set_group(res["group"])
+        return {"backend": "gloo (standing in for RCCL: GB_BENCH_FAKE_RCCL)" if fake else "nccl", "requested": "nccl"}
+    if not stuck and res.get("group") is not None and not fake:
+        try:
+            dist.destroy_process_group(res["group"])     # the half-built group: gone before the proofs start
+        except Exception as e:   # noqa: BLE001
+            print("bench.py: destroying the RCCL group failed: %s" % _first_line(e), file=sys.stderr)
+    global _HARD_EXIT
+    _HARD_EXIT = stuck or fake    # a helper thread may still sit in the collective: leave without joining it or its group
+    return fall_back(whys, {"failed_at": "bring-up", "helper_still_waiting": stuck})
+
+
+_HARD_EXIT = False
+
+
+def finish(world, dist):
+    """end of a rank: leave the process groups; after an RCCL bring-up that is still blocked in a helper thread there is nothing to
+    tear down cleanly - flush and leave"""
+    if world > 1:
+        dist.barrier()
+        if _HARD_EXIT:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+        dist.destroy_process_group()
 
 
 def stub_main(args, rank, world, affinity, dist, control_plane=None):
@@ -495,9 +626,7 @@ def stub_main(args, rank, world, affinity, dist, control_plane=None):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                           "config": {"workload": "STUB (GB_BENCH_STUB=1): no GPU work, launch-path rehearsal only"},
                           "stub": True, "affinity": affinity, "control_plane": control_plane}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(world, dist)
 
 
 def workload_name(leg, witness):
@@ -570,7 +699,7 @@ def main():
     control_plane = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        control_plane = init_control_plane(world, local_rank, "gloo" if stub else "nccl")
+        control_plane = init_control_plane(world, rank, local_rank, "gloo" if stub else "nccl", stub)
         gathered = [None] * world
         dist.all_gather_object(gathered, affinity)      # every rank's CPU binding goes into the line (default group: gloo)
         affinity = dict(affinity or {}, ranks=gathered)
@@ -603,6 +732,8 @@ def main():
             out.update(leg.report(steps, scopes, inflight, retries))
             out["scopes_ms_per_step"] = {k: v[0] / steps for k, v in scopes.items() if v[1]}
             out["verified"] = leg.verify_last()
+            out["verified_witnesses"] = "%d of %d" % (leg.verify_all_witnesses(), N_WITNESSES)   # every distinct witness, once, gb_verify
+            out["proof_sha256_matches_golden"], out["golden"] = leg.golden_check()   # == the CPU oracle prover's bytes for that witness
             out["perm_arg_retries"] = retries  # InvZeroPermArg re-runs inside the timed steps (BabyBear: ~1 in 5 proofs)
             out["value_no_retry"] = _num(leg.no_retry_rate() and world * leg.no_retry_rate())
             out["witnesses"] = "%d pinned seeds, cycled: every step proves a different witness" % N_WITNESSES
@@ -640,6 +771,8 @@ def main():
             bb.update(bleg.report(steps, bscopes, inflight, bret))
             bb["scopes_ms_per_step"] = {k: v[0] / steps for k, v in bscopes.items() if v[1]}
             bb["verified"] = bleg.verify_last()
+            bb["verified_witnesses"] = "%d of %d" % (bleg.verify_all_witnesses(), N_WITNESSES)
+            bb["proof_sha256_matches_golden"], bb["golden"] = bleg.golden_check()
             bb["perm_arg_retries"] = bret     # at their natural rate: `value` has the re-done proofs inside, value_no_retry has not
             bb["value_no_retry"] = _num(bleg.no_retry_rate())
             if not args.no_resident:
@@ -735,10 +868,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample)
     if rank == 0:
         print(json.dumps(out, allow_nan=False))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     ctx.close()
+    finish(world, dist)
 
 
 if __name__ == "__main__":

@@ -116,8 +116,30 @@ def test_control_plane_falls_back_to_gloo_when_rccl_cannot_come_up():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r)
     cp = j["control_plane"]
-    assert cp["backend"] == "gloo" and cp["requested"] == "nccl" and cp["fallback_reason"]
+    assert cp["backend"] == "gloo" and cp["requested"] == "nccl" and cp["fallback_reason"] and cp["failed_at"] == "precondition"
     assert "RCCL control plane unavailable" in r.stderr
+
+
+def test_control_plane_survives_one_rank_failing_rccl():
+    """RCCL fails on ONE rank while its peer is already inside the collective (a gloo group stands in for the RCCL one:
+    GB_BENCH_FAKE_RCCL; rank 1 raises instead of entering the probe all-reduce).  The peer's bring-up runs under a bounded wait, the
+    outcome is agreed over gloo, and the run goes on over gloo - one line, exit 0, the reason names the rank."""
+    r = _run_bench_parent({"GB_BENCH_BACKEND": "nccl", "GB_BENCH_FAKE_RCCL": "1", "GB_BENCH_RCCL_FAIL_RANK": "1", "GB_BENCH_RCCL_TIMEOUT": "6"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    cp = _line(r)["control_plane"]
+    assert cp["backend"] == "gloo" and cp["requested"] == "nccl" and cp["failed_at"] == "bring-up"
+    assert "rank 1: RuntimeError: RCCL bring-up failed on this rank" in cp["fallback_reason"]
+    assert "RCCL control plane unavailable" in r.stderr
+
+
+def test_control_plane_second_group_carries_the_barrier_when_it_comes_up():
+    """the branch in which the second group DID come up on every rank (here a gloo group in RCCL's place): the barrier and the
+    max-over-ranks of the timed region run over it"""
+    r = _run_bench_parent({"GB_BENCH_BACKEND": "nccl", "GB_BENCH_FAKE_RCCL": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r)
+    assert j["control_plane"]["requested"] == "nccl" and "standing in for RCCL" in j["control_plane"]["backend"]
+    assert j["ms_per_step"] >= 4.0 and "RCCL control plane unavailable" not in r.stderr
 
 
 def test_bench_parent_fails_when_a_rank_fails():
