@@ -393,7 +393,11 @@ static void bb_intt_group(const u32* src, u32* coeffs, u32* scratch, size_t ncol
 // columns of `vals` are left in Montgomery form, the rest canonical.  false: shape not covered (2^16..2^20 rows are), nothing done.
 bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncols, size_t mont_cols, const BbNttTables& t, hipStream_t stream) {
     if (t.log_n < 16 || t.log_n > 20) return false;
-    const size_t g = std::max<size_t>(1, 2 * (size_t)ntt_knobs().intt_group), n = (size_t)1 << t.log_n;
+    const size_t g = 2 * (size_t)ntt_knobs().intt_group, n = (size_t)1 << t.log_n;
+    if (g == 0 || t.log_n < 18 || ncols <= g) {   // the grouping rule of bb_intt_columns: 0 = one launch per pass, groups from 2^18 rows
+        bb_intt_columns_r16(nullptr, coeffs, scratch, ncols, t, stream, vals, mont_cols);
+        return true;
+    }
     for (size_t c0 = 0; c0 < ncols; c0 += g)
         bb_intt_columns_r16(nullptr, coeffs + c0 * n, scratch, std::min(g, ncols - c0), t, stream, vals + c0 * n, mont_cols > c0 ? mont_cols - c0 : 0);
     return true;

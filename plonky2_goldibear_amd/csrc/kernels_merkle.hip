@@ -42,17 +42,47 @@ using poseidon_gl::to_mont;
 // The sponge state of these kernels is kept in the permutation's Montgomery form (poseidon_gl.hpp): absorbed words go through
 // to_mont, the digest through from_mont (canonical); the capacity words never leave that form between absorptions.
 
+#ifdef GB_PROBE
+// Attribution build (tools/probe_leaves.py; never the product): every `wave_step`-th wave of k_gl_merkle_leaves writes a
+// (s_memtime, site) pair at each probe site into its slice of a trace buffer.
+struct ProbeCfg {
+    ulonglong2* buf;
+    u32 max_per_wave, wave_step, nslots;
+};
+__device__ ProbeCfg gb_probe_cfg;
+extern "C" int gb_probe_setup(void* dev_buf, unsigned max_per_wave, unsigned wave_step, unsigned nslots) {
+    ProbeCfg c{static_cast<ulonglong2*>(dev_buf), max_per_wave, wave_step, nslots};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(gb_probe_cfg), &c, sizeof c);
+}
+#define GB_PROBE_INIT(amat)                                                                        \
+    do {                                                                                           \
+        const u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
+        const ProbeCfg pc = gb_probe_cfg;                                                          \
+        const bool traced = pc.buf && pc.wave_step && wave % pc.wave_step == 0 && wave / pc.wave_step < pc.nslots; \
+        amat.trace = traced ? pc.buf + (size_t)(wave / pc.wave_step) * pc.max_per_wave : nullptr;  \
+        amat.pidx = 0;                                                                             \
+    } while (0)
+#else
+#define GB_PROBE_INIT(amat) do {} while (0)
+#endif
+
 // hash/hashing.rs:100-123 (overwrite-mode sponge, rate 8) + plonk/config.rs:70-84 (hash_or_noop)
 __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
                                                                         u64 num_leaves, u64* __restrict__ out) {
     const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = j0 < num_leaves;
     const u64 j = live ? j0 : num_leaves - 1;
+#ifdef GB_PROBE
+    poseidon_gl::MdsOperand amat = mds_mfma_matrix();
+    GB_PROBE_INIT(amat);
+#else
     const poseidon_gl::MdsOperand amat = mds_mfma_matrix();
+#endif
     GB_POSEIDON_OPS();
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
+    GB_PROBE_AT(amat, 1, s);   // kernel: start (operand table filled)
     if (width <= 4) {
         for (u32 c = 0; c < width; c++) s[c] = cols[(size_t)c * col_stride + j];
     } else {
@@ -66,8 +96,10 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const
                 for (int i = 0; i < 8; i++)
                     if (c0 + i < width) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
             }
+            GB_PROBE_AT(amat, 2, s);   // absorption: 8 column loads + to_mont
             // (a full absorption follows: words 0..7 of this permutation's output will be overwritten - only the capacity is produced)
             permute_mont_mfma(s, amat, c0 + 16 <= width);  // the state stays a lazy Montgomery-form residue between absorptions
+            GB_PROBE_AT(amat, 3, s);   // permutation: the last layer
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) s[i] = from_mont(s[i]);

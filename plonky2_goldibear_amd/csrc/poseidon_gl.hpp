@@ -364,7 +364,53 @@ __device__ static const raw::MfmaInitTable MFMA_INIT = raw::mfma_init_table();
 struct MdsOperand {
     v4i a;          // this lane's share of the constant A operand (mds_mfma_matrix)
     int one, k16;   // 1 and 65536
+#ifdef GB_PROBE     // tools/probe_leaves.py: time stamps of a few waves at segment boundaries (an attribution build, never the product)
+    mutable ulonglong2* trace;   // this wave's slice of the trace buffer, or nullptr (wave-uniform)
+    mutable u32 pidx;
+#endif
 };
+// GB_PROBE_AT(amat, ID, s): in the attribution build, wave time stamp (s_memtime, shader clock) + site ID into the wave's trace.
+// The state words pass through an empty asm as in-out operands, so that the vector work in front of the site is in front of it in
+// the instruction stream and the work behind it behind (a time stamp alone does not order arithmetic).  Nothing in the product.
+#ifdef GB_PROBE
+template <int N>
+__device__ __forceinline__ void probe_pin(u64 (&s)[N]) {
+    if constexpr (N == 12)
+        asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]), "+v"(s[8]), "+v"(s[9]),
+                     "+v"(s[10]), "+v"(s[11]));
+    else
+#pragma unroll
+        for (int i = 0; i < N; i++) asm volatile("" : "+v"(s[i]));
+}
+template <int N>
+__device__ __forceinline__ void probe_pin(long long (&s)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(s[i]));
+}
+template <int A, int B>
+__device__ __forceinline__ void probe_pin(u32 (&p)[A][B]) {
+#pragma unroll
+    for (int i = 0; i < A; i++)
+#pragma unroll
+        for (int j = 0; j < B; j++) asm volatile("" : "+v"(p[i][j]));
+}
+template <int ID>
+__device__ __forceinline__ void probe_stamp(const MdsOperand& m) {
+    asm volatile("; GB_PROBE_SITE %0" ::"n"(ID));
+    if (m.trace) {
+        const u64 t = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) m.trace[m.pidx] = make_ulonglong2(t, (u64)ID);
+        m.pidx++;
+    }
+}
+#define GB_PROBE_AT(amat, ID, ...)          \
+    do {                                    \
+        poseidon_gl::probe_pin(__VA_ARGS__);\
+        poseidon_gl::probe_stamp<ID>(amat); \
+    } while (0)
+#else
+#define GB_PROBE_AT(amat, ID, ...) do {} while (0)
+#endif
 #ifdef GB_MAD_ASM   // round 3's form (inline asm, invisible to the hazard recognizer: needs GB_KEEP_TILES)
 __device__ __forceinline__ long long mad_i64(int a, const MdsOperand& m, long long c) {
     long long d;
@@ -442,6 +488,7 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& a
 #pragma unroll
             for (int p = 0; p < 4; p++) pl[4 * half + p][g] = t[p];
         }
+    GB_PROBE_AT(amat, 20, pl);   // layer: byte planes cut
     long long lo[12], hi[12];
     const u64* ilo = MFMA_INIT.lo + 12 * rnext;   // uniform index: scalar loads
     const u64* ihi = MFMA_INIT.hi + 12 * rnext;
@@ -484,6 +531,9 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& a
         }
         GB_KEEP_TILES(d0, d1, pp < 2 ? lo[11] : hi[11]);
     }
+#endif
+#ifdef GB_PROBE
+    if constexpr (Q0 == 0) { probe_pin(lo); probe_pin(hi); probe_stamp<21>(amat); }   // layer: 8 MFMAs + recombination
 #endif
     // fold_halves with its carry fix on a rare path: value = lo + 2^32 hi = (lo + (hi >> 32) EPS) + 2^32 (u32)hi, and the last
     // addition wraps only when (u32)hi lies within 2^12 of 2^32 - about 4e-4 of the wave-layers have such a lane.  The fast path

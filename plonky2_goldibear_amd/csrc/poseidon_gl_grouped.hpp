@@ -150,6 +150,7 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
     const grp::GroupInit& init = S::init();
     const int gi = r0 - HALF_FULL;
     s[0] = sbox(s[0]);
+    GB_PROBE_AT(amat, 30, s);   // group: the first s-box
     // byte planes of the state: pl[p][w] = byte p of words 4w .. 4w+3 (signed: ^ 0x80); dword 3 = the d_j, not known yet
     u32 pl[8][4], cpl[8][4];
     {
@@ -175,6 +176,7 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
     for (int p = 0; p < 8; p++)
 #pragma unroll
         for (int w = 0; w < 4; w++) cpl[p][w] = ~pl[p][w];   // only the planes a schedule complements are ever materialised
+    GB_PROBE_AT(amat, 31, pl);   // group: byte planes of the state (cut + complements)
     // ---- phase A: the words u_1 .. u_(G-1) before the d_i terms
     u64 ulo[G - 1], uhi[G - 1];
 #if GB_POSEIDON_PHASE_A_MFMA
@@ -226,6 +228,9 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
         uhi[j - 1] = hi;
     }
 #endif
+#ifdef GB_PROBE
+    probe_pin(ulo); probe_pin(uhi); probe_stamp<32>(amat);   // group: phase A dot products
+#endif
     // ---- the s-boxes of rounds r0 + 1 .. r0 + G - 1, one after the other
     u64 dl[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -239,6 +244,9 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
         const u64 u = fold_halves(lo, hi);
         dl[j - 1] = sub_lazy(sbox(u), u);
     }
+#ifdef GB_PROBE
+    probe_pin(dl); probe_stamp<33>(amat);   // group: the G - 1 dependent s-boxes
+#endif
     // ---- the d_j's byte planes into dword 3 of the B operands
     if constexpr (G == 2) {   // one word: byte p of it in slot 12, the slots beside it meet zeros
 #pragma unroll
@@ -259,6 +267,7 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
     }
 #pragma unroll
     for (int p = 0; p < 8; p++) cpl[p][3] = ~pl[p][3];
+    GB_PROBE_AT(amat, 34, pl);   // group: the d_j planes
     // ---- phase B: the state G rounds on
     long long lo[12], hi[12];
     {
@@ -285,7 +294,11 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
         for (int q = 0; q < 12; q++) hi[q] = mad_i64((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, hi[q]);
         GB_KEEP_TILES(d0, d1, hi[11]);
     }
+#ifdef GB_PROBE
+    probe_pin(lo); probe_pin(hi); probe_stamp<35>(amat);   // group: phase B MFMA chains + recombination
+#endif
     fold_rows_rare_carry(s, lo, hi);
+    GB_PROBE_AT(amat, 36, s);   // group: fold
 }
 
 // The permutation with every MDS layer on the matrix pipe and the partial rounds in groups; same contract as
@@ -294,10 +307,13 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
 __device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const MdsOperand& amat, const v4i* __restrict__ ops, bool capacity_only = false) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
+    GB_PROBE_AT(amat, 10, s);   // permutation: first constants
     for (int r = 0; r < HALF_FULL; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        GB_PROBE_AT(amat, 11, s);   // full round: 12 s-boxes
         mds_layer_mfma(s, amat, r + 1);
+        GB_PROBE_AT(amat, 22, s);   // layer: fold
     }
     for (int gidx = 0; gidx < GROUP_N; gidx++) partial_group<GROUP_G>(s, amat, ops, HALF_FULL + GROUP_G * gidx);
     if constexpr (GROUP_G2 >= 2) partial_group<GROUP_G2>(s, amat, ops + GROUP_OPS_MAIN * 64, HALF_FULL + GROUP_G * GROUP_N);
@@ -308,10 +324,13 @@ __device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const Md
     for (int r = HALF_FULL + N_PARTIAL; r + 1 < 2 * HALF_FULL + N_PARTIAL; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        GB_PROBE_AT(amat, 11, s);
         mds_layer_mfma(s, amat, r + 1);
+        GB_PROBE_AT(amat, 22, s);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+    GB_PROBE_AT(amat, 11, s);
     // capacity_only (uniform): a full absorption follows and overwrites words 0..7 - only words 8..11 of the output are produced
     if (capacity_only) mds_layer_mfma<8>(s, amat, MFMA_NO_RC);
     else mds_layer_mfma<0>(s, amat, MFMA_NO_RC);

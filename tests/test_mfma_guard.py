@@ -65,6 +65,20 @@ k:
     assert raw[3] == 10   # s_nop 9 = ten wait states: two short of what a read needs
 
 
+def test_guard_reports_tiles_in_accumulation_registers():
+    """the RAW / WAW walk sees v-registers only; a kernel that keeps MFMA tiles in a[..] must not pass silently"""
+    text = """
+k:
+	v_mov_b32_e32 v20, 0
+	v_mfma_i32_32x32x32_i8 a[0:15], v[20:23], v[20:23], 0
+	s_nop 15
+	v_accvgpr_read_b32 v40, a3
+	s_endpgm
+"""
+    n, out = mfma_guard.check_text(text)
+    assert n == 1 and [f[0] for f in out].count("agpr") == 2, out
+
+
 def test_guard_follows_loop_back_edges():
     text = """
 k:

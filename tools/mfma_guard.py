@@ -13,6 +13,9 @@ order and reports, per MFMA destination tile,
          it parks another value in a DEAD register of the tile (outputs the kernel never reads),
   * partial: an MFMA whose accumulator operand overlaps a tile in flight without being that tile,
   * undefined: an MFMA source register that no instruction of the kernel ever writes.
+  * agpr: the checks above follow ARCHITECTURAL vector registers only.  A kernel whose MFMA tiles live in accumulation registers
+         (a[..] operands, v_accvgpr_read / v_accvgpr_write) would pass them unexamined, so it is reported instead: every product
+         kernel has NumAgprs 0 today, and a register-budget change that moves tiles there must extend this guard first.
 
 Wait states are counted as the hazard recognizer counts them: one per instruction, s_nop N = N + 1.  Program order is walked once (a
 forward branch does not reset the count: conservative), and every backward branch is followed once more - the top of its loop is
@@ -115,6 +118,8 @@ def check_kernel(name, body):
             ws = 1
             if op == "s_nop":
                 ws = int(line.split(";")[0].split()[1], 0) + 1
+            if collect and (op.startswith("v_accvgpr") or (op.startswith(("v_mfma", "v_smfmac")) and AREG.search(line.split(";")[0].split(None, 1)[1]))):
+                findings.append(("agpr", name, ln, 0, line.strip(), "accumulation registers are outside this guard's model"))
             if op.startswith("v_mfma") or op.startswith("v_smfmac"):
                 ops = split_operands(line.split(";")[0].strip().split(None, 1)[1])
                 dst = set(regs_of(ops[0]))
