@@ -77,29 +77,59 @@ def cpu_baseline_commit(ncols, log_n, rate_bits, cap_height, sample_log_n):
     }
 
 
-def cpu_baseline_prove(log_n, num_challenges, sample_log_n, field="goldilocks"):
-    """The CPU oracle prover (restatement of the reference's prove(), OpenMP where the reference uses
-    Rayon) on a smaller dummy circuit of the same shape, scaled linearly in rows."""
+def _oracle_prove_seconds(D, log_n, num_challenges, field):
+    """one oracle prove() of the 2^log_n-row dummy circuit -> (seconds without the build() share, proof verified)"""
+    if field == "babybear":
+        from oracle.fields import BB
+        circ = D.DummyCircuit(log_n, D.CircuitConfig.babybear(num_challenges), check_security=False, F=BB)
+    else:
+        circ = D.DummyCircuit(log_n, D.CircuitConfig(num_challenges=num_challenges), check_security=False)
+    _ = circ.circuit_digest  # build(): not part of prove()
+    for seed in range(1, 9):   # a witness that meets a zero denominator (BabyBear) would be re-drawn by the retry loop: take the next
+        w = circ.witness(seed=seed)
+        t0 = time.perf_counter()
+        try:
+            proof, _dbg = D.prove_cpu(circ, w)
+        except RuntimeError:
+            continue
+        dt = time.perf_counter() - t0 - D.prove_cpu.last_cs_commit_seconds  # the oracle redoes build()'s constants/sigmas commit
+        assert D.verify(circ, proof)
+        return dt
+    raise RuntimeError("no witness without InvZeroPermArg among 8 seeds")
+
+
+def cpu_baseline_prove(log_n, num_challenges, sample_log_n, field="goldilocks", budget_s=150.0):
+    """The CPU oracle prover (restatement of the reference's prove(), OpenMP where the reference uses Rayon) on the host cores of
+    the box.  sample_log_n = None: AT THE BENCHMARK'S OWN SIZE when a calibration run (2^15 rows, scaled by rows) says it fits
+    `budget_s`, otherwise on the largest smaller circuit that does, scaled linearly in rows ("scaled": true)."""
     from oracle import oracle as O
     from oracle import plonk_dummy as D
     cores = O.use_host_cpu_share()  # a 1-GPU box grants 16 of the host's CPUs (cgroup quota): more threads only contend
-    if field == "babybear":
-        from oracle.fields import BB
-        circ = D.DummyCircuit(sample_log_n, D.CircuitConfig.babybear(num_challenges), check_security=False, F=BB)
-    else:
-        circ = D.DummyCircuit(sample_log_n, D.CircuitConfig(num_challenges=num_challenges), check_security=False)
-    _ = circ.circuit_digest  # build(): not part of prove()
-    w = circ.witness(seed=1)
-    t0 = time.perf_counter()
-    proof, _dbg = D.prove_cpu(circ, w)
-    dt = time.perf_counter() - t0 - D.prove_cpu.last_cs_commit_seconds  # the oracle redoes build()'s constants/sigmas commit
-    assert D.verify(circ, proof)
+    calib = None
+    if sample_log_n is None:
+        cal_n = min(log_n, 15)
+        calib = _oracle_prove_seconds(D, cal_n, num_challenges, field)
+        est = calib * (1 << (log_n - cal_n)) * 1.25      # + the log factor of the transforms and colder caches
+        sample_log_n = log_n
+        while sample_log_n > cal_n and est > budget_s:
+            sample_log_n, est = sample_log_n - 1, est / 2
+    dt = _oracle_prove_seconds(D, sample_log_n, num_challenges, field)
     scale = float(1 << (log_n - sample_log_n))
+    placement = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES", "GOMP_CPU_AFFINITY") if os.environ.get(k)}
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+        placement["affinity_mask"] = "%d cpus [%d..%d]" % (len(aff), aff[0], aff[-1])
+    except AttributeError:
+        pass
     return {
-        "value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "kind": "port",
-        "sample": "oracle prove() of the 2^%d-row dummy circuit (1/%d of the rows, num_challenges %d) took %.2f s and "
-                  "verified; scaled linearly in rows" % (sample_log_n, int(scale), num_challenges, dt),
-        "sample_seconds": dt,
+        "value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "kind": "port", "scaled": scale != 1.0,
+        "sample": ("oracle prove() of the 2^%d-row %s dummy circuit itself (num_challenges %d) took %.2f s and verified" % (
+                       sample_log_n, field, num_challenges, dt)) if scale == 1.0 else
+                  ("oracle prove() of the 2^%d-row dummy circuit (1/%d of the rows, num_challenges %d) took %.2f s and "
+                   "verified; scaled linearly in rows" % (sample_log_n, int(scale), num_challenges, dt)),
+        "sample_seconds": dt, "sample_log_n": sample_log_n, "calibration_seconds": calib,
+        "threads": "%d OpenMP threads (gbo_set_num_threads = the cgroup's CPU share), no explicit binding beyond the process's "
+                   "affinity mask" % cores, "omp_placement": placement,
     }
 
 
@@ -367,6 +397,8 @@ class ProveLeg:
         tj = _latest_profile("r*_ntt_traffic_pmc_%s.json" % fname)
         if self.log_n == 20 and tj:
             traffic = tj["ifft_bytes_per_column"] * (self.nwires + nzs) + tj["lde_bytes_per_column"] * (self.nwires + nzs + nq + self.ext_d)
+        rj = _latest_profile("r*_roofline_recompute.json")      # the same object recomputed from the committed rocprofv3 summaries
+        rf = (rj or {}).get(fname) if self.log_n == 20 else None
         out = {
             "roofline": {"bound": "hbm", "kernel": "NTT pass = %s (IFFT) + %s (FFT + blinding), all commitments of the step" % (
                              ("k_bb_intt16_*", "k_bb_lde_pa16*+pb16") if bb else ("k_gl_intt16_*", "k_gl_lde_pa16*+pb16")),
@@ -374,9 +406,19 @@ class ProveLeg:
                          "frac": _num(achieved / HBM_PEAK_GBS if achieved else None), "traffic": traffic,
                          "traffic_source": tj and {"file": tj["profile_file"], "stale": tj["stale"]},
                          "algorithmic_bytes": alg_bytes, "ms": _num(ntt_ms),
-                         # the transform is VALU-issue bound, not HBM bound: 31 integer instructions per algorithmic byte (DESIGN.md
-                         # section 4) cap `frac` at 0.32 with a 2-cycle issue and at 0.217 with the measured 2.9 cycles per instruction
-                         "valu_ceiling_frac": None if bb else 0.217},
+                         # `frac` is live (HIP-event scopes of this run); frac_from_profile is the same ratio from the kernel trace
+                         # committed under profiles/ (sum of the NTT kernels' durations per proof): rocprofv3's per-kernel times on
+                         # another box of the pool, a few per cent apart
+                         "frac_from_profile": _num(rf and rf.get("frac_from_profile")),
+                         "ntt_kernel_ms_from_profile": _num(rf and rf.get("ntt_kernel_ms_per_proof")),
+                         # the transform is VALU-issue bound, not HBM bound: SQ_INSTS_VALU of the NTT kernels per algorithmic byte
+                         # (31 Goldilocks / 25 BabyBear lane-instructions) at the measured 2.9 cycles per wave64 integer
+                         # instruction caps `frac` at valu_ceiling_frac; pass_structure_ceiling_frac is the other cap of this
+                         # transform - its 31 n s of physical traffic per from_values column at the chip's plain-copy rate
+                         "valu_ceiling_frac": _num(rf and rf.get("valu_ceiling_frac")),
+                         "pass_structure_ceiling_frac": _num(rf and rf.get("pass_structure_ceiling_frac")),
+                         "physical_frac_from_profile": _num(rf and rf.get("physical_frac")),
+                         "profile_source": rj and {"file": rj["profile_file"], "stale": rj["stale"]}},
             "merkle": {"permutations": perms, "Gperm_per_s": _num(perms / (merkle_ms * 1e-3) / 1e9 if merkle_ms else None),
                        "ms": _num(merkle_ms)},
         }
@@ -397,6 +439,11 @@ class ProveLeg:
             alu.update({"valu_instr_per_permutation": ipp, "achieved": ach, "frac": ach / peak,
                         "issue_cost_floor_frac": _num(ipp * leaf_perms / 64.0 * cyc / (SIMDS * CLOCK_HZ * leaves_ms * 1e-3)) if cyc else None,
                         "source": pj.get("profile_file"), "stale": pj.get("stale")})
+            kj = None if bb else _latest_profile("r*_leaf_kernel_probe.json")
+            if kj and cyc:   # the same floor at the clock the chip holds under this load (s_memtime probes, tools/probe_leaves.py)
+                alu["shader_clock_hz_under_load"] = kj["shader_clock_hz_under_load"]
+                alu["issue_cost_floor_frac_at_measured_clock"] = _num(ipp * leaf_perms / 64.0 * cyc / (SIMDS * kj["shader_clock_hz_under_load"] * leaves_ms * 1e-3))
+                alu["clock_source"] = {"file": kj["profile_file"], "stale": kj["stale"]}
             mpp = pj.get("mfma_instr_per_permutation")
             if mpp:   # Goldilocks: the MDS layers run on the matrix pipe - v_mfma_i32_32x32x32_i8, 32 cycles each on its SIMD
                 alu["mfma_instr_per_permutation"] = mpp
@@ -658,7 +705,9 @@ def main():
                          "batch of that many proofs")
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cols", type=int, default=135)
-    ap.add_argument("--cpu-sample-log-n", type=int, default=None)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=None,
+                    help="rows of the CPU baseline's circuit; default: --log-n itself when a calibration run says it fits --cpu-budget-s")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-babybear", action="store_true", help="skip the BASELINE configs[3] leg of the default run")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident-witness leg (value_hbm_resident)")
@@ -796,11 +845,9 @@ def main():
             from oracle import oracle as _O
             cores = _O.host_cpu_share()
             bbf = args.field == "babybear"
-            sample = args.cpu_sample_log_n
-            if sample is None:
-                sample = max(8, min(log_n, 19 if bbf else 18, (15 if bbf else 14) + (cores.bit_length() - 1)))  # ~10-30 s of CPU work
             ch = args.challenges or max(6 if bbf else 2, -(-100 // ((31 if bbf else 64) - log_n)))
-            out["cpu_baseline"] = cpu_baseline_prove(log_n, ch, sample, args.field)
+            # default: the benchmark's own circuit when the calibrated estimate fits the budget (~50 s on 16 cores at 2^20 rows)
+            out["cpu_baseline"] = cpu_baseline_prove(log_n, ch, args.cpu_sample_log_n, args.field, args.cpu_budget_s)
     else:
         ncols, n = args.cols, 1 << log_n
         host = splitmix64_matrix((0xC0FFEE ^ (ncols << 32) ^ log_n) + rank, ncols, n)

@@ -848,6 +848,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
 
     const u64* src = static_cast<const u64*>(cols.base);
     const bool staged = !dev_in && !is_coeffs && log_n >= 12;
+    const bool fused_ntt = !is_coeffs && log_n == 20 && gbk::ntt_knobs().fuse_intt_lde;
     if (staged) {
         // column chunks: H2D into values_dev on the copy stream, then (main stream, behind an event) inverse NTT and LDE of the chunk
         const size_t CH = 16;
@@ -864,8 +865,13 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
                  hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
             if (!ok) break;
             if (p3) gbk::gl_canonicalize(vals + c0 * n, cc * n, st);   // p3-goldilocks keeps any u64 representative in memory
-            { Scope sc(ctx, "IFFT"); gbk::gl_intt_columns(vals + c0 * n, b->coeffs + c0 * n, (u64*)ctx->scratch.p, cc, *tabs, st); }
-            { Scope sc(ctx, "FFT + blinding"); gbk::gl_lde_columns(b->coeffs + c0 * n, b->lde + c0 * N, cc, *tabs, *cos, st); }
+            if (fused_ntt) {   // 2^20 rows: the inverse transform's last pass and the LDE's first are one kernel (timed under the LDE's scope)
+                Scope sc(ctx, "FFT + blinding");
+                gbk::gl_from_values_columns(vals + c0 * n, b->coeffs + c0 * n, b->lde + c0 * N, (u64*)ctx->scratch.p, cc, *tabs, *cos, st);
+            } else {
+                { Scope sc(ctx, "IFFT"); gbk::gl_intt_columns(vals + c0 * n, b->coeffs + c0 * n, (u64*)ctx->scratch.p, cc, *tabs, st); }
+                { Scope sc(ctx, "FFT + blinding"); gbk::gl_lde_columns(b->coeffs + c0 * n, b->lde + c0 * N, cc, *tabs, *cos, st); }
+            }
             if (!hash_ready_segments(c0 + cc)) return cleanup(fail(ctx, GB_ERR_OOM, "sponge state"));
         }
         if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
@@ -879,12 +885,15 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
     }
     if (!is_coeffs && !staged) {
         if ((s = ensure(ctx, ctx->scratch, ncols * n * sizeof(u64)))) return cleanup(s);
-        Scope sc(ctx, "IFFT");
-        gbk::gl_intt_columns(src, b->coeffs, (u64*)ctx->scratch.p, ncols, *tabs, st);
+        if (!fused_ntt) {
+            Scope sc(ctx, "IFFT");
+            gbk::gl_intt_columns(src, b->coeffs, (u64*)ctx->scratch.p, ncols, *tabs, st);
+        }
     }
     {
         Scope sc(ctx, "FFT + blinding");
-        if (!staged) gbk::gl_lde_columns(b->coeffs, b->lde, ncols, *tabs, *cos, st);
+        if (!staged && fused_ntt) gbk::gl_from_values_columns(src, b->coeffs, b->lde, (u64*)ctx->scratch.p, ncols, *tabs, *cos, st);
+        else if (!staged) gbk::gl_lde_columns(b->coeffs, b->lde, ncols, *tabs, *cos, st);
         if (nsalt) {
             // salt columns arrive in LDE-point order (like lde_values' extra columns, oracle.rs:144-148)
             // and are stored, like everything else, in leaf order: leaf j <- point bitrev(j)
@@ -1124,10 +1133,10 @@ gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) {
         ctx->upload_legacy_chunks = value != 0;
     } else if (k == "retry_verify") {
         ctx->retry_verify = value != 0;
-    } else if (k == "lde_group" || k == "pa_log_split" || k == "intt_group") {   // process-wide (kernels_ntt.hip)
+    } else if (k == "lde_group" || k == "pa_log_split" || k == "intt_group" || k == "fuse_intt_lde") {   // process-wide (kernels_ntt.hip)
         if (value < 0 || value > 4096) return fail(ctx, GB_ERR_INVALID, "option value out of range");
         gbk::NttKnobs& kn = gbk::ntt_knobs_mut();
-        (k == "lde_group" ? kn.lde_group : k == "pa_log_split" ? kn.pa_log_split : kn.intt_group) = (u32)value;
+        (k == "lde_group" ? kn.lde_group : k == "pa_log_split" ? kn.pa_log_split : k == "intt_group" ? kn.intt_group : kn.fuse_intt_lde) = (u32)value;
     } else {
         return fail(ctx, GB_ERR_INVALID, "unknown option: " + k);
     }

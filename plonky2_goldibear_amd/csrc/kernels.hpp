@@ -44,6 +44,7 @@ struct NttKnobs {
     u32 lde_group;     // Goldilocks columns per PA -> PB group (BabyBear: twice as many)
     u32 pa_log_split;  // log2 of the workgroups that share a PA tile's cosets
     u32 intt_group;    // Goldilocks columns per inverse-transform group (BabyBear: twice as many)
+    u32 fuse_intt_lde; // 1: from_values at 2^20 rows runs the inverse transform's last pass and the LDE's strided pass as one kernel
 };
 const NttKnobs& ntt_knobs();
 NttKnobs& ntt_knobs_mut();
@@ -55,6 +56,9 @@ void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, co
 // any u64 representative -> the canonical one, in place (GB_INPUT_P3_REPR: p3-goldilocks' in-memory words)
 void gl_canonicalize(u64* p, size_t count, hipStream_t stream);
 
+// values -> coefficients (kept) -> LDE, with the last inverse pass and the first LDE pass fused where the shape allows (2^20 rows)
+void gl_from_values_columns(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
+                            hipStream_t stream);
 // coefficients [ncols][n] -> LDE [ncols][N] in LEAF order: lde[c][j] = P_c(7 * w_N^bitrev_logN(j))
 // (fri/oracle.rs:108-109 order, no transpose / bit-reverse pass needed afterwards).
 void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,

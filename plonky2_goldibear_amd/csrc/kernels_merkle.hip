@@ -66,6 +66,22 @@ extern "C" int gb_probe_setup(void* dev_buf, unsigned max_per_wave, unsigned wav
 #define GB_PROBE_INIT(amat) do {} while (0)
 #endif
 
+// The NEXT absorption's eight columns on their way while this one is permuted (GB_ABSORB_PREFETCH: an experiment of round 5, off in
+// the product).  A wave reads 512 contiguous bytes per column, and the s_memtime attribution
+// (profiles/r05_leaf_kernel_probe_attribution.txt) shows it parked ~10 k cycles per absorption on those loads; there are no sixteen
+// registers to land them in early (128 VGPRs, 4 waves per SIMD), so one throw-away dword per lane and column pulls the lines into
+// the cache hierarchy instead.  Measured: 41.0 ms with, 41.0-41.2 ms without (profiles/r05_leaf_kernel_ab.txt) - the three other
+// waves of the SIMD issue while one waits, nothing is gained.  (The asm loads are older than any load the compiler counts in vmcnt
+// and return in order: its waits stay correct.)
+__device__ __forceinline__ void prefetch_columns(const u64* __restrict__ cols, size_t col_stride, u32 c0, u32 c_end, u64 j) {
+#ifdef GB_ABSORB_PREFETCH
+    u32 sink;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (c0 + i < c_end) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(cols + (size_t)(c0 + i) * col_stride + j) : "memory");
+#endif
+}
+
 // hash/hashing.rs:100-123 (overwrite-mode sponge, rate 8) + plonk/config.rs:70-84 (hash_or_noop)
 __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
                                                                         u64 num_leaves, u64* __restrict__ out) {
@@ -96,6 +112,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const
                 for (int i = 0; i < 8; i++)
                     if (c0 + i < width) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
             }
+            prefetch_columns(cols, col_stride, c0 + 8, width, j);
             GB_PROBE_AT(amat, 2, s);   // absorption: 8 column loads + to_mont
             // (a full absorption follows: words 0..7 of this permutation's output will be overwritten - only the capacity is produced)
             permute_mont_mfma(s, amat, c0 + 16 <= width);  // the state stays a lazy Montgomery-form residue between absorptions
@@ -145,6 +162,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(c
             for (int i = 0; i < 8; i++)
                 if (c0 + i < c_end) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
         }
+        prefetch_columns(cols, col_stride, c0 + 8, c_end, j);
         // is the absorption that follows (in this segment or at the head of the next) a full one?  then only the capacity matters
         const bool next_full = LAST ? c0 + 16 <= c_end : (c0 + 8 < c_end || keep_from == 8);
         permute_mont_mfma(s, amat, next_full);

@@ -270,8 +270,8 @@ static InvGeom inv_geom(u32 L) {
 // (8.55 ms with all columns per launch, 8.7-14.5 ms in groups of 16..1) - so the LDE default stays "all columns"; the three
 // memory-bound passes of the inverse transform gain 8 % in groups of 16 columns (1.49 -> 1.36 ms).  The knobs remain for ablations
 // (gb_ctx_set_option).
-NttKnobs& ntt_knobs_mut() {   // gb_ctx_set_option("lde_group" / "pa_log_split" / "intt_group"): process-wide
-    static NttKnobs k{0, 0, 16};
+NttKnobs& ntt_knobs_mut() {   // gb_ctx_set_option("lde_group" / "pa_log_split" / "intt_group" / "fuse_intt_lde"): process-wide
+    static NttKnobs k{0, 0, 16, 0};   // fuse_intt_lde off: measured no faster (profiles/r05_ntt_fused_p3_pa_ablation_goldilocks.txt)
     return k;
 }
 const NttKnobs& ntt_knobs() { return ntt_knobs_mut(); }
@@ -305,6 +305,28 @@ static void gl_intt_group(const u64* src, u64* coeffs, u64* scratch, size_t ncol
     }
     hipLaunchKernelGGL(k_gl_intt_p3, dim3((u32)(ncols << (g.LB + g.LA - 4))), dim3(THREADS), 0, stream, scratch, coeffs,
                        g, t.tw4096_inv, t.n_inv);
+}
+
+bool gl_intt_pa_fused_r16(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
+                          hipStream_t stream);
+
+// from_values in one go: values -> coefficients (kept: a required output) -> LDE.  With the option "fuse_intt_lde" = 1 the inverse
+// transform's last pass and the LDE's strided pass are ONE kernel per group of columns at 2^20 rows (k_gl_intt16_p3_pa16x2: the
+// coefficient tile goes on in registers, PA's re-read of the column and a launch disappear: 31 -> 30 n s of physical traffic per
+// column).  Round 5 built and measured it: 4.70-4.71 ms fused against 4.24-4.29 (PA) + 0.47 (P3) ms apart, the whole NTT 10.42-10.44
+// against 10.34-10.40 ms per 135 columns - the strided pass is bound by VALU issue, not by the read it saves.  Default: off.
+void gl_from_values_columns(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
+                            hipStream_t stream) {
+    const u32 L = t.log_n, r = ct.rate_bits;
+    if (L != 20 || !ntt_knobs().fuse_intt_lde || ntt_knobs().lde_group || ntt_knobs().pa_log_split) {
+        gl_intt_columns(src, coeffs, scratch, ncols, t, stream);
+        gl_lde_columns(coeffs, lde, ncols, t, ct, stream);
+        return;
+    }
+    const size_t g = ntt_knobs().intt_group ? ntt_knobs().intt_group : ncols, n = (size_t)1 << L;
+    for (size_t c0 = 0; c0 < ncols; c0 += g)   // the scratch block of one group is reused by the next: it never leaves the cache
+        gl_intt_pa_fused_r16(src + c0 * n, coeffs + c0 * n, lde + (c0 << (L + r)), scratch, std::min(g, ncols - c0), t, ct, stream);
+    gl_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
 }
 
 void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,

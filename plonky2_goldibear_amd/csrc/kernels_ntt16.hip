@@ -477,6 +477,82 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p3(const u64* __restrict_
     }
 }
 
+// P3 + PA in one kernel (2^20 rows; round 5): P3's output tile - coefficients l = 16 tg .. 16 tg + 15 at every stride-4096 position
+// a < 256, tg = 16 k_b + g_a - is exactly the tile k_gl_lde_pa16x2 reads, and P3's stage-2 thread (k_c1 slot hi4, i_a = lo4) ends
+// up holding the sixteen values PA's stage-1 thread (a0 = brev4(hi4), j = lo4) starts from (a = k_c = a0 + 16 brev4(s)).  So the
+// coefficients are written once, as the required output of from_values (fri/oracle.rs:82-90), and go on into the coset loop in
+// registers: PA's read of the column (n s bytes) and one launch disappear.  Thread roles of the PA half: stage 1 with a0 = brev4(hi4)
+// (its LDS row hi4 holds a0 = brev4(hi4)), stage 2 as in k_gl_lde_pa16x2.
+__global__ __launch_bounds__(THREADS, 3) void k_gl_intt16_p3_pa16x2(const u64* __restrict__ src, u64* __restrict__ coeffs, u64* __restrict__ lde,
+                                                                 u32 rate_bits, const u64* __restrict__ tw4096_inv, u64 n_inv,
+                                                                 const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
+                                                                 const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
+                                                                 const u64* __restrict__ pow_hi) {
+    constexpr u32 L = 20;
+    __shared__ u64 sh[16 * 272];
+    __shared__ u64 tw256[256];
+    const size_t col = blockIdx.x >> 8;
+    const u32 tg = blockIdx.x & 255, kb = tg >> 4, ga = tg & 15;
+    const size_t cbase = col << L;
+    const size_t sbase = cbase + ((size_t)kb << 16) + ((size_t)(16 * ga) << 8);
+    const u32 tid = threadIdx.x, hi4 = tid >> 4, lo4 = tid & 15;
+    tw256[tid] = tw4096[tid * 16];
+    u64 orig[16];
+    {   // ---- the inverse transform's last pass (k_gl_intt16_p3)
+        u64 x[16];
+#pragma unroll
+        for (u32 c1 = 0; c1 < 16; c1++) x[c1] = src[sbase + hi4 * 256 + c1 * 16 + lo4];
+        u64 tw[16];
+        load_tw16(tw, tw4096_inv, lo4 * 16);  // w_256^-(k_c1 c0)
+        dft16<true>(x);
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) sh[s * 272 + lo4 * 17 + hi4] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
+        __syncthreads();
+#pragma unroll
+        for (u32 c0 = 0; c0 < 16; c0++) x[c0] = sh[hi4 * 272 + c0 * 17 + lo4];
+        dft16<true>(x);
+        const u32 kc1 = brev4(hi4);
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) {
+            const u32 kc = kc1 + 16 * brev4(s);
+            const u64 v = gl::mul_mont(x[s], n_inv);
+            coeffs[cbase + ((size_t)kc << 12) + ((size_t)kb << 8) + 16 * ga + lo4] = v;
+            orig[brev4(s)] = v;                     // a = k_c = a0 + 16 a1: a0 = brev4(hi4), a1 = brev4(s)
+        }
+    }
+    __syncthreads();   // sh is reused below; tw256 visible
+    // ---- the LDE's strided pass over the tile (k_gl_lde_pa16x2)
+    const u32 a0 = brev4(hi4), j = lo4;
+    const u32 l = (tg << 4) + j;
+    const size_t n = (size_t)1 << L;
+    const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
+    const u64 f0 = tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // stage 2: w_n^(k_a1 l), k_a1 slot = hi4
+    for (u32 c = 0; c < (1u << rate_bits); c++) {
+        const u64* ph = pow_hi + (size_t)c * 256 + a0;
+        u64 x[16];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = ph[a1 * 16];  // s_c^(4096 a)
+        const u64 sl = pow_lo[(size_t)c * 4096 + l];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul_mont<true>(orig[a1], x[a1]);
+        dft16<false>(x);
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul_mont<true>(x[s], tw256[(brev4(s) * a0) & 255]) : x[s];  // [k_a1 slot][row hi4 = brev4(a0)][j]
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) x[q] = sh[hi4 * 272 + brev4(q) * 16 + j];   // digit a0 = q sits in row brev4(q)
+        dft16<false>(x);
+        u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+        u64 f = gl::mul_mont_lazy<true>(sl, f0);
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
+            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul_mont<true>(x[brev4(k)], f);
+            if (k < 15) f = gl::mul_mont_lazy<true>(f, ratio);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ launchers (called from kernels_ntt.hip's dispatchers)
 // Every kernel of this file takes the MONTGOMERY-form copies of the tables (GlNttTables::*_m, GlCosetTables::*_m): all of their
 // general multiplications have a table value as one factor (gl::mul_mont).
@@ -496,6 +572,19 @@ bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols
     else if (g.LB == 1) hipLaunchKernelGGL(k_gl_intt16_p2s<1>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv_m);
     hipLaunchKernelGGL(k_gl_intt16_p3, dim3((u32)(ncols << (g.LB + 4))), dim3(THREADS), 0, stream, scratch, coeffs, g,
                        t.tw4096_inv_m, t.n_inv_m);
+    return true;
+}
+
+// values -> coefficients AND the strided LDE pass, the last inverse pass fused with it (2^20 rows); false: shape not covered
+bool gl_intt_pa_fused_r16(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
+                          hipStream_t stream) {
+    if (t.log_n != 20 || ncols == 0) return false;
+    Inv16Geom g{20, 4};
+    hipLaunchKernelGGL(k_gl_intt16_p1, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, src, coeffs, g, t.tw4096_inv_m, t.tw_hi_inv_m,
+                       t.tw_lo_inv_m);
+    hipLaunchKernelGGL(k_gl_intt16_p2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, scratch, 20u, t.tw4096_inv_m);
+    hipLaunchKernelGGL(k_gl_intt16_p3_pa16x2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, scratch, coeffs, lde, ct.rate_bits,
+                       t.tw4096_inv_m, t.n_inv_m, t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
     return true;
 }
 

@@ -442,6 +442,60 @@ __device__ __forceinline__ void byte_transpose4(u32 w0, u32 w1, u32 w2, u32 w3, 
     t[2] = __builtin_amdgcn_perm(b_hi, a_hi, 0x05040100u);
     t[3] = __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
 }
+// The high words of four folds at once: r1[i] = th[i] + sh[i] (mod 2^32) and cnt += the carries, ALL ON THE VECTOR SIDE - an
+// experiment of round 5 (GB_FOLD_VCNT), NOT the product.  The product's fold ORs every add's carry mask into a scalar register pair:
+// twelve VALU -> SALU hand-overs per fold, and the s_memtime attribution (profiles/r05_leaf_kernel_probe_attribution.txt) shows a wave
+// spending 7.6 % of its lifetime in the folds for 2.3 % of its issue work.  Counting the carries with v_addc through three rotating
+// scalar pairs and looking at the counter once per fold removes those hand-overs - and makes the kernel 1.4 % SLOWER
+// (41.0-41.2 -> 41.5-41.8 ms, profiles/r05_leaf_kernel_ab.txt): while one wave waits for its scalar OR the three others issue, so
+// the wait costs the SIMD nothing, and the twelve extra vector instructions do.  The kernel's time is its VALU instruction count.
+// Inline asm: the hazard recognizer does not see it, so the sequence itself keeps two instructions between a VALU write of a
+// scalar pair and the VALU read of it (gfx940+: VALU writes SGPR -> VALU reads it: 2 wait states).
+__device__ __forceinline__ void fold_high4(u32 (&r1)[4], const u32 (&th)[4], const u32 (&sh)[4], u32& cnt) {
+    u64 ca, cb, cc;   // three rotating carry masks (scalar register pairs)
+    asm("v_add_co_u32 %0, %5, %8, %12\n\t"
+        "v_add_co_u32 %1, %6, %9, %13\n\t"
+        "v_add_co_u32 %2, %7, %10, %14\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %5\n\t"
+        "v_add_co_u32 %3, %5, %11, %15\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %6\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %7\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %5"
+        : "=&v"(r1[0]), "=&v"(r1[1]), "=&v"(r1[2]), "=&v"(r1[3]), "+v"(cnt), "=&s"(ca), "=&s"(cb), "=&s"(cc)
+        : "v"(th[0]), "v"(th[1]), "v"(th[2]), "v"(th[3]), "v"(sh[0]), "v"(sh[1]), "v"(sh[2]), "v"(sh[3])
+        : "vcc");
+}
+// (lo, hi)[Q0 .. 12) -> s[q] = lo + 2^32 hi as a lazy residue: value = (lo + (hi >> 32) EPS) + 2^32 (u32)hi, and the last addition
+// wraps only when (u32)hi lies within 2^12 of 2^32 - about 4e-4 of the wave-folds have such a lane.  The fast path is one mad and one
+// add per word (+ a quarter of fold_high4's counter adds); a wave in which any lane wrapped takes the branch and adds EPS (= 2^64
+// mod p) in those lanes (no second wrap: a wrapped high word is < 2^12).
+template <int Q0>
+__device__ __forceinline__ void fold_rows_counted(u64 (&s)[12], const long long (&lo)[12], const long long (&hi)[12]) {
+    static_assert((12 - Q0) % 4 == 0, "words are folded four at a time");
+    u32 cnt = 0;
+#pragma unroll
+    for (int q0 = Q0; q0 < 12; q0 += 4) {
+        u32 tl[4], th[4], sh[4], r1[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const u64 t = (u64)lo[q0 + i] + (u64)(u32)((u64)hi[q0 + i] >> 32) * EPS;
+            tl[i] = (u32)t;
+            th[i] = (u32)(t >> 32);
+            sh[i] = (u32)hi[q0 + i];
+        }
+        fold_high4(r1, th, sh, cnt);
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[q0 + i] = (u64)tl[i] | ((u64)r1[i] << 32);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt != 0) != 0, 0)) {
+#pragma unroll
+        for (int q = Q0; q < 12; q++) {
+            const bool wrapped = (u32)(s[q] >> 32) < (u32)hi[q];   // r1 = t_hi + (u32)hi wrapped  <=>  r1 < (u32)hi
+            s[q] += wrapped ? EPS : 0;
+        }
+    }
+}
+
 // This lane's share of the constant A operand (see above); call with all 64 lanes of the wave active, blockDim.x a multiple of 64.
 __device__ __forceinline__ MdsOperand mds_mfma_matrix() {
     const u32 l = threadIdx.x & 63, r = l & 31, h = l >> 5;
@@ -539,6 +593,9 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& a
     // addition wraps only when (u32)hi lies within 2^12 of 2^32 - about 4e-4 of the wave-layers have such a lane.  The fast path
     // is one mad and one add per word; the wave-wide OR of the carries is scalar work, and a wave in which any lane wrapped
     // takes the branch and adds EPS (= 2^64 mod p) in those lanes (no second wrap: a wrapped high word is < 2^12).
+#ifdef GB_FOLD_VCNT   // round 5 A/B: the carries counted on the vector side (fold_rows_counted) - 1.4 % SLOWER, see fold_high4
+    fold_rows_counted<Q0>(s, lo, hi);
+#else
     u64 any_carry = 0;
 #pragma unroll
     for (int q = Q0; q < 12; q++) {
@@ -557,6 +614,7 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& a
             s[q] += wrapped ? EPS : 0;
         }
     }
+#endif
 }
 
 // Four full rounds; the state comes in with round0's constants already added, and leaves with `tail_rc` added (the

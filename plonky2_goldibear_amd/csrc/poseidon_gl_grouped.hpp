@@ -297,7 +297,11 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
 #ifdef GB_PROBE
     probe_pin(lo); probe_pin(hi); probe_stamp<35>(amat);   // group: phase B MFMA chains + recombination
 #endif
+#ifdef GB_FOLD_VCNT   // round 5 A/B (poseidon_gl.hpp, fold_high4): slower, not the product
+    fold_rows_counted<0>(s, lo, hi);
+#else
     fold_rows_rare_carry(s, lo, hi);
+#endif
     GB_PROBE_AT(amat, 36, s);   // group: fold
 }
 

@@ -65,18 +65,27 @@ k:
     assert raw[3] == 10   # s_nop 9 = ten wait states: two short of what a read needs
 
 
-def test_guard_reports_tiles_in_accumulation_registers():
-    """the RAW / WAW walk sees v-registers only; a kernel that keeps MFMA tiles in a[..] must not pass silently"""
+def test_guard_follows_tiles_in_accumulation_registers():
+    """the FRI-leaf / proof-of-work kernels keep their MFMA tiles in a[..]; the walk follows those registers too - a read
+    (v_accvgpr_read) or write (v_accvgpr_write) of a tile register too soon after the MFMA is reported like a v-register one"""
     text = """
 k:
 	v_mov_b32_e32 v20, 0
+	v_mov_b32_e32 v21, 0
+	v_mov_b32_e32 v22, 0
+	v_mov_b32_e32 v23, 0
 	v_mfma_i32_32x32x32_i8 a[0:15], v[20:23], v[20:23], 0
-	s_nop 15
+	s_nop 5
 	v_accvgpr_read_b32 v40, a3
+	v_accvgpr_write_b32 a14, v20
+	s_nop 15
+	v_accvgpr_read_b32 v41, a4
 	s_endpgm
 """
     n, out = mfma_guard.check_text(text)
-    assert n == 1 and [f[0] for f in out].count("agpr") == 2, out
+    kinds = sorted(f[0] for f in out)
+    assert n == 1 and kinds == ["RAW", "WAW"], out
+    assert mfma_guard.regs_of("a[2:3]") == [514, 515] and mfma_guard.regs_of("v7") == [7]
 
 
 def test_guard_follows_loop_back_edges():

@@ -13,9 +13,8 @@ order and reports, per MFMA destination tile,
          it parks another value in a DEAD register of the tile (outputs the kernel never reads),
   * partial: an MFMA whose accumulator operand overlaps a tile in flight without being that tile,
   * undefined: an MFMA source register that no instruction of the kernel ever writes.
-  * agpr: the checks above follow ARCHITECTURAL vector registers only.  A kernel whose MFMA tiles live in accumulation registers
-         (a[..] operands, v_accvgpr_read / v_accvgpr_write) would pass them unexamined, so it is reported instead: every product
-         kernel has NumAgprs 0 today, and a register-budget change that moves tiles there must extend this guard first.
+Accumulation registers (a[..] tiles, v_accvgpr_read / v_accvgpr_write: the FRI-leaf and proof-of-work kernels keep their tiles
+there) are followed like architectural ones, in a register namespace of their own (a<N> = register 512 + N).
 
 Wait states are counted as the hazard recognizer counts them: one per instruction, s_nop N = N + 1.  Program order is walked once (a
 forward branch does not reset the count: conservative), and every backward branch is followed once more - the top of its loop is
@@ -34,17 +33,18 @@ RAW_MIN = 12
 WAW_MIN = 9
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
-AREG = re.compile(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b")
+REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+AGPR_BASE = 512   # a<N> is register 512 + N of the walk: its own namespace beside v0..v511
 
 
 def regs_of(operand):
     out = []
     for m in REG.finditer(operand):
-        if m.group(3) is not None:
-            out.append(int(m.group(3)))
+        if m.group(5) is not None:
+            out.append(int(m.group(5)) + (AGPR_BASE if m.group(4) == "a" else 0))
         else:
-            out.extend(range(int(m.group(1)), int(m.group(2)) + 1))
+            base = AGPR_BASE if m.group(1) == "a" else 0
+            out.extend(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
     return out
 
 
@@ -118,8 +118,6 @@ def check_kernel(name, body):
             ws = 1
             if op == "s_nop":
                 ws = int(line.split(";")[0].split()[1], 0) + 1
-            if collect and (op.startswith("v_accvgpr") or (op.startswith(("v_mfma", "v_smfmac")) and AREG.search(line.split(";")[0].split(None, 1)[1]))):
-                findings.append(("agpr", name, ln, 0, line.strip(), "accumulation registers are outside this guard's model"))
             if op.startswith("v_mfma") or op.startswith("v_smfmac"):
                 ops = split_operands(line.split(";")[0].strip().split(None, 1)[1])
                 dst = set(regs_of(ops[0]))

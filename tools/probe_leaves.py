@@ -132,6 +132,7 @@ def run():
     b.free()
     perms = -(-ncols // 8)
     seg_cyc, seg_cnt, life = collections.Counter(), collections.Counter(), []
+    first_ts, last_ts = [], []
     for w in range(nslots):
         ids = t[w, :, 1]
         k = int(np.count_nonzero(ids))
@@ -143,11 +144,15 @@ def run():
             seg_cyc[(int(a), int(bb))] += int(c)
             seg_cnt[(int(a), int(bb))] += 1
         life.append(int(ts[-1] - ts[0]))
+        first_ts.append(int(ts[0]))
+        last_ts.append(int(ts[-1]))
     nw = len(life)
     total = sum(seg_cyc.values())
     stat = static_segments()
     print("k_gl_merkle_leaves (attribution build, -DGB_PROBE), wires commitment 135 x 2^20 Goldilocks: 'hash leaves' %.2f ms with probes" % ms)
     print("%d traced waves, %.0f wave cycles (s_memtime) from first to last probe on average, %d permutations per wave" % (nw, np.mean(life), perms))
+    clock_hz = (max(last_ts) - min(first_ts)) / (ms * 1e-3)   # traced waves are spread over the whole grid: first to last stamp = the kernel
+    print("shader clock under this load: %.3f GHz (first to last time stamp of the traced waves / the kernel's 'hash leaves' scope)" % (clock_hz / 1e9))
     print()
     print("%-58s %6s %9s %7s | %5s %5s %5s %4s %5s %5s %4s %8s %6s" % ("segment (site a -> site b)", "n/perm", "cyc/occ", "share", "mad", "pl32", "other",
                                                                         "mfma", "nopws", "salu", "lds", "model", "cyc/m"))
@@ -180,6 +185,15 @@ def run():
         tot_c, tot_m = tot_c + c, tot_m + m
     print("%-28s %6.1f%% %14.0f %14.0f %8.2f" % ("all", 100.0, tot_c, tot_m, tot_c / tot_m))
     print()
+    out_json = os.environ.get("GB_PROBE_JSON")
+    if out_json:
+        import json
+        from csrc_hash import measured_sha16
+        json.dump({"kernel": "gbk::k_gl_merkle_leaves (attribution build, -DGB_PROBE)", "hash_leaves_ms_with_probes": ms, "traced_waves": nw,
+                   "wave_cycles_per_permutation": tot_c, "model_issue_cycles_per_permutation": tot_m,
+                   "simd_issue_utilisation_vs_model": 4.0 * tot_m / tot_c, "shader_clock_hz_under_load": clock_hz,
+                   "classes": {cls: {"share": v[0], "wave_cycles_per_permutation": v[1], "model_cycles_per_permutation": v[2]} for cls, v in agg.items()},
+                   "csrc_sha16": measured_sha16()}, open(out_json, "w"), indent=1)
     print("cyc/m = wave cycles per model issue cycle: four waves share a SIMD, so a segment that issues exactly as the cost model says reads 4.0 / (SIMD issue "
           "utilisation); a larger figure is a segment in which the wave waits for something its three neighbours do not fill")
 
