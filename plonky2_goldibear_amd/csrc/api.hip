@@ -81,6 +81,7 @@ struct gb_ctx {
     std::multimap<size_t, void*> pool;                      // freed batch blocks by size (stream-ordered reuse)
     DeviceBuf scratch;                                      // grow-only workspace
     DeviceBuf small;                                        // small gather staging (rows, siblings)
+    DeviceBuf big_work;                                     // log_n > 20: work buffer of the outer radix step (ntt_outer.hpp)
     hipEvent_t upload_mark = nullptr;                       // recorded on `stream` after the last host -> device copy of a commit
     bool upload_marked = false;
     std::vector<gb_circuit*> circuits;                      // live circuits of this context: what they keep for gb_prove_retry is
@@ -260,6 +261,12 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
     }
     GlTableSet set;
     set.t.log_n = log_n;
+    set.t.sub = nullptr;
+    if (log_n > 20) {   // the outer radix step (ntt_outer.hpp) runs the 2^20-row passes: their tables first (std::map nodes do not move)
+        const gbk::GlNttTables* sub20;
+        if (gb_status s20 = gl_tables_for(ctx, 20, &sub20)) return s20;
+        set.t.sub = sub20;
+    }
     set.t.tw4096_fwd = ctx->tw4096_fwd;
     set.t.tw4096_inv = ctx->tw4096_inv;
     set.t.tw4096_fwd_m = ctx->tw4096_fwd_m;
@@ -294,10 +301,26 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
 // coset c (block c of n leaves) has shift s_c = shift * w_N^bitrev_r(c): leaf j = c*n + jl is the LDE
 // point shift * w_N^bitrev_logN(j) (fri/oracle.rs:109 + polynomial/mod.rs:282-295; shift = 7, or
 // 7^(arity^l) for FRI layer l, fri/prover.rs:122-123).  inverse: tables of s_c^-1 instead.
+// log_n > 20: the work buffer of the outer radix step (de-interleaved coefficients + sub-LDEs of a group of columns), grown on demand
+gb_status ensure_big_work(gb_ctx* ctx, u32 log_n, u32 rate_bits, size_t es, void** p, size_t* elems) {
+    const size_t n = (size_t)1 << log_n, per_col = n + (n << rate_bits), cols = 8;
+    if (gb_status s = ensure(ctx, ctx->big_work, cols * per_col * es)) return s;
+    *p = ctx->big_work.p;
+    *elems = ctx->big_work.bytes / es;
+    return GB_OK;
+}
 gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u64 shift, bool inverse, const gbk::GlCosetTables** out) {
     auto key = std::make_tuple(log_n, rate_bits, shift, inverse ? 1 : 0);
     auto it = ctx->gl_cosets.find(key);
-    if (it != ctx->gl_cosets.end()) { *out = &it->second.t; return GB_OK; }
+    if (it != ctx->gl_cosets.end()) {
+        if (log_n > 20) {   // the work buffer may have moved since (ensure() grows by reallocating)
+            void* w; size_t we;
+            if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u64), &w, &we)) return sw;
+            it->second.t.work = (u64*)w; it->second.t.work_elems = we;
+        }
+        *out = &it->second.t;
+        return GB_OK;
+    }
     size_t n = (size_t)1 << log_n;
     size_t nlo = n < 4096 ? n : 4096, nhi = n > 4096 ? n / 4096 : 1;
     u32 nc = 1u << rate_bits;
@@ -312,6 +335,15 @@ gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u64 shift, bool i
     }
     GlCosetSet set;
     set.t.rate_bits = rate_bits;
+    set.t.sub = nullptr; set.t.work = nullptr; set.t.work_elems = 0;
+    if (log_n > 20) {   // sub-transforms of 2^20 rows on the shift s_c^R, R = n / 2^20 (ntt_outer.hpp)
+        const gbk::GlCosetTables* sub20;
+        if (gb_status s20 = gl_cosets_for(ctx, 20, rate_bits, gl::pow(shift, (u64)1 << (log_n - 20)), inverse, &sub20)) return s20;
+        set.t.sub = sub20;
+        void* w; size_t we;
+        if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u64), &w, &we)) return sw;
+        set.t.work = (u64*)w; set.t.work_elems = we;
+    }
     u64 *dlo, *dhi;
     gb_status s;
     if ((s = upload(ctx, lo, &dlo, &set.owned))) return s;
@@ -357,6 +389,12 @@ gb_status bb_tables_for(gb_ctx* ctx, u32 log_n, const gbk::BbNttTables** out) {
     }
     BbTableSet set;
     set.t.log_n = log_n;
+    set.t.sub = nullptr;
+    if (log_n > 20) {
+        const gbk::BbNttTables* sub20;
+        if (gb_status s20 = bb_tables_for(ctx, 20, &sub20)) return s20;
+        set.t.sub = sub20;
+    }
     set.t.tw4096_fwd = ctx->bb_tw4096_fwd;
     set.t.tw4096_inv = ctx->bb_tw4096_inv;
     u32 w = bb::two_adic_generator(log_n), wi = bb::inv(w);
@@ -375,7 +413,15 @@ gb_status bb_tables_for(gb_ctx* ctx, u32 log_n, const gbk::BbNttTables** out) {
 gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u32 shift_mont, bool inverse, const gbk::BbCosetTables** out) {
     auto key = std::make_tuple(log_n, rate_bits, shift_mont, inverse ? 1 : 0);
     auto it = ctx->bb_cosets.find(key);
-    if (it != ctx->bb_cosets.end()) { *out = &it->second.t; return GB_OK; }
+    if (it != ctx->bb_cosets.end()) {
+        if (log_n > 20) {
+            void* w; size_t we;
+            if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u32), &w, &we)) return sw;
+            it->second.t.work = (u32*)w; it->second.t.work_elems = we;
+        }
+        *out = &it->second.t;
+        return GB_OK;
+    }
     size_t n = (size_t)1 << log_n;
     size_t nlo = n < 4096 ? n : 4096, nhi = n > 4096 ? n / 4096 : 1;
     u32 nc = 1u << rate_bits;
@@ -390,6 +436,15 @@ gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u32 shift_mont, b
     }
     BbCosetSet set;
     set.t.rate_bits = rate_bits;
+    set.t.sub = nullptr; set.t.work = nullptr; set.t.work_elems = 0;
+    if (log_n > 20) {
+        const gbk::BbCosetTables* sub20;
+        if (gb_status s20 = bb_cosets_for(ctx, 20, rate_bits, bb::pow(shift_mont, (u64)1 << (log_n - 20)), inverse, &sub20)) return s20;
+        set.t.sub = sub20;
+        void* w; size_t we;
+        if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u32), &w, &we)) return sw;
+        set.t.work = (u32*)w; set.t.work_elems = we;
+    }
     u32 *dlo, *dhi;
     gb_status s;
     if ((s = upload32(ctx, lo, &dlo, &set.owned))) return s;
@@ -645,7 +700,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         return fail(ctx, GB_ERR_INVALID, "LDE size exceeds the field's two-adicity (32 Goldilocks / 27 BabyBear)");
     if (cap_height > log_n + rate_bits)
         return fail(ctx, GB_ERR_INVALID, "cap_height should be at most log2(leaves.len()) (merkle_tree.rs:154-157)");
-    if (log_n > 20) return fail(ctx, GB_ERR_UNSUPPORTED, "log_n > 20 not implemented");
+    if (log_n > 22) return fail(ctx, GB_ERR_UNSUPPORTED, "log_n > 22 not implemented");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
@@ -970,6 +1025,7 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     if (ctx->tw4096_inv_m) hipFree(ctx->tw4096_inv_m);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->small.p) hipFree(ctx->small.p);
+    if (ctx->big_work.p) hipFree(ctx->big_work.p);
     if (ctx->upload_mark) hipEventDestroy(ctx->upload_mark);
     for (auto& kv : ctx->pool) hipFree(kv.second);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);

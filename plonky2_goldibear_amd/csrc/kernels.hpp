@@ -27,6 +27,7 @@ struct GlNttTables {
     // tw4096_fwd_m is [8192]: the powers, then the same powers in k_gl_lde_pb16's stage-1 order [slot][tid]
     const u64 *tw4096_fwd_m, *tw4096_inv_m, *tw_lo_fwd_m, *tw_hi_fwd_m, *tw_lo_inv_m, *tw_hi_inv_m;
     u64 n_inv_m;
+    const GlNttTables* sub;  // log_n > 20: the tables of the 2^20-row transforms the outer radix step runs (ntt_outer.hpp); else null
 };
 
 // Coset tables for the LDE of rate 2^rate_bits: coset c (leaf block c) has shift
@@ -36,6 +37,10 @@ struct GlCosetTables {
     const u64* pow_lo;  // [2^r][min(n,4096)]
     const u64* pow_hi;  // [2^r][max(1, n/4096)]
     const u64 *pow_lo_m, *pow_hi_m;  // the same times R (Montgomery form), for kernels_ntt16.hip
+    // log_n > 20 (ntt_outer.hpp): the coset tables of the 2^20-row sub-transforms (shift^R) and a work buffer of the context
+    const GlCosetTables* sub;
+    u64* work;
+    size_t work_elems;
 };
 
 // Column groups of the multi-pass transforms (kernels_ntt.hip): 0 = one launch per pass over all columns.  Defaults are the
@@ -94,10 +99,14 @@ struct BbNttTables {
     u32 log_n;
     const u32 *tw4096_fwd, *tw4096_inv, *tw_lo_fwd, *tw_hi_fwd, *tw_lo_inv, *tw_hi_inv;
     u32 n_inv;
+    const BbNttTables* sub;   // log_n > 20: see GlNttTables::sub
 };
 struct BbCosetTables {
     u32 rate_bits;
     const u32 *pow_lo, *pow_hi;
+    const BbCosetTables* sub;  // log_n > 20: see GlCosetTables
+    u32* work;
+    size_t work_elems;
 };
 void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
 bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncols, size_t mont_cols, const BbNttTables& t, hipStream_t stream);

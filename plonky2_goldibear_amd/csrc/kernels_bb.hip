@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "kernels.hpp"
+#include "ntt_outer.hpp"
 #include "poseidon2_bb.hpp"
 #include "poseidon2_bb_coop.hpp"
 
@@ -403,6 +404,11 @@ bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncol
     return true;
 }
 void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
+    if (t.log_n > 20) {   // one outer radix step around the 2^20-row passes (ntt_outer.hpp)
+        outer::intt_columns<BbF>(src, coeffs, scratch, ncols, t.log_n, t.tw_hi_inv, t.tw_lo_inv,
+                                 [&](const u32* s, u32* d, u32* scr, size_t nc) { bb_intt_columns(s, d, scr, nc, *t.sub, stream); }, stream);
+        return;
+    }
     const size_t g = 2 * (size_t)ntt_knobs().intt_group, n = (size_t)1 << t.log_n;   // 4-byte words: twice Goldilocks' columns per group
     if (g == 0 || t.log_n < 18 || ncols <= g) return bb_intt_group(src, coeffs, scratch, ncols, t, stream);
     for (size_t c0 = 0; c0 < ncols; c0 += g)
@@ -432,6 +438,11 @@ static void bb_intt_group(const u32* src, u32* coeffs, u32* scratch, size_t ncol
 void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream) {
     const u32 L = t.log_n, r = ct.rate_bits;
     if (!ncols) return;
+    if (L > 20) {
+        outer::lde_columns<BbF>(coeffs, lde, ncols, L, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.work, ct.work_elems,
+                                [&](const u32* c, u32* o, size_t nc) { bb_lde_columns(c, o, nc, *t.sub, *ct.sub, stream); }, stream);
+        return;
+    }
     if (L <= 12) {
         hipLaunchKernelGGL(k_bb_lde_pb<true>, dim3((u32)(ncols << r)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd,
                            ct.pow_lo);

@@ -19,6 +19,7 @@
 
 #include "kernels.hpp"
 #include "gl_field.hpp"
+#include "ntt_outer.hpp"
 
 namespace gbk {
 
@@ -279,6 +280,11 @@ const NttKnobs& ntt_knobs() { return ntt_knobs_mut(); }
 static void gl_intt_group(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
 
 void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream) {
+    if (t.log_n > 20) {   // one outer radix step around the 2^20-row passes (ntt_outer.hpp)
+        outer::intt_columns<GlF>(src, coeffs, scratch, ncols, t.log_n, t.tw_hi_inv, t.tw_lo_inv,
+                                 [&](const u64* s, u64* d, u64* scr, size_t nc) { gl_intt_columns(s, d, scr, nc, *t.sub, stream); }, stream);
+        return;
+    }
     const size_t g = ntt_knobs().intt_group, n = (size_t)1 << t.log_n;
     if (g == 0 || t.log_n < 18 || ncols <= g) return gl_intt_group(src, coeffs, scratch, ncols, t, stream);
     for (size_t c0 = 0; c0 < ncols; c0 += g)   // the scratch block of one group is reused by the next: it never leaves the cache
@@ -333,6 +339,11 @@ void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables
                     hipStream_t stream) {
     const u32 L = t.log_n, r = ct.rate_bits;
     if (ncols == 0) return;
+    if (L > 20) {
+        outer::lde_columns<GlF>(coeffs, lde, ncols, L, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.work, ct.work_elems,
+                                [&](const u64* c, u64* o, size_t nc) { gl_lde_columns(c, o, nc, *t.sub, *ct.sub, stream); }, stream);
+        return;
+    }
     if (L <= 12) {
         hipLaunchKernelGGL(k_gl_lde_pb<true>, dim3((u32)(ncols << r)), dim3(THREADS), 0, stream, coeffs, lde, L, r,
                            t.tw4096_fwd, ct.pow_lo);

@@ -132,13 +132,17 @@ __global__ __launch_bounds__(256) void k_zs_scan_local(ZsParams<F> p, const type
     }
 }
 
-// grid (c), 1024 threads: totals[ch][b] <- exclusive prefix product (nblocks <= 1024)
+// grid (c), 1024 threads: totals[ch][b] <- exclusive prefix product.  A thread takes C = ceil(nblocks / 1024) consecutive blocks
+// (one up to 2^20 rows, two at 2^21, four at 2^22)
 template <class F>
 __global__ __launch_bounds__(1024) void k_zs_scan_totals(typename F::T* __restrict__ totals, u32 nblocks) {
     typedef typename F::T T;
     __shared__ T sh[1024];
     T* t = totals + (size_t)blockIdx.x * nblocks;
-    T mine = threadIdx.x < nblocks ? t[threadIdx.x] : F::one();
+    const u32 C = (nblocks + 1023) / 1024, b0 = threadIdx.x * C;
+    T mine = F::one();
+    for (u32 k = 0; k < C; k++)
+        if (b0 + k < nblocks) mine = F::mul(mine, t[b0 + k]);
     sh[threadIdx.x] = mine;
     __syncthreads();
     for (u32 off = 1; off < 1024; off <<= 1) {
@@ -148,7 +152,13 @@ __global__ __launch_bounds__(1024) void k_zs_scan_totals(typename F::T* __restri
         sh[threadIdx.x] = F::mul(v, o);
         __syncthreads();
     }
-    if (threadIdx.x < nblocks) t[threadIdx.x] = threadIdx.x ? sh[threadIdx.x - 1] : F::one();
+    T run = threadIdx.x ? sh[threadIdx.x - 1] : F::one();   // product of the blocks of earlier threads
+    for (u32 k = 0; k < C; k++)
+        if (b0 + k < nblocks) {
+            const T v = t[b0 + k];
+            t[b0 + k] = run;
+            run = F::mul(run, v);
+        }
 }
 
 // grid (ceil(n/256), c): Z(row) = carry * zloc; partial products p_m = Z * q_0..q_m (m < num_prods)
@@ -455,12 +465,17 @@ __global__ __launch_bounds__(256) void k_divide_local(const typename F::E* __res
         if (u0 + k < n) sloc[u0 + k] = run;  // local S_t (this block only)
     }
 }
-// single block, 1024 threads: totals[b] <- sum of totals of LATER blocks (exclusive suffix)
+// single block, 1024 threads: totals[b] <- sum of totals of LATER blocks (exclusive suffix); a thread takes C = ceil(nblocks / 1024)
+// consecutive blocks (one up to 2^20 coefficients)
 template <class F>
 __global__ __launch_bounds__(1024) void k_divide_totals(typename F::E* __restrict__ totals, u32 nblocks) {
     typedef typename F::E E;
     __shared__ E sh[1024];
-    sh[threadIdx.x] = threadIdx.x < nblocks ? totals[threadIdx.x] : F::ezero();
+    const u32 C = (nblocks + 1023) / 1024, b0 = threadIdx.x * C;
+    E mine = F::ezero();
+    for (u32 k = 0; k < C; k++)
+        if (b0 + k < nblocks) mine = F::eadd(mine, totals[b0 + k]);
+    sh[threadIdx.x] = mine;
     __syncthreads();
     for (u32 off = 1; off < 1024; off <<= 1) {
         E v = sh[threadIdx.x];
@@ -469,7 +484,13 @@ __global__ __launch_bounds__(1024) void k_divide_totals(typename F::E* __restric
         sh[threadIdx.x] = F::eadd(v, o);
         __syncthreads();
     }
-    if (threadIdx.x < nblocks) totals[threadIdx.x] = threadIdx.x + 1 < 1024 ? sh[threadIdx.x + 1] : F::ezero();
+    E run = threadIdx.x + 1 < 1024 ? sh[threadIdx.x + 1] : F::ezero();   // sum over the blocks of later threads
+    for (u32 k = C; k-- > 0;)
+        if (b0 + k < nblocks) {
+            const E v = totals[b0 + k];
+            totals[b0 + k] = run;
+            run = F::eadd(run, v);
+        }
 }
 // final[t] = final[t] * shift + q[t], q[t] = zinv^(t+1) * S_{t+1}, q[n-1] = 0   (fri/oracle.rs:218-223)
 template <class F>

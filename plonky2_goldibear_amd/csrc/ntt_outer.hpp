@@ -1,0 +1,139 @@
+// Transforms of more than 2^20 rows (round 5; the reference has no size cap below the field's two-adicity, field/src/fft.rs:168-205):
+// one outer radix-R step, R = 2^K = n / 2^20, around the 2^20-row passes.  With i = R i2 + i1 (decimation in time),
+//     X[k2 + m k1] = sum_i1 w_R^(i1 k1) * ( g(k2)^i1 * Y_i1[k2] ),     Y_i1 = the size-m = 2^20 transform of the stride-R subsequence i1,
+// g(k2) = w_n^(k2) (times the coset shift s_c for the LDE, whose sub-transforms run on the shift s_c^R).  So: de-interleave the R
+// subsequences (one pass), run the existing kernels on R times as many columns of 2^20 rows, and combine (one pass: twiddle, R-point
+// DFT).  Two extra passes over the data per transform: a size outside BASELINE.json's configs, built for coverage, not for speed.
+// Written once against the field traits (GlF: canonical words and plain tables; BbF: Montgomery words and tables).
+#pragma once
+#include <algorithm>
+
+#include "field_traits.hpp"
+
+namespace gbk {
+namespace outer {
+
+static constexpr int THREADS = 256;
+
+__device__ __forceinline__ u32 brev_bits(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// dst[col][i1][i2] = src[col][R i2 + i1]
+template <class F>
+__global__ __launch_bounds__(THREADS) void k_deinterleave(const typename F::T* __restrict__ src, typename F::T* __restrict__ dst, u32 log_m, u32 K) {
+    const size_t g = (size_t)blockIdx.x * THREADS + threadIdx.x;   // (col, i2)
+    const size_t col = g >> log_m, i2 = g & (((size_t)1 << log_m) - 1);
+    const u32 R = 1u << K;
+    const typename F::T* s = src + ((col << log_m) << K) + (i2 << K);
+    typename F::T* d = dst + ((col << log_m) << K) + i2;
+    for (u32 i1 = 0; i1 < R; i1++) d[(size_t)i1 << log_m] = s[i1];
+}
+
+// w^e from split tables (e = 1024 e_hi + e_lo), device form
+template <class F>
+__device__ __forceinline__ typename F::T tw_split(const typename F::T* __restrict__ hi, const typename F::T* __restrict__ lo, u32 e) {
+    const typename F::T w = lo[e & 1023];
+    return (e >> 10) ? F::mul(w, hi[e >> 10]) : w;
+}
+
+// R-point DFT (R = 2 or 4) of z[0..R) with the primitive 4th root `w4` (forward or inverse, as the caller passes it): X[k1] in x[k1]
+template <class F>
+__device__ __forceinline__ void dft_r(typename F::T (&z)[4], u32 K, typename F::T w4) {
+    typedef typename F::T T;
+    if (K == 1) {
+        const T a = z[0], b = z[1];
+        z[0] = F::add(a, b);
+        z[1] = F::sub(a, b);
+    } else {
+        const T s02 = F::add(z[0], z[2]), d02 = F::sub(z[0], z[2]), s13 = F::add(z[1], z[3]), d13 = F::mul(F::sub(z[1], z[3]), w4);
+        z[0] = F::add(s02, s13);
+        z[1] = F::add(d02, d13);
+        z[2] = F::sub(s02, s13);
+        z[3] = F::sub(d02, d13);
+    }
+}
+
+// in place: data[col][k1][k2] <- r_inv * sum_i1 w_R^-(i1 k1) w_n^-(i1 k2) data[col][i1][k2]
+template <class F>
+__global__ __launch_bounds__(THREADS) void k_intt_combine(typename F::T* __restrict__ data, u32 log_m, u32 K, const typename F::T* __restrict__ tw_hi_inv,
+                                                          const typename F::T* __restrict__ tw_lo_inv, typename F::T w4_inv, typename F::T r_inv) {
+    typedef typename F::T T;
+    const size_t g = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    const size_t col = g >> log_m;
+    const u32 k2 = (u32)(g & (((size_t)1 << log_m) - 1)), R = 1u << K;
+    T* p = data + ((col << log_m) << K) + k2;
+    const T w = tw_split<F>(tw_hi_inv, tw_lo_inv, k2);   // w_n^-k2
+    T z[4], f = r_inv;
+    for (u32 i1 = 0; i1 < R; i1++) {
+        z[i1] = F::mul(p[(size_t)i1 << log_m], f);
+        f = F::mul(f, w);
+    }
+    dft_r<F>(z, K, w4_inv);
+    for (u32 k1 = 0; k1 < R; k1++) p[(size_t)k1 << log_m] = z[k1];
+}
+
+// sub: [col][i1][c][q] (q = brev(k2): the sub-LDEs' leaf order) -> lde[col][c][q R + brev_K(k1)]
+template <class F>
+__global__ __launch_bounds__(THREADS) void k_lde_combine(const typename F::T* __restrict__ sub, typename F::T* __restrict__ lde, u32 log_m, u32 K, u32 rate_bits,
+                                                         const typename F::T* __restrict__ tw_hi, const typename F::T* __restrict__ tw_lo,
+                                                         const typename F::T* __restrict__ pow_lo, u32 nlo, typename F::T w4) {
+    typedef typename F::T T;
+    const size_t g = (size_t)blockIdx.x * THREADS + threadIdx.x;   // (col, c, q)
+    const u32 q = (u32)(g & (((size_t)1 << log_m) - 1)), R = 1u << K;
+    const size_t cc = g >> log_m;
+    const u32 c = (u32)(cc & ((1u << rate_bits) - 1));
+    const size_t col = cc >> rate_bits;
+    const u32 k2 = brev_bits(q, log_m);
+    const T gk = F::mul(pow_lo[(size_t)c * nlo + 1], tw_split<F>(tw_hi, tw_lo, k2));   // s_c w_n^k2
+    T z[4], f = F::one();
+    for (u32 i1 = 0; i1 < R; i1++) {
+        const T v = sub[(((((col << K) + i1) << rate_bits) + c) << log_m) + q];
+        z[i1] = i1 ? F::mul(v, f) : v;
+        f = F::mul(f, gk);
+    }
+    dft_r<F>(z, K, w4);
+    T* o = lde + ((((col << rate_bits) + c) << log_m) << K) + ((size_t)q << K);
+    for (u32 k1 = 0; k1 < R; k1++) o[brev_bits(k1, K)] = z[k1];
+}
+
+// ---- host side.  `Sub` = callables running the 2^20-row transforms: intt(src, dst, scratch, ncols) / lde(coeffs, out, ncols).
+// values [ncols][n] -> coefficients in `coeffs`; scratch holds ncols * n elements; src may equal coeffs.
+template <class F, class SubIntt>
+void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T* scratch, size_t ncols, u32 log_n, const typename F::T* tw_hi_inv,
+                  const typename F::T* tw_lo_inv, SubIntt sub_intt, hipStream_t st) {
+    typedef typename F::T T;
+    const u32 K = log_n - 20, log_m = 20;
+    const size_t n = (size_t)1 << log_n;
+    const u32 grid = (u32)((ncols << log_m) / THREADS);
+    if (src != coeffs) {
+        hipLaunchKernelGGL(k_deinterleave<F>, dim3(grid), dim3(THREADS), 0, st, src, coeffs, log_m, K);
+    } else {
+        hipLaunchKernelGGL(k_deinterleave<F>, dim3(grid), dim3(THREADS), 0, st, src, scratch, log_m, K);
+        (void)hipMemcpyAsync(coeffs, scratch, ncols * n * sizeof(T), hipMemcpyDeviceToDevice, st);
+    }
+    sub_intt(coeffs, coeffs, scratch, ncols << K);
+    const T w4_inv = F::inv(F::two_adic_generator(2)), r_inv = F::inv(F::enc((u64)1 << K));
+    hipLaunchKernelGGL(k_intt_combine<F>, dim3(grid), dim3(THREADS), 0, st, coeffs, log_m, K, tw_hi_inv, tw_lo_inv, w4_inv, r_inv);
+}
+
+// coefficients [ncols][n] -> lde [ncols][2^r][n] (leaf order); work holds work_elems elements (>= (1 + 2^r) n for one column)
+template <class F, class SubLde>
+void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, u32 log_n, u32 rate_bits, const typename F::T* tw_hi, const typename F::T* tw_lo,
+                 const typename F::T* pow_lo, typename F::T* work, size_t work_elems, SubLde sub_lde, hipStream_t st) {
+    typedef typename F::T T;
+    const u32 K = log_n - 20, log_m = 20;
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    const size_t group = std::max<size_t>(1, work_elems / (n + N));
+    const T w4 = F::two_adic_generator(2);
+    for (size_t c0 = 0; c0 < ncols; c0 += group) {
+        const size_t g = std::min(group, ncols - c0);
+        T* wc = work;            // [g R][m] de-interleaved coefficients
+        T* wl = work + g * n;    // [g R][2^r][m] their LDEs
+        hipLaunchKernelGGL(k_deinterleave<F>, dim3((u32)((g << log_m) / THREADS)), dim3(THREADS), 0, st, coeffs + c0 * n, wc, log_m, K);
+        sub_lde(wc, wl, g << K);
+        hipLaunchKernelGGL(k_lde_combine<F>, dim3((u32)(((g << rate_bits) << log_m) / THREADS)), dim3(THREADS), 0, st, wl, lde + c0 * N, log_m, K, rate_bits,
+                           tw_hi, tw_lo, pow_lo, (u32)4096, w4);
+    }
+}
+
+}  // namespace outer
+}  // namespace gbk

@@ -1,0 +1,115 @@
+"""More than 2^20 rows (round 5): the reference's transforms have no size cap below the field's two-adicity (field/src/fft.rs:168-205);
+the library runs 2^21 and 2^22 rows as one outer radix-2 / radix-4 step around its 2^20-row passes (csrc/ntt_outer.hpp).  -m gpu only.
+* PolynomialBatch::from_values at 2^21 rows: EVERY coefficient, EVERY leaf, EVERY digest and the cap against the CPU oracle's batch
+  (Goldilocks 5 columns = one sponge permutation per leaf; BabyBear 9 columns), host and device input; 2^22 rows: coefficients + cap.
+* prove() of the 2^21-row dummy circuit: accepted by gb_verify and by the independently written oracle verifier (oracle/verifier.py)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import oracle_bb as B
+from oracle import plonk_dummy as D
+from oracle.fields import GL
+from plonky2_goldibear_amd import GB_BABYBEAR, CircuitData, GpuContext, PolynomialBatch
+from plonky2_goldibear_amd import dummy_circuit as DC
+from plonky2_goldibear_amd import native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    O.use_host_cpu_share()
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("field_name,log_n,ncols", [("goldilocks", 21, 5), ("babybear", 21, 9), ("goldilocks", 22, 2), ("babybear", 22, 3)])
+def test_from_values_above_2pow20_rows(ctx, field_name, log_n, ncols):
+    import torch
+    seed = 0xB16 ^ (ncols << 8) ^ log_n
+    if field_name == "goldilocks":
+        vals, tag, idt = O.splitmix64_fill(seed, ncols << log_n).reshape(ncols, 1 << log_n), N.GB_GOLDILOCKS, np.int64
+        cpu = O.PolynomialBatch.from_values(vals, 3, 4)
+    else:
+        vals, tag, idt = B.fill(seed, ncols << log_n).reshape(ncols, 1 << log_n), GB_BABYBEAR, np.int32
+        cpu = B.PolynomialBatch.from_values(vals, 3, 4)
+    gpu = PolynomialBatch.from_values(ctx, vals, 3, 4, field=tag)
+    assert (gpu.merkle_tree.cap == cpu.cap).all()
+    assert (gpu.polynomials == cpu.polynomials).all()
+    if log_n == 21:
+        leaves = gpu.merkle_tree.leaves
+        bad = np.flatnonzero((leaves != cpu.leaves).any(axis=1))
+        assert bad.size == 0, "%d leaves differ, first %d" % (bad.size, bad[0])
+        del leaves
+        assert (gpu.merkle_tree.digests == cpu.digests).all()
+    for i in (0, 1, (1 << log_n) - 1, 1234567):
+        assert (gpu.get_lde_values(i, 8) == cpu.get_lde_values(i, 8)).all()
+    gpu.free()
+    dev = PolynomialBatch.from_values(ctx, torch.from_numpy(vals.view(idt)).cuda(), 3, 4, field=tag)
+    assert (dev.merkle_tree.cap == cpu.cap).all()
+    dev.free()
+    co = PolynomialBatch.from_coeffs(ctx, cpu.polynomials, 3, 4, field=tag)
+    assert (co.merkle_tree.cap == cpu.cap).all()
+    co.free()
+    ctx.trim()
+
+
+def test_prove_2pow21_rows_verifies(ctx):
+    """prove() of the 2^21-row Goldilocks dummy circuit (num_challenges 3): gb_verify and the oracle's verifier accept the proof, a
+    flipped byte in the opening set is rejected by both"""
+    lg, ch = 21, 3
+    cs, k_is, pi_row, _ = DC.build_dummy_circuit(lg)
+    gpu = CircuitData(ctx, lg, cs, k_is, num_challenges=ch)
+    del cs
+    w = DC.dummy_witness(lg, pi_row, seed=5)
+    proof = gpu.prove(w)
+    assert gpu.verify(proof)
+    view = D.DummyCircuit.verifier_view(lg, D.CircuitConfig(num_challenges=ch), GL, k_is)
+    view.set_cap(gpu.constants_sigmas_cap)
+    assert (view.circuit_digest == gpu.circuit_digest).all()
+    assert D.verify(view, proof)
+    bad = bytearray(proof)
+    bad[3 * 16 * 32 + 100] ^= 1
+    with pytest.raises(N.VerifyError):
+        gpu.verify(bytes(bad))
+    with pytest.raises(AssertionError):
+        D.verify(view, bytes(bad))
+    gpu.free()
+    ctx.trim()
+
+
+def test_zs_running_product_above_1024_blocks(ctx):
+    """wires_permutation_partial_products_and_zs at 2^21 rows (plonk/prover.rs:480-546): the running product is a scan over 2048
+    blocks of 1024 rows - more than one thread per block total.  The dummy circuit's sigma is the identity almost everywhere (every
+    quotient 1: a broken carry between blocks would go unnoticed), so the sigma columns are rotated by one and the witness is random:
+    Z(0) = 1 and Z(row + 1) prod_j den_j(row) == Z(row) prod_j num_j(row) on every block boundary and on random rows."""
+    lg, ch, nr = 21, 3, 80
+    n, P = 1 << lg, GL.P
+    cs, k_is, pi_row, _ = DC.build_dummy_circuit(lg)
+    cs[3:3 + nr] = np.roll(cs[3:3 + nr], 1, axis=0)      # sigma_j <- sigma_(j-1): any field values will do for the formula
+    gpu = CircuitData(ctx, lg, cs, k_is, num_challenges=ch)
+    rng = np.random.default_rng(21)
+    w = np.zeros((135, n), dtype=np.uint64)
+    w[:nr] = rng.integers(0, P, (nr, n), dtype=np.uint64)
+    betas = [int(x) for x in rng.integers(1, P, ch, dtype=np.uint64)]
+    gammas = [int(x) for x in rng.integers(1, P, ch, dtype=np.uint64)]
+    out = gpu.zs_partial_products(w, betas, gammas)
+    assert out.shape == (ch * 10, n)
+    sub = DC.gl_powers(pow(1753635133440165772, 1 << (32 - lg), P), n)
+    rows = sorted(set([0, 1, n - 2] + [1024 * b - 1 for b in range(1, 2048)] + [int(r) for r in rng.integers(0, n - 1, 512)]))
+    ks = [int(k) for k in k_is]
+    for c in range(ch):
+        Z = out[c]
+        assert int(Z[0]) == 1
+        for r in rows:
+            x = int(sub[r])
+            num = den = 1
+            for j in range(nr):
+                wv = int(w[j, r])
+                num = num * ((wv + betas[c] * ks[j] % P * x + gammas[c]) % P) % P
+                den = den * ((wv + betas[c] * int(cs[3 + j, r]) + gammas[c]) % P) % P
+            assert int(Z[r + 1]) * den % P == int(Z[r]) * num % P, (c, r)
+    gpu.free()
+    ctx.trim()
