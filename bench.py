@@ -182,7 +182,10 @@ class ProveLeg:
         self.nwires, self.nrouted, self.arity_bits, self.ext_d, self.esz = (167, 41, 3, 4, 4) if bb else (135, 80, 4, 2, 8)
         self.idt = np.int32 if bb else np.int64
         self.dev = "cuda:%d" % local_rank
+        t_build = time.perf_counter()
         cs, k_is, pi_row, _ = dummy_circuit_inputs(bb, log_n)
+        self.build_s = time.perf_counter() - t_build        # the dummy circuit's constants / sigma columns (numpy, this rank's cores)
+        t_build = time.perf_counter()
         cs_dev = torch.from_numpy(cs.view(self.idt)).to(self.dev)
         self.lanes = []  # one (context, circuit, host witness) per proof in flight: independent circuits, as across GPUs
         self.extra_ctx = []
@@ -214,6 +217,7 @@ class ProveLeg:
         self.proof, self.proof_len, self.retries = None, 0, 0
         del cs, cs_dev
         torch.cuda.synchronize()
+        self.circuit_create_s = time.perf_counter() - t_build   # gb_circuit_create: the constants/sigmas commitment (build()'s GPU share)
 
     def to_p3_words(self, a):
         """canonical values -> the words the reference's field types hold in memory (GB_INPUT_P3_REPR): p3-baby-bear's Montgomery
@@ -462,6 +466,23 @@ class ProveLeg:
         self.torch.cuda.empty_cache()
 
 
+def host_footprint(leg):
+    """this rank's host-side footprint for the multi-rank rehearsals: resident set (now / peak), page-locked bytes it asked for
+    (the witness block of the "pinned" legs, the library's staging ring of the "vecs" legs), circuit build times"""
+    rss = peak = None
+    try:
+        for line in open("/proc/self/status"):
+            if line.startswith("VmRSS:"):
+                rss = int(line.split()[1]) / 1024.0
+            elif line.startswith("VmHWM:"):
+                peak = int(line.split()[1]) / 1024.0
+    except OSError:
+        pass
+    wit = leg.nwires * (1 << leg.log_n) * leg.esz * leg.inflight
+    return {"rss_mb": rss, "rss_peak_mb": peak, "pinned_witness_mb": wit / 2.0 ** 20, "library_staging_ring_mb": 256.0,
+            "circuit_columns_build_s": leg.build_s, "circuit_create_s": leg.circuit_create_s}
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -581,9 +602,14 @@ def init_control_plane(world, rank, local_rank, default_backend, stub=False):
         return int(flag.item()) == 1, whys
 
     def fall_back(whys, extra=None):
-        reason = "; ".join("rank %d: %s" % (r, w) for r, w in enumerate(whys) if w) or "another rank could not bring RCCL up"
-        print("bench.py: RCCL control plane unavailable (%s) - barrier and max-over-ranks go over gloo; the proofs use no collective"
-              % reason, file=sys.stderr)
+        given = [w for w in whys if w]
+        if given and len(given) == len(whys) and len(set(given)) == 1:
+            reason = "all %d ranks: %s" % (len(whys), given[0])
+        else:
+            reason = "; ".join("rank %d: %s" % (r, w) for r, w in enumerate(whys) if w) or "another rank could not bring RCCL up"
+        if rank == 0:
+            print("bench.py: RCCL control plane unavailable (%s) - barrier and max-over-ranks go over gloo; the proofs use no collective"
+                  % reason, file=sys.stderr)
         cp = {"backend": "gloo", "requested": "nccl", "fallback_reason": reason}
         cp.update(extra or {})
         return cp
@@ -788,6 +814,13 @@ def main():
             out["witnesses"] = "%d pinned seeds, cycled: every step proves a different witness" % N_WITNESSES
             out["affinity"] = affinity
             out["control_plane"] = control_plane
+        if world > 1:   # every rank's host footprint goes into the line (the default group is gloo: host objects)
+            foot = [None] * world
+            dist.all_gather_object(foot, host_footprint(leg))
+            if rank == 0:
+                out["ranks_host"] = foot
+        elif rank == 0:
+            out["ranks_host"] = [host_footprint(leg)]
         if not args.no_resident:
             dt2, scopes2, _ = leg.timed(steps, args.warmup, "hbm")
             if rank == 0:
