@@ -68,6 +68,26 @@ int main(int argc, char** argv) {
     proof[100] ^= 1;  // a cap word of the wires commitment
     if (gb_verify(circuit, proof.data(), len) != GB_ERR_VERIFY) { std::fprintf(stderr, "tampered proof was not rejected\n"); return 1; }
     proof[100] ^= 1;
+    {   // MatrixWitness.wire_values as the reference holds it (iop/witness.rs:277-279): one separately allocated column per wire,
+        // handed over as a pointer table - gb_prove_cols; the same bytes.  Then the same columns in page-locked memory of the library.
+        std::vector<std::vector<u64>> cols(wires);
+        std::vector<const void*> ptrs(wires);
+        for (unsigned c = 0; c < wires; c++) { cols[c].assign(wit.begin() + (size_t)c * n, wit.begin() + (size_t)(c + 1) * n); ptrs[c] = cols[c].data(); }
+        std::vector<uint8_t> p2(4 << 20);
+        size_t len2 = 0;
+        CHECK(gb_prove_cols(circuit, ptrs.data(), GB_INPUT_HOST, nullptr, 0, p2.data(), p2.size(), &len2));
+        if (len2 != len || std::memcmp(p2.data(), proof.data(), len) != 0) { std::fprintf(stderr, "gb_prove_cols differs from gb_prove\n"); return 1; }
+        void* pinned = nullptr;
+        CHECK(gb_host_alloc(ctx, (size_t)wires * n * sizeof(u64), &pinned));
+        std::memcpy(pinned, wit.data(), (size_t)wires * n * sizeof(u64));
+        for (unsigned c = 0; c < wires; c++) ptrs[c] = static_cast<u64*>(pinned) + (size_t)c * n;
+        CHECK(gb_prove_cols(circuit, ptrs.data(), GB_INPUT_HOST, nullptr, 0, p2.data(), p2.size(), &len2));
+        if (len2 != len || std::memcmp(p2.data(), proof.data(), len) != 0) { std::fprintf(stderr, "gb_prove_cols (page-locked) differs\n"); return 1; }
+        CHECK(gb_host_free(ctx, pinned));
+        CHECK(gb_ctx_set_option(ctx, "copy_threads", 2));
+        if (gb_ctx_set_option(ctx, "no_such_option", 1) != GB_ERR_INVALID) { std::fprintf(stderr, "unknown option accepted\n"); return 1; }
+        if (gb_prove(circuit, wit.data(), 0x200, nullptr, 0, p2.data(), p2.size(), &len2) != GB_ERR_INVALID) { std::fprintf(stderr, "unknown flag bit accepted\n"); return 1; }
+    }
 
     // the verifier's side without the prover's circuit object: CommonCircuitData (config + gate table) and VerifierOnlyCircuitData
     // (cap, digest) only - no device involved (ctx = NULL) - and the compressed form of the proof

@@ -1,14 +1,17 @@
 #!/bin/bash
 # Regenerates profiles/${R}_* on an MI355X box (the command sequence that produced the committed files):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/make_profiles.sh'      then, locally:  bash tools/make_profiles.sh --collect
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/make_profiles.sh counters'   then, locally:  bash tools/make_profiles.sh --collect
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/make_profiles.sh bench'      then, locally:  bash tools/make_profiles.sh --collect
+# (two calls: a box lives for one call of at most 20 minutes; the second call ships the summaries the first one brought back)
 # rocprofv3 writes rocpd SQLite databases on this image; tools/rocpd_kernel_stats.py, tools/pmc_traffic.py,
 # tools/pmc_sq_summary.py and tools/pmc_poseidon.py turn them into the CSV / JSON summaries.  PMC passes are separate runs
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass) and never combined with tracing.
-# Order on the box (round 4): the PMC passes first, their summaries written into profiles/ of the box's copy of the tree, THEN the
-# bench runs whose JSON lines quote those summaries - so that no committed bench line says "stale": true about a sibling of the
-# same run.  Everything that has to come back is also written under gpurun_out/profiles/ (only gpurun_out/ travels back).
+# Order on the box: the PMC passes, the s_memtime attribution of the leaf-hash kernel and the per-field kernel traces first, their
+# summaries (incl. rNN_roofline_recompute.json) written into profiles/ of the box's copy of the tree, THEN the default bench line
+# that quotes them - so that no committed bench line says "stale": true about a sibling of the same run.  Everything that has to
+# come back is also written under gpurun_out/profiles/ (only gpurun_out/ travels back).
 set -e
-R=${GB_PROFILE_ROUND:-r04}
+R=${GB_PROFILE_ROUND:-r05}
 OUT=gpurun_out
 P=$OUT/profiles
 if [ "$1" = "--collect" ]; then
@@ -16,8 +19,11 @@ if [ "$1" = "--collect" ]; then
     ls -la profiles | grep " ${R}_"
     exit 0
 fi
+STAGE=${1:-all}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p $P
+python3 tools/csrc_hash.py > $OUT/profile_csrc_sha16.txt   # the sources these figures are measured on
+if [ "$STAGE" != bench ]; then
 SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"
 for F in goldilocks babybear; do
     COLS=$([ $F = babybear ] && echo 167 || echo 135)
@@ -39,14 +45,23 @@ for F in goldilocks babybear; do
     python3 tools/pmc_sq_summary.py $OUT/pmc_${F}_sq/s_results.db $P/${R}_commit_${F}_2p20_sq_counters.csv
     python3 tools/pmc_poseidon.py $P/${R}_commit_${F}_2p20_sq_counters.csv $F $COLS 20 $P/${R}_poseidon_valu_$F.json > /dev/null
 done
-cp $P/${R}_* profiles/          # the box's own tree: what the bench lines below quote
-# the driver's own command: kernel trace + stats of the default bench line (both fields, host and HBM-resident witness)
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 > $OUT/prof_bench.log 2>&1
-python3 tools/rocpd_kernel_stats.py $OUT/prof_bench/p_results.db $P/${R}_bench_default_kernel_stats.csv
-grep '"metric"' $OUT/prof_bench.log > $P/${R}_bench_default.json
+# where the wave cycles of the leaf-hash kernel go (attribution build tools/bin/libs/probe.so, built in the build container) and the
+# shader clock the chip holds under that load
+if [ -f tools/bin/libs/probe.so ]; then
+    GB_PROBE_JSON=$P/${R}_leaf_kernel_probe.json timeout -k 10 300 python3 tools/probe_leaves.py > $P/${R}_leaf_kernel_probe_attribution.txt 2> $OUT/probe_leaves.err || true
+fi
+# one field per run, host-witness leg only, under the kernel trace: 7 proofs each (5 timed + 2 warm-up), no verification proofs
 for F in goldilocks babybear; do
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$F -o p -- python3 bench.py --field $F --steps 5 --warmup 2 --no-babybear --no-resident --no-inflight2 --no-cpu-baseline > $OUT/prof_$F.log 2>&1
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$F -o p -- python3 bench.py --field $F --steps 5 --warmup 2 --no-babybear --no-resident --no-inflight2 --no-vecs --no-cpu-baseline --no-checks > $OUT/prof_$F.log 2>&1
     python3 tools/rocpd_kernel_stats.py $OUT/prof_$F/p_results.db $P/${R}_prove_${F}_2p20_kernel_stats.csv
     grep '"metric"' $OUT/prof_$F.log > $P/${R}_bench_prove_${F}_2p20.json
 done
+python3 tools/roofline_recompute.py $P $R 7 > /dev/null
+cp $P/${R}_* profiles/          # the box's own tree: what the bench line below quotes
+fi
+[ "$STAGE" = counters ] && { ls -la $P; exit 0; }
+# the driver's own command under the kernel trace, then once more bare (the line the driver will reproduce)
+timeout -k 10 700 rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 > $OUT/prof_bench.log 2>&1
+python3 tools/rocpd_kernel_stats.py $OUT/prof_bench/p_results.db $P/${R}_bench_default_kernel_stats.csv
+timeout -k 10 700 python3 bench.py --steps 20 --warmup 5 > $P/${R}_bench_default.json 2> $OUT/bench_default.err
 ls -la $P
