@@ -151,8 +151,13 @@ def run():
     stat = static_segments()
     print("k_gl_merkle_leaves (attribution build, -DGB_PROBE), wires commitment 135 x 2^20 Goldilocks: 'hash leaves' %.2f ms with probes" % ms)
     print("%d traced waves, %.0f wave cycles (s_memtime) from first to last probe on average, %d permutations per wave" % (nw, np.mean(life), perms))
-    clock_hz = (max(last_ts) - min(first_ts)) / (ms * 1e-3)   # traced waves are spread over the whole grid: first to last stamp = the kernel
-    print("shader clock under this load: %.3f GHz (first to last time stamp of the traced waves / the kernel's 'hash leaves' scope)" % (clock_hz / 1e9))
+    # Shader clock under this load.  s_memtime counters of different XCDs are not synchronised, so stamps of different waves are not
+    # compared; instead: the grid's n_waves run in 4096 wave slots (256 CUs x 16 waves: 128 VGPRs, 4 waves per SIMD), back to back, so a
+    # slot is busy for (n_waves / 4096) wave lifetimes during the kernel.  First-to-last probe leaves out a wave's prologue and epilogue
+    # (the operand table, the store: ~1 %), so this reads slightly low.
+    clock_hz = (n_waves / 4096.0) * float(np.mean(life)) / (ms * 1e-3)
+    print("shader clock under this load: ~%.2f GHz (%d waves per slot x the mean wave lifetime / the kernel's 'hash leaves' scope; the guide's nominal "
+          "clock is 2.4 GHz)" % (clock_hz / 1e9, n_waves // 4096))
     print()
     print("%-58s %6s %9s %7s | %5s %5s %5s %4s %5s %5s %4s %8s %6s" % ("segment (site a -> site b)", "n/perm", "cyc/occ", "share", "mad", "pl32", "other",
                                                                         "mfma", "nopws", "salu", "lds", "model", "cyc/m"))
