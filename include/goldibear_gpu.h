@@ -187,6 +187,10 @@ typedef struct gb_circuit_config {
  * (selector, constants, sigma columns - circuit_builder.rs:1198-1229); k_is: [num_routed_wires]. */
 gb_status gb_circuit_create(gb_ctx* ctx, const gb_circuit_config* cfg, const void* constants_sigmas, const void* k_is,
                             uint32_t flags, gb_circuit** out);
+/* the same with constants_sigmas as build() holds it (circuit_builder.rs:1198-1229: a Vec<PolynomialValues<F>>, one allocation per
+ * column): constants_sigmas_cols[i] points to the 2^degree_bits canonical values of column i */
+gb_status gb_circuit_create_cols(gb_ctx* ctx, const gb_circuit_config* cfg, const void* const* constants_sigmas_cols, const void* k_is,
+                                 uint32_t flags, gb_circuit** out);
 gb_status gb_circuit_free(gb_circuit* c);
 /* The same for a general gate set: `gates` is CommonCircuitData.gates - sorted by (degree, id) as
  * circuit_builder.rs:1194-1196 leaves them - with selectors_info flattened into each entry (gates/selectors.rs:16-26:
@@ -229,6 +233,8 @@ typedef struct gb_gate {
 } gb_gate;
 gb_status gb_circuit_create_gates(gb_ctx* ctx, const gb_circuit_config* cfg, const gb_gate* gates, uint32_t num_gates,
                                   const void* constants_sigmas, const void* k_is, uint32_t flags, gb_circuit** out);
+gb_status gb_circuit_create_gates_cols(gb_ctx* ctx, const gb_circuit_config* cfg, const gb_gate* gates, uint32_t num_gates,
+                                       const void* const* constants_sigmas_cols, const void* k_is, uint32_t flags, gb_circuit** out);
 /* ProverOnlyCircuitData.constants_sigmas_commitment (plonk/circuit_data.rs:532-534), the PolynomialBatch built by
  * gb_circuit_create*: a BORROWED handle - owned by the circuit, valid until gb_circuit_free, never passed to gb_batch_free.  The
  * reference's prover reads it for the opening set (plonk/proof.rs:359-377) and the query rounds. */

@@ -130,6 +130,11 @@ extern "C" {
     fn gb_batch_eval_ext(b: *mut gb_batch, z: *const c_void, out: *mut c_void) -> i32;
     fn gb_circuit_create(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, constants_sigmas: *const c_void, k_is: *const c_void,
                          flags: u32, out: *mut *mut gb_circuit) -> i32;
+    fn gb_circuit_create_cols(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, constants_sigmas_cols: *const *const c_void,
+                              k_is: *const c_void, flags: u32, out: *mut *mut gb_circuit) -> i32;
+    fn gb_circuit_create_gates_cols(ctx: *mut gb_ctx, cfg: *const gb_circuit_config, gates: *const gb_gate, num_gates: u32,
+                                    constants_sigmas_cols: *const *const c_void, k_is: *const c_void, flags: u32,
+                                    out: *mut *mut gb_circuit) -> i32;
     fn gb_circuit_free(c: *mut gb_circuit) -> i32;
     fn gb_circuit_verifier_data(c: *mut gb_circuit, cap_out: *mut c_void, digest_out: *mut c_void) -> i32;
     fn gb_circuit_set_fri_reduction_arity_bits(c: *mut gb_circuit, arity_bits: *const u32, num_layers: u32) -> i32;
@@ -429,6 +434,21 @@ impl<'c, W: Copy + Default> GpuCircuit<'c, W> {
         check(ctx.0, unsafe {
             gb_circuit_create_gates(ctx.0, &config, gates.as_ptr(), gates.len() as u32, constants_sigmas.as_ptr() as *const c_void,
                                     k_is.as_ptr() as *const c_void, GB_INPUT_HOST, &mut h)
+        })?;
+        Ok(Self { ctx, handle: h, config, _w: std::marker::PhantomData })
+    }
+    /// `with_gates` over `constants_sigmas_vecs` as `build()` holds them (circuit_builder.rs:1198-1229): one column per `Vec`, canonical
+    /// words, handed over as a pointer table (`gb_circuit_create_gates_cols`)
+    pub fn with_gates_columns<C: AsRef<[W]>>(ctx: &'c GpuContext, mut config: gb_circuit_config, gates: &[gb_gate], constants_sigmas: &[C],
+                                             k_is: &[W]) -> Result<Self, GpuError> {
+        config.field = field_tag::<W>();
+        need("constants_sigmas", constants_sigmas.len(), (config.num_selectors + config.num_constants + config.num_routed_wires) as usize)?;
+        need("k_is", k_is.len(), config.num_routed_wires as usize)?;
+        let table = column_table("constants_sigmas", constants_sigmas, 1usize << config.degree_bits)?;
+        let mut h = ptr::null_mut();
+        check(ctx.0, unsafe {
+            gb_circuit_create_gates_cols(ctx.0, &config, gates.as_ptr(), gates.len() as u32, table.as_ptr(), k_is.as_ptr() as *const c_void,
+                                         GB_INPUT_HOST, &mut h)
         })?;
         Ok(Self { ctx, handle: h, config, _w: std::marker::PhantomData })
     }

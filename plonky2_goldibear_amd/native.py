@@ -58,6 +58,8 @@ SIGNATURES = {
     "gb_permute": (_i32, [_vp, _u32, _vp, _vp, _u64]),
     "gb_circuit_create": (_i32, [_vp, _vp, _vp, _vp, _u32, _pvp]),
     "gb_circuit_create_gates": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _pvp]),
+    "gb_circuit_create_cols": (_i32, [_vp, _vp, _cols, _vp, _u32, _pvp]),
+    "gb_circuit_create_gates_cols": (_i32, [_vp, _vp, _vp, _u32, _cols, _vp, _u32, _pvp]),
     "gb_circuit_free": (_i32, [_vp]),
     "gb_circuit_verifier_data": (_i32, [_vp, _vp, _vp]),
     "gb_circuit_constants_sigmas_commitment": (_i32, [_vp, _pvp]),

@@ -100,7 +100,8 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
                                      max_quotient_degree_factor, rate_bits, cap_height, proof_of_work_bits,
                                      num_query_rounds, arity_bits, final_poly_bits, num_selectors, gate_constant, gate_pi,
                                      1 if zero_knowledge else 0, num_public_inputs)
-        ptr, shape, flags, keep = _as_input(constants_sigmas, field)
+        cs_cols = is_column_list(constants_sigmas)   # constants_sigmas_vecs as build() holds them: one allocation per column
+        ptr, shape, flags, keep = _as_columns(constants_sigmas, field) if cs_cols else _as_input(constants_sigmas, field)
         want = (num_selectors + num_constants + num_routed_wires, 1 << degree_bits)
         if tuple(shape) != want:
             raise N.ShapeError(N.GB_ERR_INVALID, "constants_sigmas must be %r, got %r" % (want, tuple(shape)))
@@ -115,11 +116,12 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
             kptr, keep2 = k.ctypes.data, k
         h = C.c_void_p()
         if gates is None:
-            N.check(self._lib.gb_circuit_create(ctx.handle, C.byref(self.cfg), ptr, kptr, flags, C.byref(h)), ctx.handle)
+            fn = self._lib.gb_circuit_create_cols if cs_cols else self._lib.gb_circuit_create
+            N.check(fn(ctx.handle, C.byref(self.cfg), ptr, kptr, flags, C.byref(h)), ctx.handle)
         else:
             arr = (gb_gate * len(gates))(*[gb_gate(*g) for g in gates])
-            N.check(self._lib.gb_circuit_create_gates(ctx.handle, C.byref(self.cfg), arr, len(gates), ptr, kptr, flags, C.byref(h)),
-                    ctx.handle)
+            fn = self._lib.gb_circuit_create_gates_cols if cs_cols else self._lib.gb_circuit_create_gates
+            N.check(fn(ctx.handle, C.byref(self.cfg), arr, len(gates), ptr, kptr, flags, C.byref(h)), ctx.handle)
         del keep, keep2
         self.handle = h
         cap = np.empty((1 << cap_height, hout), dtype=self._dt)

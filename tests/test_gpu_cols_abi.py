@@ -41,9 +41,9 @@ def to_p3_words(a, field):
     return out
 
 
-def _gpu_circuit(ctx, circ, tag):
+def _gpu_circuit(ctx, circ, tag, cs=None):
     cfg = circ.cfg
-    return CircuitData(ctx, circ.degree_bits, circ.constants_sigmas, circ.k_is, num_wires=cfg.num_wires,
+    return CircuitData(ctx, circ.degree_bits, circ.constants_sigmas if cs is None else cs, circ.k_is, num_wires=cfg.num_wires,
                        num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
                        num_challenges=cfg.num_challenges, arity_bits=cfg.arity_bits, gate_constant=circ.GATE_CONSTANT,
                        gate_pi=circ.GATE_PI, field=tag)
@@ -183,6 +183,11 @@ def test_prove_cols_bytes_match_oracle(ctx, field_name, degree_bits, num_challen
             continue
     assert (gpu.zs_partial_products(columns_of(w), betas, gammas) == flat).all()
     assert (gpu.zs_partial_products(columns_of(to_p3_words(w, tag)), betas, gammas, p3_repr=True) == flat).all()
+    # build(): constants_sigmas_vecs as separately allocated columns (gb_circuit_create_cols) - the same circuit
+    gpu2 = _gpu_circuit(ctx, circ, tag, cs=columns_of(circ.constants_sigmas))
+    assert (gpu2.constants_sigmas_cap == gpu.constants_sigmas_cap).all() and (gpu2.circuit_digest == gpu.circuit_digest).all()
+    assert gpu2.prove_once(columns_of(w)) == want
+    gpu2.free()
     gpu.free()
     ctx.trim()
 
