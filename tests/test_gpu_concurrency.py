@@ -89,3 +89,29 @@ def test_concurrent_commits_match_oracle():
             assert (cap == want[i].cap).all() and (pol == want[i].polynomials).all() and (sib == want[i].prove(r * 37)).all()
     for c in ctxs:
         c.close()
+
+
+def test_two_contexts_stage_pageable_columns_concurrently():
+    """each context has its own page-locked ring and copy threads (round 5): two host threads commit wide batches from separately
+    allocated pageable columns on two contexts at once, repeatedly (the rings' slots come round) - every tree equals the one made alone"""
+    ctxs = [GpuContext(0), GpuContext(0)]
+    ctxs[1].set_option("copy_threads", 2)
+    log_n = 16
+    mats = [O.splitmix64_fill(0xC0 + i, 72 << log_n).reshape(72, 1 << log_n) for i in range(2)]
+    want = [O.PolynomialBatch.from_values(m, 3, 4).cap for m in mats]
+    cols = [[np.array(c, copy=True) for c in m] for m in mats]
+    got = [[None] * 5, [None] * 5]
+
+    def worker(i):
+        def f():
+            for r in range(5):
+                b = PolynomialBatch.from_values(ctxs[i], cols[i], 3, 4)
+                got[i][r] = b.merkle_tree.cap
+                b.free()
+        return f
+    _run_threads([worker(0), worker(1)])
+    for i in range(2):
+        for r in range(5):
+            assert (got[i][r] == want[i]).all(), (i, r)
+    for c in ctxs:
+        c.close()
