@@ -41,3 +41,39 @@ def test_a_source_change_makes_the_quote_stale(tmp_path, monkeypatch):
     monkeypatch.setattr(csrc_hash, "csrc_sha16", lambda: "0" * 16)
     assert b._latest_profile("r*_poseidon_valu_goldilocks.json")["stale"] is True
     assert j["stale"] in (True, False)
+
+
+def test_roofline_is_reproducible_from_the_committed_summaries():
+    """profiles/rNN_roofline_recompute.json holds, per field, exactly what tools/roofline_recompute.py derives from
+    the committed kernel-stats / traffic / counter summaries of the same round - frac_from_profile to the digit - and the newest
+    committed bench line quotes those figures."""
+    import csv
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_recompute.json")))
+    assert paths, "no roofline recompute summary committed"
+    path = paths[-1]
+    rnd = os.path.basename(path).split("_")[0]
+    j = json.load(open(path))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import roofline_recompute as R
+    for field in ("goldilocks", "babybear"):
+        f = j[field]
+        alg, ncv, ncc = R.algorithmic_bytes(field)
+        assert f["algorithmic_bytes_per_proof"] == alg
+        ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_prove_%s_2p20_kernel_stats.csv" % (rnd, field))))
+                 if "intt" in r["Name"] or "lde_p" in r["Name"]) / 7
+        assert abs(f["ntt_kernel_ms_per_proof"] - ns / 1e6) < 1e-9
+        assert abs(f["frac_from_profile"] - alg / (ns * 1e-9) / 8.0e12) < 1e-12
+        t = json.load(open(os.path.join(ROOT, "profiles", "%s_ntt_traffic_pmc_%s.json" % (rnd, field))))
+        phys = t["ifft_bytes_per_column"] * ncv + t["lde_bytes_per_column"] * (ncv + ncc)
+        assert abs(f["physical_bytes_per_proof"] - phys) < 1.0
+        assert 0.10 < f["frac_from_profile"] < f["valu_ceiling_frac"] < 0.40 and 0.15 < f["pass_structure_ceiling_frac"] < 0.30
+    line_path = os.path.join(ROOT, "profiles", "%s_bench_default.json" % rnd)
+    if os.path.exists(line_path):
+        line = json.loads(open(line_path).read().strip().splitlines()[-1])
+        for field, obj in (("goldilocks", line["roofline"]), ("babybear", line["babybear"]["roofline"])):
+            assert obj["frac_from_profile"] == j[field]["frac_from_profile"] and obj["valu_ceiling_frac"] == j[field]["valu_ceiling_frac"]
+            assert obj["profile_source"]["stale"] is False
+        assert line["proof_sha256_matches_golden"] is True and line["babybear"]["proof_sha256_matches_golden"] is True
+        assert line["verified_witnesses"] == "16 of 16" and "value_vec_of_vecs" in line and "value_vec_of_vecs" in line["babybear"]
+        assert line["cpu_baseline"]["scaled"] is False and line["cpu_baseline"]["sample_log_n"] == 20
