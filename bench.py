@@ -627,12 +627,14 @@ def init_control_plane(world, rank, local_rank, default_backend, stub=False):
         try:
             if os.environ.get("GB_BENCH_RCCL_FAIL_RANK") == str(rank):       # test hook: this rank's RCCL raises, its peers wait
                 raise RuntimeError("RCCL bring-up failed on this rank (GB_BENCH_RCCL_FAIL_RANK)")
+            if not fake:
+                torch.cuda.set_device(local_rank)     # the current device is per thread: this helper starts on device 0
             res["group"] = group = dist.new_group(backend="gloo" if fake else "nccl", timeout=datetime.timedelta(seconds=timeout))
             t = torch.ones(1) if fake else torch.ones(1, device=torch.device("cuda", local_rank))
             work = dist.all_reduce(t, group=group, async_op=True)
             work.wait()
             if not fake:
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(local_rank)
             if int(t.item()) != world:
                 raise RuntimeError("all_reduce over RCCL returned %r, expected %d" % (t.item(), world))
             res["ok"] = True
