@@ -673,7 +673,7 @@ _HARD_EXIT = False
 def finish(world, dist):
     """end of a rank: leave the process groups; after an RCCL bring-up that is still blocked in a helper thread there is nothing to
     tear down cleanly - flush and leave"""
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.barrier()
         if _HARD_EXIT:
             sys.stdout.flush()
@@ -776,7 +776,10 @@ def main():
         torch.cuda.set_device(device_index)
     local_rank = device_index
     control_plane = None
-    if world > 1:
+    # GB_BENCH_FORCE_CONTROL_PLANE=1 (rehearsal): bring the control plane up even for one rank under the launcher - a one-rank RCCL
+    # group is the only way to execute the "RCCL came up" branch (new_group, probe all-reduce, barrier and max over it) on a box
+    # with a single GPU, where ranks would otherwise have to share a device
+    if world > 1 or (os.environ.get("GB_BENCH_FORCE_CONTROL_PLANE") and "MASTER_PORT" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         control_plane = init_control_plane(world, rank, local_rank, "gloo" if stub else "nccl", stub)
         gathered = [None] * world

@@ -35,3 +35,11 @@ j = json.loads([l for l in open("$OUT/n1_$mode.json") if l.startswith("{")][-1])
 print("N = 1 %-8s value %.3f proofs/s  ms_per_step %.2f  vec_of_vecs %.3f" % ("$mode", j["value"], j["ms_per_step"], j.get("value_vec_of_vecs", 0)))
 PY
 done
+# the branch in which RCCL DID come up, on real hardware: one rank under the launcher with the control plane forced on
+GB_BENCH_FORCE_CONTROL_PLANE=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 6 --warmup 2 $ARGS > $OUT/n1_rccl.json 2> $OUT/n1_rccl.err
+echo "forced control plane, one rank: exit code $?" | tee -a $OUT/summary.txt
+python3 - <<PY | tee -a $OUT/summary.txt
+import json
+j = json.loads([l for l in open("$OUT/n1_rccl.json") if l.startswith("{")][-1])
+print("N = 1 with an RCCL control plane: value %.3f proofs/s  control_plane %s" % (j["value"], json.dumps(j["control_plane"])))
+PY
