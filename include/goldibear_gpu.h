@@ -43,7 +43,7 @@ enum {
     GB_ERR_INVALID = 1,     /* shape / argument violation (reference: assert!/panic!) */
     GB_ERR_HIP = 2,         /* a HIP runtime call failed */
     GB_ERR_OOM = 3,         /* device allocation failed */
-    GB_ERR_UNSUPPORTED = 4  /* valid in the reference, not implemented here (e.g. log_n > 20) */
+    GB_ERR_UNSUPPORTED = 4  /* valid in the reference, not implemented here (e.g. log_n > 24, the lookup gates) */
 };
 
 enum { GB_GOLDILOCKS = 0, GB_BABYBEAR = 1 }; /* field tag: F = Goldilocks (Poseidon-12) | BabyBear (Poseidon2-16) */
@@ -184,7 +184,8 @@ typedef struct gb_circuit_config {
 } gb_circuit_config;
 
 /* constants_sigmas: [num_selectors + num_constants + num_routed_wires][2^degree_bits] VALUES on H_n
- * (selector, constants, sigma columns - circuit_builder.rs:1198-1229); k_is: [num_routed_wires]. */
+ * (selector, constants, sigma columns - circuit_builder.rs:1198-1229); k_is: [num_routed_wires].  Canonical words, or with
+ * GB_INPUT_P3_REPR (host input) the field types' in-memory words - constants_sigmas and k_is alike. */
 gb_status gb_circuit_create(gb_ctx* ctx, const gb_circuit_config* cfg, const void* constants_sigmas, const void* k_is,
                             uint32_t flags, gb_circuit** out);
 /* the same with constants_sigmas as build() holds it (circuit_builder.rs:1198-1229: a Vec<PolynomialValues<F>>, one allocation per

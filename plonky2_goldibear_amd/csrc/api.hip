@@ -303,7 +303,7 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
 // 7^(arity^l) for FRI layer l, fri/prover.rs:122-123).  inverse: tables of s_c^-1 instead.
 // log_n > 20: the work buffer of the outer radix step (de-interleaved coefficients + sub-LDEs of a group of columns), grown on demand
 gb_status ensure_big_work(gb_ctx* ctx, u32 log_n, u32 rate_bits, size_t es, void** p, size_t* elems) {
-    const size_t n = (size_t)1 << log_n, per_col = n + (n << rate_bits), cols = 8;
+    const size_t n = (size_t)1 << log_n, per_col = n + (n << rate_bits), cols = log_n > 22 ? 2 : 8;
     if (gb_status s = ensure(ctx, ctx->big_work, cols * per_col * es)) return s;
     *p = ctx->big_work.p;
     *elems = ctx->big_work.bytes / es;
@@ -514,7 +514,10 @@ struct Stager {
     bool slot_used[SLOTS] = {};
 
     explicit Stager(unsigned nthreads) {
-        for (unsigned i = 0; i < nthreads; i++) workers.emplace_back([this] { work(); });
+        try {   // the C ABI never unwinds: a thread the system refuses is one copy thread less (none: the calling thread copies)
+            for (unsigned i = 0; i < nthreads; i++) workers.emplace_back([this] { work(); });
+        } catch (...) {
+        }
     }
     ~Stager() {
         { std::lock_guard<std::mutex> g(m); stop = true; }
@@ -624,8 +627,14 @@ bool upload_columns(gb_ctx* ctx, const ColSrc& src, bool pinned, size_t c0, size
     char* d = static_cast<char*>(dst);
     const bool ring = !pinned && ctx->copy_threads >= 0 && cc * col_bytes >= ((size_t)2 << 20);
     if (ring) {
-        if (!ctx->stager) ctx->stager = new (std::nothrow) Stager((unsigned)ctx->copy_threads);
-        if (ctx->stager && ctx->stager->upload(src, c0, cc, col_bytes, d, ctx->copy_stream)) return true;
+        bool done = false;
+        try {   // (std::bad_alloc from the piece list: thrown before any worker has been handed the job)
+            if (!ctx->stager) ctx->stager = new (std::nothrow) Stager((unsigned)ctx->copy_threads);
+            done = ctx->stager && ctx->stager->upload(src, c0, cc, col_bytes, d, ctx->copy_stream);
+        } catch (...) {
+            done = false;
+        }
+        if (done) return true;
         (void)hipGetLastError();   // no ring (out of page-locked memory?): the runtime's own pageable path still works
     }
     if (!src.ptrs) return hipMemcpyAsync(d, src.col(c0, col_bytes), cc * col_bytes, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess;
@@ -700,7 +709,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         return fail(ctx, GB_ERR_INVALID, "LDE size exceeds the field's two-adicity (32 Goldilocks / 27 BabyBear)");
     if (cap_height > log_n + rate_bits)
         return fail(ctx, GB_ERR_INVALID, "cap_height should be at most log2(leaves.len()) (merkle_tree.rs:154-157)");
-    if (log_n > 22) return fail(ctx, GB_ERR_UNSUPPORTED, "log_n > 22 not implemented");
+    if (log_n > 24) return fail(ctx, GB_ERR_UNSUPPORTED, "log_n > 24 not implemented");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
@@ -1174,7 +1183,7 @@ gb_status gb_host_unregister(gb_ctx* ctx, void* p) {
 }
 
 // Tuning and debugging switches (none changes a result).  Per context unless noted.
-gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) {
+gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) try {
     if (!ctx || !key) return fail(ctx, GB_ERR_INVALID, "null argument");
     const std::string k(key);
     if (k == "copy_threads") {
@@ -1197,6 +1206,8 @@ gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) {
         return fail(ctx, GB_ERR_INVALID, "unknown option: " + k);
     }
     return GB_OK;
+} catch (...) {
+    return GB_ERR_OOM;
 }
 
 gb_status gb_batch_free(gb_batch* b) {

@@ -28,16 +28,20 @@ using poseidon_gl::to_mont;
 // The group operands live in LDS: every kernel fills its workgroup's table first (GB_POSEIDON_OPS, one barrier).
 #if defined(GB_POSEIDON_HYBRID)
 #define GB_POSEIDON_OPS() const poseidon_gl::v4i* gops = nullptr
-#define permute_mont_mfma(s, amat, cap_only) poseidon_gl::permute_mont_mfma(s, amat)
+#define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma(s, amat)
 #elif defined(GB_POSEIDON_SINGLE_LAYERS)
 #define GB_POSEIDON_OPS() const poseidon_gl::v4i* gops = nullptr
-#define permute_mont_mfma(s, amat, cap_only) poseidon_gl::permute_mont_mfma_naive(s, amat)
+#define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma_naive(s, amat)
 #else
 #define GB_POSEIDON_OPS()                                            \
     __shared__ poseidon_gl::v4i gops_lds[poseidon_gl::GROUP_LDS_V4]; \
     poseidon_gl::group_ops_init(gops_lds);                           \
     const poseidon_gl::v4i* gops = gops_lds + (threadIdx.x & 63)
-#define permute_mont_mfma(s, amat, cap_only) poseidon_gl::permute_mont_mfma_grouped(s, amat, gops, cap_only)
+#ifdef GB_NO_ZERO_CAP   // A/B: the four capacity s-boxes of a permutation that starts from a zero capacity computed like any other
+#define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma_grouped(s, amat, gops, cap_only, false)
+#else
+#define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma_grouped(s, amat, gops, cap_only, zero_cap)
+#endif
 #endif
 // The sponge state of these kernels is kept in the permutation's Montgomery form (poseidon_gl.hpp): absorbed words go through
 // to_mont, the digest through from_mont (canonical); the capacity words never leave that form between absorptions.
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const
             prefetch_columns(cols, col_stride, c0 + 8, width, j);
             GB_PROBE_AT(amat, 2, s);   // absorption: 8 column loads + to_mont
             // (a full absorption follows: words 0..7 of this permutation's output will be overwritten - only the capacity is produced)
-            permute_mont_mfma(s, amat, c0 + 16 <= width);  // the state stays a lazy Montgomery-form residue between absorptions
+            permute_mont_mfma(s, amat, c0 + 16 <= width, c0 == 0);  // the state stays a lazy Montgomery-form residue between absorptions; the first absorption meets a zero capacity
             GB_PROBE_AT(amat, 3, s);   // permutation: the last layer
         }
 #pragma unroll
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(c
         prefetch_columns(cols, col_stride, c0 + 8, c_end, j);
         // is the absorption that follows (in this segment or at the head of the next) a full one?  then only the capacity matters
         const bool next_full = LAST ? c0 + 16 <= c_end : (c0 + 8 < c_end || keep_from == 8);
-        permute_mont_mfma(s, amat, next_full);
+        permute_mont_mfma(s, amat, next_full, FIRST && c0 == c_begin);
     }
     if (!live) return;
     if (!LAST) {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_level(const 
     ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
     u64 s[12] = {to_mont(a.x), to_mont(a.y), to_mont(b.x), to_mont(b.y), to_mont(c.x), to_mont(c.y), to_mont(d.x), to_mont(d.y),
                  0, 0, 0, 0};
-    permute_mont_mfma(s, amat, false);
+    permute_mont_mfma(s, amat, false, true);   // two_to_one: zero capacity
     if (!live) return;
     ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
     o[0] = make_ulonglong2(from_mont(s[0]), from_mont(s[1]));
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_poseidon_permute(co
     u64 s[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) s[e] = to_mont(in[12 * i + e]);
-    permute_mont_mfma(s, amat, false);
+    permute_mont_mfma(s, amat, false, false);
     if (!live) return;
 #pragma unroll
     for (int e = 0; e < 12; e++) out[12 * i + e] = from_mont(s[e]);

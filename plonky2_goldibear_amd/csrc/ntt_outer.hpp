@@ -1,5 +1,5 @@
 // Transforms of more than 2^20 rows (round 5; the reference has no size cap below the field's two-adicity, field/src/fft.rs:168-205):
-// one outer radix-R step, R = 2^K = n / 2^20, around the 2^20-row passes.  With i = R i2 + i1 (decimation in time),
+// one outer radix-R step, R = 2^K = n / 2^20 <= 16 (2^21 .. 2^24 rows), around the 2^20-row passes.  With i = R i2 + i1 (decimation in time),
 //     X[k2 + m k1] = sum_i1 w_R^(i1 k1) * ( g(k2)^i1 * Y_i1[k2] ),     Y_i1 = the size-m = 2^20 transform of the stride-R subsequence i1,
 // g(k2) = w_n^(k2) (times the coset shift s_c for the LDE, whose sub-transforms run on the shift s_c^R).  So: de-interleave the R
 // subsequences (one pass), run the existing kernels on R times as many columns of 2^20 rows, and combine (one pass: twiddle, R-point
@@ -35,15 +35,28 @@ __device__ __forceinline__ typename F::T tw_split(const typename F::T* __restric
     return (e >> 10) ? F::mul(w, hi[e >> 10]) : w;
 }
 
-// R-point DFT (R = 2 or 4) of z[0..R) with the primitive 4th root `w4` (forward or inverse, as the caller passes it): X[k1] in x[k1]
+// R-point DFT (R = 2^K <= 16) of z[0..R) with the primitive R-th root `wr` (forward or inverse, as the caller passes it): X[k1] in
+// z[k1].  R = 2 and 4 in registers; 8 and 16 (2^23 and 2^24 rows) as the plain O(R^2) sum - coverage, not speed.
 template <class F>
-__device__ __forceinline__ void dft_r(typename F::T (&z)[4], u32 K, typename F::T w4) {
+__device__ __forceinline__ void dft_r(typename F::T (&z)[16], u32 K, typename F::T wr) {
     typedef typename F::T T;
     if (K == 1) {
         const T a = z[0], b = z[1];
         z[0] = F::add(a, b);
         z[1] = F::sub(a, b);
+    } else if (K > 2) {
+        const u32 R = 1u << K;
+        T wp[16], x[16];
+        wp[0] = F::one();
+        for (u32 j = 1; j < R; j++) wp[j] = F::mul(wp[j - 1], wr);
+        for (u32 k1 = 0; k1 < R; k1++) {
+            T acc = z[0];
+            for (u32 i1 = 1; i1 < R; i1++) acc = F::add(acc, F::mul(z[i1], wp[(i1 * k1) & (R - 1)]));
+            x[k1] = acc;
+        }
+        for (u32 k1 = 0; k1 < R; k1++) z[k1] = x[k1];
     } else {
+        const T w4 = wr;
         const T s02 = F::add(z[0], z[2]), d02 = F::sub(z[0], z[2]), s13 = F::add(z[1], z[3]), d13 = F::mul(F::sub(z[1], z[3]), w4);
         z[0] = F::add(s02, s13);
         z[1] = F::add(d02, d13);
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(THREADS) void k_intt_combine(typename F::T* __restr
     const u32 k2 = (u32)(g & (((size_t)1 << log_m) - 1)), R = 1u << K;
     T* p = data + ((col << log_m) << K) + k2;
     const T w = tw_split<F>(tw_hi_inv, tw_lo_inv, k2);   // w_n^-k2
-    T z[4], f = r_inv;
+    T z[16], f = r_inv;
     for (u32 i1 = 0; i1 < R; i1++) {
         z[i1] = F::mul(p[(size_t)i1 << log_m], f);
         f = F::mul(f, w);
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(THREADS) void k_lde_combine(const typename F::T* __
     const size_t col = cc >> rate_bits;
     const u32 k2 = brev_bits(q, log_m);
     const T gk = F::mul(pow_lo[(size_t)c * nlo + 1], tw_split<F>(tw_hi, tw_lo, k2));   // s_c w_n^k2
-    T z[4], f = F::one();
+    T z[16], f = F::one();
     for (u32 i1 = 0; i1 < R; i1++) {
         const T v = sub[(((((col << K) + i1) << rate_bits) + c) << log_m) + q];
         z[i1] = i1 ? F::mul(v, f) : v;
@@ -111,7 +124,7 @@ void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T
         (void)hipMemcpyAsync(coeffs, scratch, ncols * n * sizeof(T), hipMemcpyDeviceToDevice, st);
     }
     sub_intt(coeffs, coeffs, scratch, ncols << K);
-    const T w4_inv = F::inv(F::two_adic_generator(2)), r_inv = F::inv(F::enc((u64)1 << K));
+    const T w4_inv = F::inv(F::two_adic_generator(K < 2 ? 2 : K)), r_inv = F::inv(F::enc((u64)1 << K));   // the R-th root (R = 2: unused)
     hipLaunchKernelGGL(k_intt_combine<F>, dim3(grid), dim3(THREADS), 0, st, coeffs, log_m, K, tw_hi_inv, tw_lo_inv, w4_inv, r_inv);
 }
 
@@ -123,7 +136,7 @@ void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, 
     const u32 K = log_n - 20, log_m = 20;
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     const size_t group = std::max<size_t>(1, work_elems / (n + N));
-    const T w4 = F::two_adic_generator(2);
+    const T w4 = F::two_adic_generator(K < 2 ? 2 : K);   // the primitive R-th root
     for (size_t c0 = 0; c0 < ncols; c0 += group) {
         const size_t g = std::min(group, ncols - c0);
         T* wc = work;            // [g R][m] de-interleaved coefficients

@@ -70,6 +70,22 @@ constexpr u64 FIRST_RC[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST
 constexpr u64 PARTIAL_RC[22] = {GL_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS_LIST};
 }  // namespace raw
 __device__ static const U64Table<GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN> RC_T = raw::times_r(raw::ALL_RC);
+// A permutation that starts from a ZERO capacity (two_to_one: hash/hashing.rs:76-96; the first absorption of a sponge, :100-123):
+// words 8..11 after the first constant layer ARE the round constants, so their first s-boxes are constants too -
+// (rc^7) R, Montgomery form like the state - and 4 of the permutation's 118 s-boxes are not computed (round 5).
+namespace raw {
+constexpr u64 cpow7(u64 c) {
+    const u128 p = gl::P;
+    const u64 c2 = (u64)((u128)c * c % p), c4 = (u64)((u128)c2 * c2 % p), c3 = (u64)((u128)c2 * c % p);
+    return (u64)((u128)c3 * c4 % p);
+}
+constexpr U64Table<4> zero_capacity_sboxes() {
+    U64Table<4> t{};
+    for (int i = 0; i < 4; i++) t.v[i] = cmulmod_r(cpow7(ALL_RC[8 + i] % gl::P));
+    return t;
+}
+}  // namespace raw
+__device__ static const U64Table<4> ZERO_CAP_SBOX_T = raw::zero_capacity_sboxes();
 __device__ static const U64Table<12> FP_FIRST_T = raw::times_r(raw::FIRST_RC);
 __device__ static const U64Table<22> FP_RC_T = raw::times_r(raw::PARTIAL_RC);
 #define GB_RC (poseidon_gl::RC_T.v)

@@ -307,14 +307,23 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
 
 // The permutation with every MDS layer on the matrix pipe and the partial rounds in groups; same contract as
 // permute_mont_mfma_naive (Montgomery-form lazy residues in and out).  `amat` = mds_mfma_matrix(), `ops` = the workgroup's operand
-// table (group_ops_init) offset by this thread's lane.  capacity_only: see mds_layer_mfma<Q0>.
-__device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const MdsOperand& amat, const v4i* __restrict__ ops, bool capacity_only = false) {
+// table (group_ops_init) offset by this thread's lane.  capacity_only: see mds_layer_mfma<Q0>.  zero_capacity (uniform): words
+// 8..11 of the state are zero on entry - their first s-boxes are the constants ZERO_CAP_SBOX_T and are not computed.
+__device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const MdsOperand& amat, const v4i* __restrict__ ops, bool capacity_only = false,
+                                                          bool zero_capacity = false) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
     GB_PROBE_AT(amat, 10, s);   // permutation: first constants
     for (int r = 0; r < HALF_FULL; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        for (int i = 0; i < 8; i++) s[i] = sbox(s[i]);
+        if (r == 0 && zero_capacity) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[8 + i] = ZERO_CAP_SBOX_T.v[i];
+        } else {
+#pragma unroll
+            for (int i = 8; i < 12; i++) s[i] = sbox(s[i]);
+        }
         GB_PROBE_AT(amat, 11, s);   // full round: 12 s-boxes
         mds_layer_mfma(s, amat, r + 1);
         GB_PROBE_AT(amat, 22, s);   // layer: fold

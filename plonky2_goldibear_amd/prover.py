@@ -88,7 +88,7 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
     def __init__(self, ctx, degree_bits, constants_sigmas, k_is, *, num_wires=135, num_routed_wires=80, num_constants=2,
                  num_challenges=2, max_quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16,
                  num_query_rounds=28, arity_bits=4, final_poly_bits=5, num_selectors=1, gate_constant=1, gate_pi=2,
-                 field=N.GB_GOLDILOCKS, gates=None, zero_knowledge=False, num_public_inputs=0, reduction_arity_bits=None):
+                 field=N.GB_GOLDILOCKS, gates=None, zero_knowledge=False, num_public_inputs=0, reduction_arity_bits=None, p3_repr=False):
         """`gates` = None: the dummy circuit's gate set, given by the selector values gate_constant / gate_pi
         (gb_circuit_create).  Otherwise CommonCircuitData.gates with selectors_info, one tuple
         (kind, param, selector_index, group_start, group_end) per gate in sorted order (gb_circuit_create_gates; what
@@ -115,6 +115,8 @@ class CircuitData(_ProofBytesOps, _FriParamsOps):
         else:
             kptr, keep2 = k.ctypes.data, k
         h = C.c_void_p()
+        if p3_repr:   # constants_sigmas and k_is are the field types' in-memory words (host input)
+            flags |= N.GB_INPUT_P3_REPR
         if gates is None:
             fn = self._lib.gb_circuit_create_cols if cs_cols else self._lib.gb_circuit_create
             N.check(fn(ctx.handle, C.byref(self.cfg), ptr, kptr, flags, C.byref(h)), ctx.handle)

@@ -41,12 +41,12 @@ def to_p3_words(a, field):
     return out
 
 
-def _gpu_circuit(ctx, circ, tag, cs=None):
+def _gpu_circuit(ctx, circ, tag, cs=None, k_is=None, p3_repr=False):
     cfg = circ.cfg
-    return CircuitData(ctx, circ.degree_bits, circ.constants_sigmas if cs is None else cs, circ.k_is, num_wires=cfg.num_wires,
-                       num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
+    return CircuitData(ctx, circ.degree_bits, circ.constants_sigmas if cs is None else cs, circ.k_is if k_is is None else k_is,
+                       num_wires=cfg.num_wires, num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
                        num_challenges=cfg.num_challenges, arity_bits=cfg.arity_bits, gate_constant=circ.GATE_CONSTANT,
-                       gate_pi=circ.GATE_PI, field=tag)
+                       gate_pi=circ.GATE_PI, field=tag, p3_repr=p3_repr)
 
 
 @pytest.mark.parametrize("field_name,log_n,ncols", [
@@ -188,6 +188,11 @@ def test_prove_cols_bytes_match_oracle(ctx, field_name, degree_bits, num_challen
     assert (gpu2.constants_sigmas_cap == gpu.constants_sigmas_cap).all() and (gpu2.circuit_digest == gpu.circuit_digest).all()
     assert gpu2.prove_once(columns_of(w)) == want
     gpu2.free()
+    # ... and as the field types' in-memory words (circuit data and witness alike: nothing canonicalised on the host)
+    gpu3 = _gpu_circuit(ctx, circ, tag, cs=columns_of(to_p3_words(circ.constants_sigmas, tag)), k_is=to_p3_words(circ.k_is, tag), p3_repr=True)
+    assert (gpu3.constants_sigmas_cap == gpu.constants_sigmas_cap).all() and (gpu3.circuit_digest == gpu.circuit_digest).all()
+    assert gpu3.prove_once(columns_of(to_p3_words(w, tag)), p3_repr=True) == want
+    gpu3.free()
     gpu.free()
     ctx.trim()
 

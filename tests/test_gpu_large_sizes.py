@@ -113,3 +113,57 @@ def test_zs_running_product_above_1024_blocks(ctx):
             assert int(Z[r + 1]) * den % P == int(Z[r]) * num % P, (c, r)
     gpu.free()
     ctx.trim()
+
+
+@pytest.mark.parametrize("field_name,log_n", [("goldilocks", 23), ("babybear", 23), ("goldilocks", 24), ("babybear", 24)])
+def test_from_values_2pow23_and_2pow24_rows_sparse_polynomials(ctx, field_name, log_n):
+    """2^23 / 2^24 rows (outer radix 8 / 16; BabyBear's two-adicity ends at 2^24 rows with rate_bits 3) through size-independent
+    properties, no oracle run of that size: the values of SPARSE polynomials a x^k1 + b x^k2 + c with exponents all over [0, n) are
+    built on the host with vectorised powers; from_values must return exactly those coefficients (EVERY one of the n compared), the LDE
+    rows must equal the polynomials evaluated directly at 7 w_N^i, and sampled Merkle paths must verify against the cap."""
+    n = 1 << log_n
+    if field_name == "goldilocks":
+        P, tag, dt, powers, hmod = GL.P, N.GB_GOLDILOCKS, np.uint64, DC.gl_powers, O
+        gen_N = pow(1753635133440165772, 1 << (32 - log_n - 3), P)
+        mul = DC.gl_mul
+        shift = 7
+    else:
+        P, tag, dt, powers, hmod = DC.BB_P, GB_BABYBEAR, np.uint32, DC.bb_powers, B
+        gen_N = pow(0x1a427a41, 1 << (27 - log_n - 3), P)
+        mul = DC.bb_mul
+        shift = 31
+    w_n = pow(gen_N, 8, P)
+    rng = np.random.default_rng(log_n)
+    polys = []
+    for _ in range(2):
+        ks = sorted({0, int(rng.integers(1, n)), n - 1 - int(rng.integers(0, 1000)), int(rng.integers(1, 1 << 20))})
+        polys.append({k: int(rng.integers(1, P, dtype=np.uint64)) for k in ks})
+    vals = np.zeros((2, n), dtype=dt)
+    for c, poly in enumerate(polys):
+        acc = np.zeros(n, dtype=np.uint64)
+        for k, a in poly.items():
+            term = mul(powers(pow(w_n, k, P), n), dt(a)).astype(np.uint64)      # a (w_n^k)^i
+            with np.errstate(over="ignore"):
+                t = acc + term                                                   # BabyBear: no wrap; Goldilocks: 2^64 = 2^32 - 1 (mod p)
+                if P > (1 << 32):
+                    t = np.where(t < acc, t + np.uint64(0xFFFFFFFF), t)
+                acc = np.where(t >= np.uint64(P), t - np.uint64(P), t)
+        vals[c] = acc.astype(dt)
+    gpu = PolynomialBatch.from_values(ctx, vals, 3, 4, field=tag)
+    for c, poly in enumerate(polys):
+        want = np.zeros(n, dtype=dt)
+        for k, a in poly.items():
+            want[k] = a
+        assert (gpu.polynomial(c) == want).all(), "coefficients of column %d" % c
+    Nn = n << 3
+    for i in (0, 1, n - 1, 5 * n + 12345, Nn - 1):
+        x = shift * pow(gen_N, i, P) % P
+        want = [sum(a * pow(x, k, P) for k, a in poly.items()) % P for poly in polys]
+        got = gpu.get_lde_values(i, 1)
+        assert [int(v) for v in got] == want, i
+    cap = gpu.merkle_tree.cap
+    for leaf in (0, 77, Nn - 1, int(rng.integers(0, Nn))):
+        row, sib = gpu._leaf(leaf)
+        assert hmod.merkle_verify(row, leaf, cap, sib), leaf
+    gpu.free()
+    ctx.trim()
