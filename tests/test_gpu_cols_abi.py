@@ -148,6 +148,10 @@ def test_cols_errors(ctx):
     assert lib.gb_commit_values_cols(ctx.handle, 0, ptrs, 4, 6, 3, 4, None, 0x200, C.byref(h)) == N.GB_ERR_INVALID  # unknown flag bit
     assert lib.gb_commit_values_cols(ctx.handle, 0, ptrs, 4, 6, 3, 4, None, N.GB_INPUT_DEVICE | N.GB_INPUT_P3_REPR, C.byref(h)) == N.GB_ERR_INVALID
     assert lib.gb_commit_values(ctx.handle, 0, vals.ctypes.data, 4, 6, 3, 4, None, 0x100, C.byref(h)) == N.GB_ERR_INVALID   # the internal bit
+    # page-locked memory: a zero-sized allocation and the unregistration of a range that was never registered are errors, not crashes
+    assert lib.gb_host_alloc(ctx.handle, 0, C.byref(h)) == N.GB_ERR_INVALID
+    assert lib.gb_host_unregister(ctx.handle, cols[0].ctypes.data) == N.GB_ERR_INVALID
+    assert lib.gb_host_free(ctx.handle, None) == N.GB_OK
     with pytest.raises(ShapeError):
         ctx.set_option("no_such_option", 1)
     with pytest.raises(ShapeError):
