@@ -78,5 +78,17 @@ def test_gpu_salted_proof_bytes_match_oracle(F, degree_bits):
     assert gpu.prove(wd, salts=sd) == want
     with pytest.raises(N.ShapeError):
         gpu.prove(w)             # a zero-knowledge circuit needs its salts
+    # the witness as separately allocated columns and, like the salts (F::rand_vec columns), in the field type's in-memory words
+    # (gb_prove_salted_cols + GB_INPUT_P3_REPR): the same bytes
+    def p3(a):
+        if F is GL:
+            out = a.copy()
+            small = a < np.uint64(0xFFFFFFFF)
+            out[small] = a[small] + np.uint64(GL.P)      # a non-canonical representative wherever one fits in 64 bits
+            return out
+        return ((a.astype(np.uint64) << np.uint64(32)) % np.uint64(BB.P)).astype(np.uint32)
+    assert gpu.prove([np.array(c, copy=True) for c in w], salts=salts) == want
+    assert gpu.prove([np.array(c, copy=True) for c in p3(w)], salts=p3(np.ascontiguousarray(salts)), p3_repr=True) == want
+    assert gpu.prove(p3(w), salts=p3(np.ascontiguousarray(salts)), p3_repr=True) == want
     gpu.free()
     ctx.close()
