@@ -218,6 +218,22 @@ def test_retry_cols_is_incremental_and_byte_identical(ctx):
         with pytest.raises(PermArgZeroError):
             gpu.prove_once(columns_of(conv(w0)), p3_repr=p3)
         assert gpu.prove_once(columns_of(conv(w)), retry_wire=rw, p3_repr=p3) == want
+    # "retry_verify": the library compares the caller's columns with the copy the failed attempt kept, column by column
+    ctx.set_option("retry_verify", 1)
+    try:
+        gpu.arm_perm_arg_failure()
+        with pytest.raises(PermArgZeroError):
+            gpu.prove_once(columns_of(w0))
+        assert gpu.prove_once(columns_of(w), retry_wire=rw) == want
+        other = columns_of(w)
+        other[7][123] = np.uint64(5)
+        gpu.arm_perm_arg_failure()
+        with pytest.raises(PermArgZeroError):
+            gpu.prove_once(columns_of(w0))
+        with pytest.raises(ShapeError):
+            gpu.prove_once(other, retry_wire=rw)        # differs in more than witness[wire][row]
+    finally:
+        ctx.set_option("retry_verify", 0)
     # the retry loop of the host mirror over a column list (prover.rs:183-226)
     cols = columns_of(w0)
     gpu.arm_perm_arg_failure()
