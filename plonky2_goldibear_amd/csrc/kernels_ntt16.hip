@@ -141,6 +141,50 @@ __device__ __forceinline__ void load_tw16(u64 (&tw)[16], const u64* __restrict__
 // The inter-stage twiddles cost as much as the butterflies here (ablations in DESIGN.md: without their loads and products the pass
 // runs 33 % faster, close to a plain copy): the first stage reads them from a copy of the table laid out [slot][tid] (coalesced),
 // the second from a 256-entry table in LDS.
+#ifdef GB_PB_OCC5
+// Experiment (round 5, NOT the product): five workgroups per CU instead of four - the tile in exactly 32 KB of LDS (no row padding:
+// the transposes rotate columns within their 16-blocks instead), the stage-2 twiddles read from the table (L2) instead of a 2 KB
+// LDS copy, 96 VGPRs, no scratch.  Bit-identical; measured 5.36 ms against 4.72 ms per 135 columns (same box, alternating,
+// tools/ab_kernel_times.sh pbbase pbocc5): the fifth workgroup does not pay for the stage-2 twiddles coming from L2.
+__global__ __launch_bounds__(THREADS, 5) void k_gl_lde_pb16(u64* __restrict__ lde, const u64* __restrict__ tw4096) {
+    __shared__ u64 sh[16 * 256];
+    u64* p = lde + ((size_t)blockIdx.x << 12);
+    const u32 tid = threadIdx.x;
+    u64 x[16];
+#pragma unroll
+    for (u32 d = 0; d < 16; d++) x[d] = p[d * 256 + tid];
+    {
+        u64 tw[16];
+#pragma unroll
+        for (u32 s = 1; s < 16; s++) tw[s] = tw4096[4096 + s * 256 + tid];
+        dft16<false>(x);
+#pragma unroll
+        for (u32 s = 0; s < 16; s++) sh[s * 256 + tid] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
+    }
+    __syncthreads();
+    const u32 hi4 = tid >> 4, lo4 = tid & 15;
+#pragma unroll
+    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 256 + d * 16 + lo4];
+    dft16<false>(x);
+    __syncthreads();
+#pragma unroll
+    for (u32 s = 0; s < 16; s++)   // [k2 slot][d0][(k1 slot + d0) & 15]
+        sh[hi4 * 256 + lo4 * 16 + ((s + lo4) & 15)] = s ? gl::mul_mont(x[s], tw4096[((brev4(s) * lo4) & 255) * 16]) : x[s];
+    __syncthreads();
+#pragma unroll
+    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 256 + d * 16 + ((lo4 + d) & 15)];
+    dft16<false>(x);
+    __syncthreads();
+#pragma unroll
+    for (u32 s = 0; s < 16; s++) sh[tid * 16 + ((s + tid) & 15)] = x[s];
+    __syncthreads();
+#pragma unroll
+    for (u32 it = 0; it < 16; it++) {
+        const u32 q = it * 256 + tid;
+        p[q] = sh[(q >> 4) * 16 + (((q & 15) + (q >> 4)) & 15)];
+    }
+}
+#else
 __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, const u64* __restrict__ tw4096) {
     __shared__ u64 sh[16 * 272];
     __shared__ u64 tw2[256];  // the stage-2 twiddles as the threads read them: tw2[s][d0] = w_256^(brev4(s) d0) - consecutive lanes,
@@ -185,6 +229,7 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
     }
 }
 
+#endif
 // ------------------------------------------------------------------ LDE pass A
 // LA = 8: grid = ncols * 256, tile 256 rows (a = 16 a1 + a0) x 16 columns.  Per coset: scale by s^(4096 a),
 // two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
