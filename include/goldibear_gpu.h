@@ -67,7 +67,8 @@ gb_status gb_ctx_destroy(gb_ctx* ctx);
 const char* gb_last_error(const gb_ctx* ctx); /* valid until the next call on ctx; ctx may be NULL */
 gb_status gb_ctx_synchronize(gb_ctx* ctx);
 /* Freed batches keep their device blocks in a per-context pool for reuse by later commits of the
- * same shape (the reference allocates fresh Vecs per PolynomialBatch); this returns them to HIP. */
+ * same shape (the reference allocates fresh Vecs per PolynomialBatch); this returns them to HIP - together with what failed
+ * attempts keep for gb_prove_retry and the page-locked staging ring of pageable inputs (256 MiB of host memory, its copy threads). */
 gb_status gb_ctx_trim(gb_ctx* ctx);
 /* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
 gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out);

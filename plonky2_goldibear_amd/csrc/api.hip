@@ -1060,6 +1060,11 @@ gb_status gb_ctx_trim(gb_ctx* ctx) {
     drop_all_retry_state(ctx);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     ctx->pool.clear();
+    if (ctx->stager) {   // the page-locked staging ring and its copy threads come back with the next pageable input
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+        delete ctx->stager;
+        ctx->stager = nullptr;
+    }
     return GB_OK;
 }
 
