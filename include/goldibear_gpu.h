@@ -162,9 +162,14 @@ gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** di
  * over the eighteen gate kinds GB_GATE_* with any selector grouping - every gate DefaultGateSerializer knows except
  * LookupGate / LookupTableGate, which are GB_ERR_UNSUPPORTED - and evaluates it on the GPU as well.
  * Both of the reference's configurations are served (plonk/config.rs:119-150): GB_GOLDILOCKS = D 2, H 4,
- * Poseidon-12, 8-byte elements; GB_BABYBEAR = D 4 (x^4 - 11), H 8, Poseidon2-16, 4-byte elements.  The quotient
- * kernel is compiled for max_quotient_degree_factor 8 with 1..4 challenges (Goldilocks; also 16 with 1..2) and
- * 6..10 challenges (BabyBear, where circuit_builder.rs:1190-1192 demands (31 - degree_bits) * c >= 100). */
+ * Poseidon-12, 8-byte elements; GB_BABYBEAR = D 4 (x^4 - 11), H 8, Poseidon2-16, 4-byte elements.
+ * Configuration range of the prover: degree_bits 2 .. 22; max_quotient_degree_factor 8 (Goldilocks also 16); rate_bits from
+ * log2 of that factor up to 8 - above it the quotient is computed on every 2^(rate_bits - log2 factor)-th point of the LDE, as
+ * plonk/prover.rs:735-749 does (the reference's size-optimised recursion proofs use rate_bits 7 and 8,
+ * recursion/recursive_verifier.rs:573-611); num_challenges 1 .. 16 (BabyBear from 4: circuit_builder.rs:1190-1192 demands
+ * (31 - degree_bits) * c >= 100, and a count that fails that assert is GB_ERR_INVALID for either field); FRI arity_bits 1 .. 8;
+ * num_constants <= 4.  The quotient and gate kernels keep their per-challenge sums in registers and are compiled for 1 .. 4
+ * challenges (Goldilocks) and 4 .. 10 (BabyBear) - the stock configurations; other counts run as slices of those widths. */
 typedef struct gb_circuit gb_circuit;
 typedef struct gb_circuit_config {
     uint32_t field;                 /* GB_GOLDILOCKS | GB_BABYBEAR */
@@ -247,8 +252,7 @@ gb_status gb_circuit_verifier_data(gb_circuit* c, void* cap_out, void* digest_ou
  * fri/reduction_strategies.rs:29-56).  gb_circuit_create* / gb_verifier_create derive the list of the stock strategy
  * ConstantArityBits(cfg.arity_bits, cfg.final_poly_bits); a circuit configured with Fixed(..) or MinSize(..) hands the list its
  * CommonCircuitData holds over with the setter before the first proof (prover, verifier and proof compression all read it).
- * Rejected with GB_ERR_INVALID: more than GB_MAX_FRI_LAYERS layers, an arity outside [1, 4] (prover circuits; [1, 8] for
- * verify-only circuits), arities that sum past degree_bits, or a layer whose tree would be lower than cap_height
+ * Rejected with GB_ERR_INVALID: more than GB_MAX_FRI_LAYERS layers, an arity_bits outside [1, 8], arities that sum past degree_bits, or a layer whose tree would be lower than cap_height
  * (MerkleTree::new's assert, hash/merkle_tree.rs:154-157).  The getter writes at most GB_MAX_FRI_LAYERS entries. */
 #define GB_MAX_FRI_LAYERS 32
 gb_status gb_circuit_set_fri_reduction_arity_bits(gb_circuit* c, const uint32_t* arity_bits, uint32_t num_layers);

@@ -212,14 +212,17 @@ class CommonDataCircuit(DummyCircuit):
 
 
 def gate_constraint_terms(circ, witness, public_inputs=()):
-    """The gate part of eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:741-774) on the prover's whole LDE coset, for any
+    """The gate part of eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:741-774) on the prover's quotient domain (every
+    step-th point of the commitments' LDE, step = 2^(rate_bits - log2 quotient_degree_factor), prover.rs:735-749), for any
     gate set of oracle/gates.py: out[i][j] = sum over the gates of compute_filter(selector)(x_i) * unfiltered constraint j at
-    x_i = shift * w_N^i, num_gate_constraints columns.  The wires and constants at x_i are base-field values; gates.py's
+    x_i = shift * w_Q^i, Q = n * quotient_degree_factor points, num_gate_constraints columns.  The wires and constants at x_i are base-field values; gates.py's
     evaluators work on the extension algebra, in which a base value v is (v, 0, ..) and every constraint comes out as (c, 0, ..).
     Pure Python: meant for circuits of 2^6..2^8 rows."""
     e, cfg = circ.F, circ.cfg
     r, H, nsel = cfg.rate_bits, e.hout, circ.num_selectors
-    N = circ.n << r
+    qb = cfg.max_quotient_degree_factor.bit_length() - 1
+    assert cfg.max_quotient_degree_factor == 1 << qb and qb <= r
+    N, step = circ.n << qb, 1 << (r - qb)
     pi_hash = [int(x) for x in e.hash_no_pad(np.asarray(list(public_inputs), dtype=e.dtype))]
     cs = e.mod.PolynomialBatch.from_values(np.ascontiguousarray(circ.constants_sigmas[:circ.num_constants]), r, cfg.cap_height)
     wb = e.mod.PolynomialBatch.from_values(np.ascontiguousarray(witness, dtype=e.dtype), r, cfg.cap_height)
@@ -227,8 +230,8 @@ def gate_constraint_terms(circ, witness, public_inputs=()):
     out = np.zeros((N, ngc), dtype=e.dtype)
     pad = (0,) * (e.D - 1)
     for i in range(N):
-        consts = [(int(v),) + pad for v in cs.get_lde_values(i, 1)[:circ.num_constants]]
-        wires = [(int(v),) + pad for v in wb.get_lde_values(i, 1)[:cfg.num_wires]]
+        consts = [(int(v),) + pad for v in cs.get_lde_values(i, step)[:circ.num_constants]]
+        wires = [(int(v),) + pad for v in wb.get_lde_values(i, step)[:cfg.num_wires]]
         acc = [0] * ngc
         for row, g in enumerate(circ.gate_table):
             f = G.compute_filter(e, row, g, consts[g[2]], nsel > 1)

@@ -114,10 +114,10 @@ static F_T *dump_zs_values = NULL, *dump_quotient_chunks = NULL;
 #define X_CAT(a, b) X_CAT2(a, b)
 void X_CAT(X_PROVE_DUMMY, _set_dump)(F_T *zs_values, F_T *quotient_chunks) { dump_zs_values = zs_values; dump_quotient_chunks = quotient_chunks; }
 /* Gate sets beyond the five kinds evaluated below (the recursion circuits' gates): the caller hands over the gate part of
- * eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:741-774) - for every LDE point i (index of shift * w_N^i) the
+ * eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:741-774) - for every point i of the quotient domain (shift * w_Q^i, Q = n * quotient_degree_factor) the
  * num_gate_constraints sums  sum_gates filter(selector) * unfiltered_constraint_j  - computed by oracle/plonk_dummy.py
  * gate_constraint_terms() with the evaluators of oracle/gates.py (the ones the reference's recursion proof pins);
- * [N][nterms], used by the next proof instead of the inline evaluators. */
+ * [Q][nterms], used by the next proof instead of the inline evaluators. */
 /* FriParams.reduction_arity_bits of a circuit whose FriReductionStrategy is Fixed(..) or MinSize(..) (fri/reduction_strategies.rs:
  * 29-56): when set, the next proofs use this list instead of deriving ConstantArityBits' from the configuration. */
 static unsigned ext_arity_bits[32], ext_narity = 0;
@@ -144,7 +144,13 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
     const unsigned qdf = cfg->quotient_degree_factor;
     const unsigned num_prods = (nr + qdf - 1) / qdf - 1; /* util/partial_products.rs:41-48 */
     const unsigned nchunks = num_prods + 1;
-    if (((size_t)1 << r) != qdf) return -10; /* step = 1 case only (prover.rs:746-749) */
+    /* prover.rs:735-749: quotient_degree_bits = log2_ceil(quotient_degree_factor) <= rate_bits; the quotient is computed on every
+     * step-th point of the commitments' LDE, step = 2^(rate_bits - quotient_degree_bits).  Power-of-two factors only (every
+     * stock configuration has max_quotient_degree_factor = 8). */
+    unsigned qb = 0;
+    while (((size_t)1 << qb) < qdf) qb++;
+    if (((size_t)1 << qb) != qdf || qb > r || qb > 6) return -10;
+    const size_t qstep = (size_t)1 << (r - qb), Q = n << qb; /* step, lde_size */
     buf_t ob = {out, 0, out_cap};
     int rc = 0;
     const int gbo_timing_on = getenv("GBO_TIMING") != NULL;
@@ -234,15 +240,15 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
     for (unsigned i = 0; i < c; i++) alphas[i] = X_CH_GET(&ch);
 
     GBO_SCOPE("zs commit");
-    /* ---- prover.rs:712-926 compute_quotient_polys: step = 1, next_step = 2^r, lde_size = N */
-    qvals = malloc((size_t)c * N * sizeof(F_T));
+    /* ---- prover.rs:712-926 compute_quotient_polys: next_step = 2^qb, lde_size = Q = n 2^qb */
+    qvals = malloc((size_t)c * Q * sizeof(F_T));
     {
         /* ZeroPolyOnCoset (field/src/zero_poly_coset.rs:22-62) */
         F_T g_pow_n = F_POW(F_GENERATOR, n);
         F_T zh[64], zh_inv[64];
-        F_T wr = F_TWO_ADIC(r), xr = 1;
-        for (unsigned i = 0; i < (1u << r); i++) { zh[i] = F_SUB(F_MUL(g_pow_n, xr), 1); zh_inv[i] = F_INV(zh[i]); xr = F_MUL(xr, wr); }
-        F_T wN = F_TWO_ADIC(lgN);
+        F_T wr = F_TWO_ADIC(qb), xr = 1;
+        for (unsigned i = 0; i < (1u << qb); i++) { zh[i] = F_SUB(F_MUL(g_pow_n, xr), 1); zh_inv[i] = F_INV(zh[i]); xr = F_MUL(xr, wr); }
+        F_T wN = F_TWO_ADIC(lg + qb); /* points = two_adic_subgroup(degree_bits + quotient_degree_bits) */
         /* num_gate_constraints = max over the gate set (circuit_builder.rs:1286-1290) */
         unsigned ngc = 0;
         for (unsigned g = 0; g < cfg->num_gates; g++) {
@@ -256,17 +262,18 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
         if (nterms > GBO_MAX_TERMS || ngc > GBO_MAX_GATE_CONSTRAINTS || (!ext_gate_terms && cfg->num_gates > 16)) { rc = -11; goto done; }
         /* Rayon par_chunks(BATCH_SIZE = 32) over the points (prover.rs:791-797) */
 #pragma omp parallel for schedule(static)
-        for (size_t i0 = 0; i0 < N; i0 += 32) {
+        for (size_t i0 = 0; i0 < Q; i0 += 32) {
         F_T terms[GBO_MAX_TERMS];
         F_T pt = F_POW(wN, i0);
-        for (size_t i = i0; i < i0 + 32 && i < N; i++, pt = F_MUL(pt, wN)) {
+        for (size_t i = i0; i < i0 + 32 && i < Q; i++, pt = F_MUL(pt, wN)) {
             F_T x = F_MUL(F_GENERATOR, pt); /* shifted_x */
-            size_t i_next = (i + ((size_t)1 << r)) % N;
-            const F_T *lcs = batch_lde(&cs, i, 1), *lw = batch_lde(&wires, i, 1), *lz = batch_lde(&zs, i, 1), *nz = batch_lde(&zs, i_next, 1);
+            size_t i_next = (i + ((size_t)1 << qb)) % Q;
+            const F_T *lcs = batch_lde(&cs, i, qstep), *lw = batch_lde(&wires, i, qstep), *lz = batch_lde(&zs, i, qstep),
+                      *nz = batch_lde(&zs, i_next, qstep); /* get_lde_values(i, step) (prover.rs:819-831) */
             const F_T *consts = lcs, *sig = lcs + cfg->num_constants;
             unsigned t = 0;
             /* eval_l_0 (zero_poly_coset.rs:58-61) */
-            F_T l0 = F_MUL(zh[i % (1u << r)], F_INV(F_MUL(F_FROM_U64(n), F_SUB(x, 1))));
+            F_T l0 = F_MUL(zh[i % (1u << qb)], F_INV(F_MUL(F_FROM_U64(n), F_SUB(x, 1))));
             for (unsigned k = 0; k < c; k++) terms[t++] = F_MUL(l0, F_SUB(lz[k], 1));
             for (unsigned k = 0; k < c; k++) {
                 /* check_partial_products (util/partial_products.rs:53-77) */
@@ -318,7 +325,7 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
             for (unsigned k = 0; k < c; k++) {
                 F_T cum = 0;
                 for (unsigned tt = t; tt-- > 0;) cum = F_ADD(terms[tt], F_MUL(cum, alphas[k]));
-                qvals[(size_t)k * N + i] = F_MUL(cum, zh_inv[i % (1u << r)]);
+                qvals[(size_t)k * Q + i] = F_MUL(cum, zh_inv[i % (1u << qb)]);
             }
         }
         }
@@ -326,8 +333,8 @@ int X_PROVE_DUMMY_SALTED(const gbo_circuit_cfg *cfg, const F_T *constants_sigmas
     /* coset_ifft (prover.rs:921-925), trim_to_len + chunks (:361-374): c * qdf chunk polys of n coefficients */
     qchunks = malloc((size_t)c * qdf * n * sizeof(F_T));
     for (unsigned k = 0; k < c; k++) {
-        X_COSET_IFFT(qvals + (size_t)k * N, lgN, F_GENERATOR);
-        memcpy(qchunks + (size_t)k * qdf * n, qvals + (size_t)k * N, (size_t)qdf * n * sizeof(F_T));
+        X_COSET_IFFT(qvals + (size_t)k * Q, lg + qb, F_GENERATOR);
+        memcpy(qchunks + (size_t)k * qdf * n, qvals + (size_t)k * Q, (size_t)qdf * n * sizeof(F_T));
     }
     GBO_SCOPE("quotient values + coset_ifft");
     if (dump_quotient_chunks) memcpy(dump_quotient_chunks, qchunks, (size_t)c * qdf * n * sizeof(F_T));

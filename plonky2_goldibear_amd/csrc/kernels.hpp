@@ -7,6 +7,7 @@
 
 #include "field_traits.hpp"
 #include "gate_set.hpp"
+#include "challenge_slices.hpp"
 
 namespace gbk {
 
@@ -152,17 +153,23 @@ struct ZsParams {
 };
 template <class F>
 struct QuotientParams {
+    // rate_bits: log2 of the QUOTIENT domain's blow-up, quotient_degree_bits of prover.rs:735 (the first 2^rate_bits coset blocks of
+    // the commitments' leaf-order LDEs ARE every step-th LDE point, step = 2^(fri rate_bits - quotient_degree_bits));
+    // num_challenges: the challenges this launch computes
     u32 log_n, rate_bits, num_challenges, num_routed, num_constants /* selectors + constants */, num_selectors;
     u32 chunk, nchunks, nterms;
     u32 gate_constant, gate_pi, num_gate_consts;
     PowTab<F> w_N;   // LDE domain generator powers
     const typename F::T* l0;  // [N] L_0 on the LDE domain, leaf order (l0_table)
     u32 ext_gates;            // 1: the gate terms are already in qv (gate_constraints); 0: the dummy gate set, evaluated inline
+    u32 stride_bits;          // log2 of a column's length in cs / wires / zs: log_n + the FRI rate_bits
+    u32 k0, total_challenges; // a slice [k0, k0 + num_challenges) of total_challenges (sliced launches only; else 0, num_challenges)
 };
 template <class F>
 struct GateParams {
-    u32 log_n, rate_bits, num_challenges, nterms, t0 /* index of the first gate term */;
+    u32 log_n, rate_bits /* of the quotient domain, as QuotientParams */, num_challenges, nterms, t0 /* index of the first gate term */;
     gates::GateSet gs;
+    u32 stride_bits;   // log2 of a column's length in cs / wires
 };
 template <class F>
 struct PolyGroups {
@@ -180,12 +187,13 @@ template <class F>
 void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, const typename F::T* sigma, const typename F::T* k_is,
                          const typename F::T* betas, const typename F::T* gammas, typename F::T* q_tmp, typename F::T* zloc_tmp,
                          typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st);
-// false if (chunk, num_challenges) has no compiled specialisation (see quotient_shape_supported)
+// false if (chunk, num_challenges) cannot be run (see quotient_shape_supported); challenge counts without a specialisation of
+// their own run as slices of compiled widths (the uniforms are laid out for the total either way)
 template <class F>
 bool quotient_values(const QuotientParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* zs,
                      const typename F::T* uniforms, typename F::T* qv, hipStream_t st);
 bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges);
-// qv <- the alpha-folded gate constraints of a general gate set (kernels_gates.hip); false if num_challenges has no instance
+// qv <- the alpha-folded gate constraints of a general gate set (kernels_gates.hip), any num_challenges <= MAX_CHALLENGES (slices)
 template <class F>
 bool gate_constraints(const GateParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* apow,
                       const typename F::T* pi_hash, typename F::T* qv, hipStream_t st);

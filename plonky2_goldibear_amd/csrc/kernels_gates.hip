@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void k_gate_constraints(GateParams<F> p, const
     typedef typename F::T T;
     typedef gates::BaseAlg<F> A;
     const u32 lgn = p.log_n, r = p.rate_bits;
-    const size_t n = (size_t)1 << lgn, N = n << r;
+    const size_t n = (size_t)1 << lgn, N = (size_t)1 << p.stride_bits;   // N: column stride of cs / wires (the FRI LDE)
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
+    if (j >= (n << r)) return;
     const u32 cidx = (u32)(j >> lgn), jl = (u32)(j & (n - 1));
     const u32 il = brev32g(jl, lgn);
     T acc[C];
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(64 * TILED_WAVES) void k_gate_constraints_tiled(Gat
     T* shc = shw + (size_t)plan.area * 64;            // [ncs][64]
     T* red = shw;                                     // [TILED_WAVES - 1][C][64] partial sums, over the wires once they are dead
     const u32 lgn = p.log_n, r = p.rate_bits;
-    const size_t n = (size_t)1 << lgn, N = n << r;
-    const size_t j0 = (size_t)blockIdx.x * 64;        // N is a multiple of 64 (the launcher checks)
+    const size_t n = (size_t)1 << lgn, N = (size_t)1 << p.stride_bits;   // N: column stride of cs / wires (the FRI LDE)
+    const size_t j0 = (size_t)blockIdx.x * 64;        // the domain n 2^r is a multiple of 64 (the launcher checks)
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (u32 idx = tid; idx < plan.nw * 64; idx += 64 * TILED_WAVES) shw[idx] = wires[(size_t)(idx >> 6) * N + j0 + (idx & 63)];
     for (u32 idx = tid; idx < plan.ncs * 64; idx += 64 * TILED_WAVES) shc[idx] = cs[(size_t)(idx >> 6) * N + j0 + (idx & 63)];
@@ -234,33 +234,49 @@ static bool has_heavy(const gates::GateSet& gs) {
         if (has_heavy(p.gs))                                                                                                  \
             hipLaunchKernelGGL((k_gate_constraints<FF, CC, gates::HEAVY_GATES>), grid, block, 0, st, p, cs, wires, apow, pi_hash, qv); \
     } while (0)
-template <>
-bool gate_constraints<GlF>(const GateParams<GlF>& p, const u64* cs, const u64* wires, const u64* apow, const u64* pi_hash, u64* qv,
-                           hipStream_t st) {
-    const size_t N = (size_t)1 << (p.log_n + p.rate_bits);
+// one launch per slice of challenges (challenge_slices, kernels.hpp): a slice [k0, k0 + w) is the same kernel on the alpha powers
+// and the qv block of challenge k0 - the gate kernels index both relative to their first challenge
+template <class F>
+static bool gate_slice(GateParams<F> p, u32 k0, u32 width, const typename F::T* cs, const typename F::T* wires, const typename F::T* apow,
+                       const typename F::T* pi_hash, typename F::T* qv, hipStream_t st) {
+    const size_t N = (size_t)1 << (p.log_n + p.rate_bits);   // points of the quotient domain
     const dim3 grid((u32)((N + 255) / 256)), block(256);
-    switch (p.num_challenges) {
-        case 1: GB_G(GlF, 1); return true;
-        case 2: GB_G(GlF, 2); return true;
-        case 3: GB_G(GlF, 3); return true;
-        case 4: GB_G(GlF, 4); return true;
-        default: return false;
+    apow += (size_t)k0 * p.nterms;
+    qv += ((size_t)k0 << p.rate_bits) << p.log_n;
+    p.num_challenges = width;
+    if constexpr (F::TAG == 0) {
+        switch (width) {
+            case 1: GB_G(F, 1); return true;
+            case 2: GB_G(F, 2); return true;
+            case 3: GB_G(F, 3); return true;
+            case 4: GB_G(F, 4); return true;
+            default: return false;
+        }
+    } else {
+        switch (width) {
+            case 4: GB_G(F, 4); return true;
+            case 5: GB_G(F, 5); return true;
+            case 6: GB_G(F, 6); return true;
+            case 7: GB_G(F, 7); return true;
+            case 8: GB_G(F, 8); return true;
+            case 9: GB_G(F, 9); return true;
+            case 10: GB_G(F, 10); return true;
+            default: return false;
+        }
     }
 }
-template <>
-bool gate_constraints<BbF>(const GateParams<BbF>& p, const u32* cs, const u32* wires, const u32* apow, const u32* pi_hash, u32* qv,
-                           hipStream_t st) {
-    const size_t N = (size_t)1 << (p.log_n + p.rate_bits);
-    const dim3 grid((u32)((N + 255) / 256)), block(256);
-    switch (p.num_challenges) {
-        case 6: GB_G(BbF, 6); return true;
-        case 7: GB_G(BbF, 7); return true;
-        case 8: GB_G(BbF, 8); return true;
-        case 9: GB_G(BbF, 9); return true;
-        case 10: GB_G(BbF, 10); return true;
-        default: return false;
-    }
+template <class F>
+bool gate_constraints(const GateParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* apow,
+                      const typename F::T* pi_hash, typename F::T* qv, hipStream_t st) {
+    u32 widths[MAX_CHALLENGES];
+    const u32 ns = challenge_slices(F::TAG, 4, p.num_challenges, widths);
+    if (!ns) return false;
+    for (u32 i = 0, k0 = 0; i < ns; k0 += widths[i], i++)
+        if (!gate_slice<F>(p, k0, widths[i], cs, wires, apow, pi_hash, qv, st)) return false;
+    return true;
 }
+template bool gate_constraints<GlF>(const GateParams<GlF>&, const u64*, const u64*, const u64*, const u64*, u64*, hipStream_t);
+template bool gate_constraints<BbF>(const GateParams<BbF>&, const u32*, const u32*, const u32*, const u32*, u32*, hipStream_t);
 #undef GB_G
 
 }  // namespace gbk

@@ -194,15 +194,19 @@ __global__ __launch_bounds__(256) void k_zs_finalize(ZsParams<F> p, const typena
 #define GB_QUOTIENT_OCC_GL 5
 #endif
 #define GB_QUOTIENT_OCC(F) (sizeof(typename F::T) == 8 ? GB_QUOTIENT_OCC_GL : 4)
-template <class F, u32 C, u32 CH>
+template <class F, u32 C, u32 CH, bool SLICE>
 __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientParams<F> p, const typename F::T* __restrict__ cs,
                                                   const typename F::T* __restrict__ wires, const typename F::T* __restrict__ zs,
                                                   const typename F::T* __restrict__ uni, typename F::T* __restrict__ qv) {
     typedef typename F::T T;
     const u32 lgn = p.log_n, r = p.rate_bits;
-    const size_t n = (size_t)1 << lgn, N = n << r;
+    const size_t n = (size_t)1 << lgn, N = (size_t)1 << p.stride_bits;   // N: column stride of cs / wires / zs (the FRI LDE)
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
+    if (j >= (n << r)) return;
+    // SLICE: this launch owns the alpha-fold accumulators of challenges [k0, k0 + C) of CT.  reduce_with_powers_multi
+    // (plonk_common.rs:105-122) folds EVERY challenge's Z and partial-product terms into every alpha's sum, so the terms of all CT
+    // challenges are generated here, C at a time; the uniforms, the zs columns and the term indices are laid out for all CT.
+    const u32 CT = SLICE ? p.total_challenges : C, k0 = SLICE ? p.k0 : 0;
     const u32 cidx = (u32)(j >> lgn), jl = (u32)(j & (n - 1));
     const u32 il = brev32(jl, lgn);
     const u32 imod = brev32(cidx, r);
@@ -214,12 +218,13 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
     // betas and bk = beta * k_j in the field's CONSTANT form (F::cform / F::mulc: Montgomery for Goldilocks)
     const u32 nr = p.num_routed, nterms = p.nterms, R = 1u << r;
     const T* betas = uni;
-    const T* gammas = uni + C;
-    const T* bk = gammas + C;
-    const T* zh = bk + (size_t)C * nr + (size_t)C * nterms;   // behind the plain alpha powers (read by the gate kernels)
+    const T* gammas = uni + CT;
+    const T* bk = uni + 2 * CT;
+    const T* zh = uni + 2 * CT + (size_t)CT * nr + (size_t)CT * nterms;   // behind the plain alpha powers (read by the gate kernels)
     const T* zh_inv = zh + R;
     const T* pi_hash = zh_inv + R;
-    const T* apow = pi_hash + F::H;                           // [c][nterms] alpha powers in constant form (F::mulc)
+    const T* apow = pi_hash + F::H + (size_t)k0 * nterms;     // [c][nterms] alpha powers in constant form (F::mulc), from challenge k0
+    if (SLICE) qv += ((size_t)k0 << r) * n;
 
     // the alpha fold: acc[k2] = sum over the constraint terms of term_t alpha_k2^t, as F::Acc sums (BabyBear keeps them unreduced)
     typename F::Acc acc[C];
@@ -231,17 +236,21 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
         if (C & 1) F::acc_mac(acc[C - 1], term, apow[(C - 1) * nterms + tt]);
     };
     u32 t = 0;
-    // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61); L_0 on the LDE domain is a per-circuit table (k_l0_table)
-    const T l0 = p.l0[j];
+    const T l0 = p.l0[j];   // L_0 on the quotient domain is a per-circuit table (k_l0_table)
+    const u32 num_prods = p.nchunks - 1;
+    for (u32 kt0 = 0; kt0 < CT; kt0 += C) {   // one pass unless SLICE
+    // the challenge whose terms slot k generates: a slot past CT recomputes the last challenge and is not folded
+    auto kt = [&](u32 k) -> u32 { return SLICE ? min(kt0 + k, CT - 1) : k; };
+    auto is_live = [&](u32 k) -> bool { return !SLICE || kt0 + k < CT; };
+    // L_0(x) (Z(x) - 1): eval_l_0 (zero_poly_coset.rs:58-61); term index = the challenge
     T zk[C];
 #pragma unroll
-    for (u32 k = 0; k < C; k++) zk[k] = zs[(size_t)k * N + j];
+    for (u32 k = 0; k < C; k++) zk[k] = zs[(size_t)kt(k) * N + j];
 #pragma unroll
-    for (u32 k = 0; k < C; k++, t++) {
-        fold(F::mul(l0, F::sub(zk[k], F::one())), t);
+    for (u32 k = 0; k < C; k++) {
+        if (is_live(k)) fold(F::mul(l0, F::sub(zk[k], F::one())), kt(k));
     }
-    // partial-product checks (util/partial_products.rs:53-77); term index = C + k * nchunks + m
-    const u32 num_prods = p.nchunks - 1;
+    // partial-product checks (util/partial_products.rs:53-77); term index = CT + challenge * nchunks + m
     T prev[C];
 #pragma unroll
     for (u32 k = 0; k < C; k++) prev[k] = zk[k];
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
         T next[C];
 #pragma unroll
         for (u32 k = 0; k < C; k++)
-            next[k] = m == num_prods ? zs[(size_t)k * N + jn] : zs[((size_t)C + (size_t)k * num_prods + m) * N + j];
+            next[k] = m == num_prods ? zs[(size_t)kt(k) * N + jn] : zs[((size_t)CT + (size_t)kt(k) * num_prods + m) * N + j];
         T np[C], dp[C];
         const u32 live = min(CH, nr - w0);  // wires in this chunk (uniform); only the tail chunk has fewer than CH
 #pragma unroll
@@ -267,9 +276,9 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
             for (u32 q = 0; q < CH; q++) {
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
-                    const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
-                    T num = F::add_lazy(wg, F::mulc(x, bk[k * nr + w0 + q]));
-                    T den = F::add_lazy(wg, F::mulc(sg[q], betas[k]));
+                    const T wg = F::add(wv[q], gammas[kt(k)]);  // shared by numerator and denominator
+                    T num = F::add_lazy(wg, F::mulc(x, bk[kt(k) * nr + w0 + q]));
+                    T den = F::add_lazy(wg, F::mulc(sg[q], betas[kt(k)]));
                     np[k] = F::mul_chain(np[k], num);  // product chains: only multiplied again
                     dp[k] = F::mul_chain(dp[k], den);
                 }
@@ -280,9 +289,9 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
                 if (q >= live) continue;
 #pragma unroll
                 for (u32 k = 0; k < C; k++) {
-                    const T wg = F::add(wv[q], gammas[k]);  // shared by numerator and denominator
-                    T num = F::add_lazy(wg, F::mulc(x, bk[k * nr + w0 + q]));
-                    T den = F::add_lazy(wg, F::mulc(sg[q], betas[k]));
+                    const T wg = F::add(wv[q], gammas[kt(k)]);  // shared by numerator and denominator
+                    T num = F::add_lazy(wg, F::mulc(x, bk[kt(k) * nr + w0 + q]));
+                    T den = F::add_lazy(wg, F::mulc(sg[q], betas[kt(k)]));
                     np[k] = F::mul_chain(np[k], num);  // product chains: only multiplied again
                     dp[k] = F::mul_chain(dp[k], den);
                 }
@@ -291,11 +300,12 @@ __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientPa
 #pragma unroll
         for (u32 k = 0; k < C; k++) {
             const T term = F::sub(F::mul(prev[k], np[k]), F::mul(next[k], dp[k]));
-            fold(term, C + k * p.nchunks + m);
+            if (is_live(k)) fold(term, CT + kt(k) * p.nchunks + m);
             prev[k] = next[k];
         }
     }
-    t = C + C * p.nchunks;
+    }
+    t = CT + CT * p.nchunks;
     // gate constraints: filter * unfiltered, summed per constraint index (vanishing_poly.rs:741-774,
     // gates/gate.rs:188-215,391-404).  One selector group {0,1,2}; no UNUSED factor (single selector).
     // PublicInputGate<H> has H constraints, ConstantGate num_gate_consts <= H.
@@ -693,48 +703,79 @@ void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, con
                        nb1024, out);
 }
 
-#define GB_Q(FF, CC, HH) hipLaunchKernelGGL((k_quotient<FF, CC, HH>), grid, block, 0, st, p, cs, wires, zs, uniforms, qv)
-template <>
-bool quotient_values<GlF>(const QuotientParams<GlF>& p, const u64* cs, const u64* wires, const u64* zs, const u64* uniforms, u64* qv,
-                          hipStream_t st) {
-    const size_t N = (size_t)1 << (p.log_n + p.rate_bits);
-    const dim3 grid(nblk(N, 256)), block(256);
-    if (p.chunk == 8) {
-        switch (p.num_challenges) {
-            case 1: GB_Q(GlF, 1, 8); return true;
-            case 2: GB_Q(GlF, 2, 8); return true;
-            case 3: GB_Q(GlF, 3, 8); return true;
-            case 4: GB_Q(GlF, 4, 8); return true;
-            default: break;
+// A challenge count with no specialisation of its own runs as slices of compiled widths <= WMAX (balanced: every slice
+// floor or ceil of count / slices); the hot counts (Goldilocks 1..4, BabyBear 6..10) are one plain launch, as before.
+#define GB_Q(FF, CC, HH, SL) hipLaunchKernelGGL((k_quotient<FF, CC, HH, SL>), grid, block, 0, st, q, cs, wires, zs, uniforms, qv)
+template <class F, u32 CH>
+static bool quotient_slice(QuotientParams<F> q, u32 width, bool slice, const typename F::T* cs, const typename F::T* wires,
+                           const typename F::T* zs, const typename F::T* uniforms, typename F::T* qv, dim3 grid, dim3 block, hipStream_t st) {
+    q.num_challenges = width;
+    if constexpr (F::TAG == 0) {
+        if (slice) switch (width) {
+            case 1: GB_Q(F, 1, CH, true); return true;
+            case 2: GB_Q(F, 2, CH, true); return true;
+            case 3: if constexpr (CH == 8) { GB_Q(F, 3, CH, true); return true; } else return false;
+            case 4: if constexpr (CH == 8) { GB_Q(F, 4, CH, true); return true; } else return false;
+            default: return false;
         }
-    }
-    if (p.chunk == 16 && p.num_challenges <= 2) {
-        if (p.num_challenges == 1) GB_Q(GlF, 1, 16); else GB_Q(GlF, 2, 16);
-        return true;
-    }
-    return false;
-}
-// BabyBear: (31 - degree_bits) * c >= 100 (circuit_builder.rs:1190-1192) needs c = 6 .. 10 for degree_bits <= 20
-template <>
-bool quotient_values<BbF>(const QuotientParams<BbF>& p, const u32* cs, const u32* wires, const u32* zs, const u32* uniforms, u32* qv,
-                          hipStream_t st) {
-    const size_t N = (size_t)1 << (p.log_n + p.rate_bits);
-    const dim3 grid(nblk(N, 256)), block(256);
-    if (p.chunk != 8) return false;
-    switch (p.num_challenges) {
-        case 6: GB_Q(BbF, 6, 8); return true;
-        case 7: GB_Q(BbF, 7, 8); return true;
-        case 8: GB_Q(BbF, 8, 8); return true;
-        case 9: GB_Q(BbF, 9, 8); return true;
-        case 10: GB_Q(BbF, 10, 8); return true;
-        default: return false;
+        switch (width) {
+            case 1: GB_Q(F, 1, CH, false); return true;
+            case 2: GB_Q(F, 2, CH, false); return true;
+            case 3: if constexpr (CH == 8) { GB_Q(F, 3, CH, false); return true; } else return false;
+            case 4: if constexpr (CH == 8) { GB_Q(F, 4, CH, false); return true; } else return false;
+            default: return false;
+        }
+    } else {
+        if (slice) switch (width) {
+            case 5: GB_Q(F, 5, CH, true); return true;
+            case 6: GB_Q(F, 6, CH, true); return true;
+            case 7: GB_Q(F, 7, CH, true); return true;
+            case 8: GB_Q(F, 8, CH, true); return true;
+            default: return false;
+        }
+        switch (width) {
+            case 4: GB_Q(F, 4, CH, false); return true;
+            case 5: GB_Q(F, 5, CH, false); return true;
+            case 6: GB_Q(F, 6, CH, false); return true;
+            case 7: GB_Q(F, 7, CH, false); return true;
+            case 8: GB_Q(F, 8, CH, false); return true;
+            case 9: GB_Q(F, 9, CH, false); return true;
+            case 10: GB_Q(F, 10, CH, false); return true;
+            default: return false;
+        }
     }
 }
 #undef GB_Q
+template <class F>
+bool quotient_values(const QuotientParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* zs,
+                     const typename F::T* uniforms, typename F::T* qv, hipStream_t st) {
+    const size_t NQ = (size_t)1 << (p.log_n + p.rate_bits);
+    const dim3 grid(nblk(NQ, 256)), block(256);
+    u32 widths[MAX_CHALLENGES];
+    const u32 ns = challenge_slices(F::TAG, p.chunk == 8 ? 4 : 2, p.num_challenges, widths);
+    if (!ns || (p.chunk != 8 && !(F::TAG == 0 && p.chunk == 16))) return false;
+    QuotientParams<F> q = p;
+    q.total_challenges = p.num_challenges;
+    q.k0 = 0;
+    for (u32 i = 0; i < ns; q.k0 += widths[i], i++) {
+        bool ok;
+        if constexpr (F::TAG == 0)
+            ok = p.chunk == 8 ? quotient_slice<F, 8>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st)
+                              : quotient_slice<F, 16>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st);
+        else
+            ok = quotient_slice<F, 8>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st);
+        if (!ok) return false;
+    }
+    return true;
+}
+template bool quotient_values<GlF>(const QuotientParams<GlF>&, const u64*, const u64*, const u64*, const u64*, u64*, hipStream_t);
+template bool quotient_values<BbF>(const QuotientParams<BbF>&, const u32*, const u32*, const u32*, const u32*, u32*, hipStream_t);
+// BabyBear: (31 - degree_bits) * c >= 100 (circuit_builder.rs:1190-1192) needs c >= 4; Goldilocks c >= 2
 bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges) {
-    if (field == GlF::TAG)
-        return (chunk == 8 && num_challenges >= 1 && num_challenges <= 4) || (chunk == 16 && num_challenges >= 1 && num_challenges <= 2);
-    return chunk == 8 && num_challenges >= 6 && num_challenges <= 10;
+    u32 widths[MAX_CHALLENGES];
+    if (num_challenges == 0 || num_challenges > MAX_CHALLENGES) return false;
+    if (chunk != 8 && !(field == GlF::TAG && chunk == 16)) return false;
+    return challenge_slices(field, chunk == 8 ? 4 : 2, num_challenges, widths) != 0;
 }
 
 template <class F>

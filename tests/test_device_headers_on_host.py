@@ -32,3 +32,15 @@ def test_bb_wide_accumulators_match_montgomery_sums(tmp_path):
     out = subprocess.run([str(exe), "3000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
+
+
+def test_challenge_slices_cover_every_count(tmp_path):
+    """csrc/challenge_slices.hpp: how a num_challenges without a compiled kernel width is split into launches"""
+    exe = tmp_path / "challenge_slices"
+    shim = os.path.join(ROOT, "tests", "host_shim")
+    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "plonky2_goldibear_amd", "csrc"), "-o", str(exe),
+           os.path.join(shim, "challenge_slices.cpp")]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout

@@ -1,0 +1,201 @@
+"""The configuration range of prove() beyond the stock configs (round 5; VERDICT r4 "missing" #5 and the reference's own
+size-optimised recursion configs):
+
+* rate_bits above log2(quotient_degree_factor) - compute_quotient_polys then works on every step-th point of the commitments'
+  LDE (plonk/prover.rs:735-749); the reference's recursion test proves with rate_bits 7 and 8 at quotient_degree_factor 8
+  (recursion/recursive_verifier.rs:573-611).  In the leaf-order layout those points are the first 2^3 coset blocks of a column.
+* any num_challenges up to 16 for both fields (circuit_data.rs:80; BabyBear needs >= 4 for (31 - degree_bits) c >= 100): counts
+  without a compiled kernel width run as slices.
+* FRI arities up to 2^8 (fri/reduction_strategies.rs:11-56 takes any).
+
+Parity bar as everywhere: proof BYTES identical to the CPU oracle prover (whose step / slices / arities are plain loops), accepted
+by gb_verify and by the oracle verifier (pinned by the reference's regression proof).  -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import plonk_dummy as D
+from oracle.fields import BB, GL
+from plonky2_goldibear_amd import GpuContext, PolynomialBatch, fri_params as FP, native as N
+from plonky2_goldibear_amd.prover import CircuitData
+
+from circuits import oracle_circuit, recursion_gates_circuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _field(name):
+    return (GL, N.GB_GOLDILOCKS, D.CircuitConfig) if name == "goldilocks" else (BB, N.GB_BABYBEAR, D.CircuitConfig.babybear)
+
+
+def _gpu(ctx, circ, tag, bits=None):
+    cfg = circ.cfg
+    return CircuitData(ctx, circ.degree_bits, circ.constants_sigmas, circ.k_is, num_wires=cfg.num_wires,
+                       num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants, num_challenges=cfg.num_challenges,
+                       max_quotient_degree_factor=cfg.max_quotient_degree_factor, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height,
+                       proof_of_work_bits=cfg.proof_of_work_bits, num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits,
+                       final_poly_bits=cfg.final_poly_bits, gate_constant=circ.GATE_CONSTANT, gate_pi=circ.GATE_PI, field=tag,
+                       reduction_arity_bits=bits)
+
+
+def _prove_and_compare(ctx, circ, tag, bits=None, seed=1):
+    gpu = _gpu(ctx, circ, tag, bits)
+    assert (gpu.circuit_digest == circ.circuit_digest).all()          # the oracle's own commitment, not the GPU's cap
+    assert (gpu.constants_sigmas_cap == circ.constants_sigmas_cap).all()
+    for attempt in range(6):   # BabyBear: a zero denominator of the permutation argument is a natural event; next witness
+        w = circ.witness(seed=seed + 100 * attempt)
+        try:
+            want, _ = D.prove_cpu(circ, w)
+        except RuntimeError as e:
+            assert "rc=1" in str(e)
+            continue
+        got = gpu.prove_once(w) if hasattr(gpu, "prove_once") else gpu.prove(w)
+        assert len(got) == len(want) and got == want
+        assert gpu.verify(got) and D.verify(circ, got)
+        comp = gpu.compress(got)
+        assert gpu.decompress(comp) == got and gpu.verify_compressed(comp)
+        gpu.free()
+        return got
+    raise AssertionError("six witnesses in a row met a zero denominator")
+
+
+# ---------------------------------------------------------------------------------------------- commitments at rates 2^5 .. 2^8
+@pytest.mark.parametrize("field_name", ["goldilocks", "babybear"])
+@pytest.mark.parametrize("log_n,ncols,rate_bits,cap_height", [(0, 2, 5, 3), (4, 3, 5, 4), (9, 2, 6, 4), (12, 3, 7, 4), (12, 2, 8, 0),
+                                                               (6, 5, 8, 4), (13, 2, 7, 4), (16, 1, 5, 4)])
+def test_from_values_at_high_rates(ctx, field_name, log_n, ncols, rate_bits, cap_height):
+    F, tag, _ = _field(field_name)
+    vals = F.fill(1000 + 31 * log_n + rate_bits, ncols << log_n).reshape(ncols, -1)
+    gpu = PolynomialBatch.from_values(ctx, vals, rate_bits, cap_height, field=tag)
+    cpu = F.mod.PolynomialBatch.from_values(vals, rate_bits, cap_height)
+    assert (gpu.merkle_tree.cap == cpu.cap).all()
+    assert (gpu.polynomials == cpu.polynomials).all()
+    assert (gpu.merkle_tree.leaves == cpu.leaves).all()
+    if cpu.digests.size:
+        assert (gpu.merkle_tree.digests == cpu.digests).all()
+    step = 1 << (rate_bits - 3)   # the prover's step at quotient_degree_factor 8
+    for i in (0, 1, 5, (8 << log_n) - 1):
+        assert (gpu.get_lde_values(i, step) == cpu.get_lde_values(i, step)).all()
+    gpu.free()
+
+
+# ---------------------------------------------------------------------------------------------- step != 1
+@pytest.mark.parametrize("field_name,degree_bits,rate_bits,qdf", [
+    ("goldilocks", 5, 4, 8), ("goldilocks", 5, 5, 8), ("goldilocks", 8, 6, 8), ("goldilocks", 12, 7, 8), ("goldilocks", 10, 8, 8),
+    ("goldilocks", 9, 5, 16), ("goldilocks", 13, 4, 8),
+    ("babybear", 5, 4, 8), ("babybear", 6, 5, 8), ("babybear", 9, 6, 8), ("babybear", 12, 7, 8), ("babybear", 10, 8, 8),
+])
+def test_proof_bytes_with_rate_above_the_quotient_degree(ctx, field_name, degree_bits, rate_bits, qdf):
+    F, tag, mk = _field(field_name)
+    nch = 2 if F is GL else 6
+    circ = D.DummyCircuit(degree_bits, mk(num_challenges=nch, rate_bits=rate_bits, max_quotient_degree_factor=qdf), F=F)
+    _prove_and_compare(ctx, circ, tag, seed=degree_bits + rate_bits)
+
+
+def test_the_size_optimised_recursion_configs(ctx):
+    """recursion/recursive_verifier.rs:573-611: `high_rate_config` (rate_bits 7, 12 query rounds) and `final_config` (37 routed
+    wires, rate_bits 8, cap_height 0, 20 proof-of-work bits, FriReductionStrategy::MinSize(None), 10 query rounds), here on the
+    2^12-row dummy circuit - the degree the reference's test asserts for both."""
+    high = D.CircuitConfig(num_challenges=2, rate_bits=7, proof_of_work_bits=16, num_query_rounds=12)
+    circ = D.DummyCircuit(12, high, F=GL)
+    _prove_and_compare(ctx, circ, N.GB_GOLDILOCKS, seed=7)
+    final = D.CircuitConfig(num_challenges=2, num_routed_wires=37, rate_bits=8, cap_height=0, proof_of_work_bits=20, num_query_rounds=10)
+    bits = FP.reduction_arity_bits(("min_size", None), 12, 8, 0, 10)
+    circ = D.DummyCircuit(12, final, F=GL)
+    circ.reduction_arity_bits = list(bits)
+    proof = _prove_and_compare(ctx, circ, N.GB_GOLDILOCKS, bits=bits, seed=8)
+    assert len(proof) < 100_000
+
+
+@pytest.mark.parametrize("field,rate_bits,queries", [(N.GB_GOLDILOCKS, 7, 12), (N.GB_BABYBEAR, 7, 12), (N.GB_GOLDILOCKS, 5, 17)])
+def test_recursion_gate_set_with_rate_above_the_quotient_degree(ctx, field, rate_bits, queries):
+    """every gate kind of the recursion circuits (csrc/gates.hpp, both gate kernels) on the subsampled quotient domain"""
+    b, pw, rows = recursion_gates_circuit(field, seed=11, public_inputs=True, rate_bits=rate_bits, num_query_rounds=queries)
+    c = b.build(ctx)
+    w, pis = c.generate_witness(pw)
+    proof = c.data.prove(w, pis, random_wire=(c.random_wire[1], c.random_wire[0]))
+    assert c.data.verify(proof)
+    oc = oracle_circuit(c, len(pis))
+    assert (c.data.circuit_digest == oc.circuit_digest).all()
+    dump = {}
+    want, _ = D.prove_cpu(oc, w, pis, dump=dump)
+    assert proof == want
+    assert (c.data.constants_sigmas_cap == D.prove_cpu.last_cs_cap).all()
+    assert D.verify(oc, proof)
+    c.data.free()
+
+
+# ---------------------------------------------------------------------------------------------- num_challenges
+@pytest.mark.parametrize("field_name,degree_bits,num_challenges", [
+    ("goldilocks", 6, 5), ("goldilocks", 9, 6), ("goldilocks", 7, 7), ("goldilocks", 12, 9), ("goldilocks", 5, 16),
+    ("babybear", 5, 4), ("babybear", 6, 4), ("babybear", 10, 5), ("babybear", 8, 11), ("babybear", 12, 13), ("babybear", 5, 16),
+])
+def test_proof_bytes_with_other_challenge_counts(ctx, field_name, degree_bits, num_challenges):
+    F, tag, mk = _field(field_name)
+    circ = D.DummyCircuit(degree_bits, mk(num_challenges=num_challenges), F=F)
+    _prove_and_compare(ctx, circ, tag, seed=degree_bits + num_challenges)
+
+
+def test_goldilocks_degree_factor_16_with_sliced_challenges(ctx):
+    circ = D.DummyCircuit(8, D.CircuitConfig(num_challenges=5, rate_bits=4, max_quotient_degree_factor=16), F=GL)
+    _prove_and_compare(ctx, circ, N.GB_GOLDILOCKS, seed=3)
+
+
+@pytest.mark.parametrize("field,num_challenges", [(N.GB_GOLDILOCKS, 5), (N.GB_GOLDILOCKS, 7), (N.GB_BABYBEAR, 4), (N.GB_BABYBEAR, 5),
+                                                  (N.GB_BABYBEAR, 11)])
+def test_recursion_gate_set_with_other_challenge_counts(ctx, field, num_challenges):
+    """the gate kernels' slices: [k0, k0 + w) of the challenges on the alpha powers / quotient block of challenge k0"""
+    b, pw, rows = recursion_gates_circuit(field, seed=5, public_inputs=True, num_challenges=num_challenges)
+    c = b.build(ctx)
+    w, pis = c.generate_witness(pw)
+    proof = c.data.prove(w, pis, random_wire=(c.random_wire[1], c.random_wire[0]))
+    assert c.data.verify(proof)
+    oc = oracle_circuit(c, len(pis))
+    want, _ = D.prove_cpu(oc, w, pis)
+    assert proof == want
+    assert (c.data.constants_sigmas_cap == D.prove_cpu.last_cs_cap).all()
+    assert D.verify(oc, proof)
+    c.data.free()
+
+
+def test_challenge_counts_that_cannot_be_sound_are_rejected(ctx):
+    circ = D.DummyCircuit(5, D.CircuitConfig.babybear(3), check_security=False, F=BB)
+    with pytest.raises(N.GoldibearError) as e:
+        _gpu(ctx, circ, N.GB_BABYBEAR)
+    assert e.value.status == N.GB_ERR_INVALID and "num_challenges" in str(e.value)
+    circ = D.DummyCircuit(5, D.CircuitConfig(num_challenges=17), F=GL)
+    with pytest.raises(N.GoldibearError) as e:
+        _gpu(ctx, circ, N.GB_GOLDILOCKS)
+    assert e.value.status == N.GB_ERR_UNSUPPORTED
+    circ = D.DummyCircuit(5, D.CircuitConfig(num_challenges=2, rate_bits=2), F=GL)   # quotient degree 8 above the rate
+    with pytest.raises(N.GoldibearError) as e:
+        _gpu(ctx, circ, N.GB_GOLDILOCKS)
+    assert e.value.status == N.GB_ERR_INVALID and "degree higher than the rate" in str(e.value)
+
+
+# ---------------------------------------------------------------------------------------------- FRI arities up to 2^8
+@pytest.mark.parametrize("field_name,degree_bits,arity_bits,final_poly_bits", [
+    ("goldilocks", 12, 5, 2), ("goldilocks", 13, 6, 1), ("goldilocks", 14, 7, 0), ("goldilocks", 16, 8, 0), ("goldilocks", 9, 8, 0),
+    ("babybear", 12, 5, 2), ("babybear", 13, 6, 1), ("babybear", 14, 7, 0), ("babybear", 16, 8, 0),
+])
+def test_proof_bytes_with_constant_arities_above_16(ctx, field_name, degree_bits, arity_bits, final_poly_bits):
+    F, tag, mk = _field(field_name)
+    nch = (2 if degree_bits <= 14 else 3) if F is GL else (6 if degree_bits <= 14 else 7)
+    circ = D.DummyCircuit(degree_bits, mk(num_challenges=nch, arity_bits=arity_bits, final_poly_bits=final_poly_bits), F=F)
+    assert circ.reduction_arity_bits and circ.reduction_arity_bits[0] == arity_bits
+    _prove_and_compare(ctx, circ, tag, seed=degree_bits)
+
+
+@pytest.mark.parametrize("field_name,degree_bits,bits", [("goldilocks", 12, [8, 3]), ("goldilocks", 13, [5, 6, 1]),
+                                                         ("babybear", 12, [7, 4]), ("babybear", 11, [6, 1, 3])])
+def test_proof_bytes_with_fixed_lists_of_wide_arities(ctx, field_name, degree_bits, bits):
+    F, tag, mk = _field(field_name)
+    circ = D.DummyCircuit(degree_bits, mk(num_challenges=2 if F is GL else 6), F=F)
+    circ.reduction_arity_bits = list(bits)
+    _prove_and_compare(ctx, circ, tag, bits=bits, seed=degree_bits)

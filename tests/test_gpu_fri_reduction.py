@@ -66,7 +66,7 @@ def test_invalid_lists_are_rejected(ctx):
     circ = D.DummyCircuit(8, D.CircuitConfig(num_challenges=2), F=GL)
     gpu = _gpu(ctx, circ, N.GB_GOLDILOCKS, None)
     stock = gpu.reduction_arity_bits
-    for bad in ([5], [0, 1], [4, 4, 4], [4] * 33):     # wider than the FRI kernels take / zero / past degree_bits (and below the cap) / too many
+    for bad in ([9], [0, 1], [4, 4, 4], [4] * 33):     # wider than 2^8 / zero / past degree_bits (and below the cap) / too many
         with pytest.raises(N.GoldibearError) as e:
             gpu.set_reduction_arity_bits(bad)
         assert e.value.status == N.GB_ERR_INVALID

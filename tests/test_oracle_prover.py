@@ -56,3 +56,26 @@ def test_witness_seed_changes_proof_but_not_digest():
     assert p0 != p1
     assert D.verify(circ, p0) and D.verify(circ, p1)
     assert np.array_equal(circ.circuit_digest, D.DummyCircuit(4).circuit_digest)
+
+
+@pytest.mark.parametrize("field_name,degree_bits,rate_bits,qdf", [("goldilocks", 5, 4, 8), ("goldilocks", 6, 7, 8), ("goldilocks", 7, 8, 8),
+                                                                  ("goldilocks", 6, 5, 16), ("babybear", 5, 5, 8), ("babybear", 7, 8, 8)])
+def test_rate_above_the_quotient_degree(field_name, degree_bits, rate_bits, qdf):
+    """step = 2^(rate_bits - log2 quotient_degree_factor) > 1 (plonk/prover.rs:735-749; the reference's size-optimised recursion
+    proofs run at rate_bits 7 and 8): the quotient computed on every step-th LDE point satisfies the verifier's identity at zeta,
+    with the verifier that the reference's own regression proof pins."""
+    from oracle.fields import BB, GL
+    F = GL if field_name == "goldilocks" else BB
+    mk = D.CircuitConfig if F is GL else D.CircuitConfig.babybear
+    circ = D.DummyCircuit(degree_bits, mk(rate_bits=rate_bits, max_quotient_degree_factor=qdf), F=F)
+    proof, _ = D.prove_cpu(circ, circ.witness(seed=rate_bits))
+    stats = {}
+    assert D.verify(circ, proof, stats)
+    pr, pis = V.read_proof_with_pis(proof, circ.common_data(), F)
+    assert len(pr["openings"]["quotient_polys"]) == circ.cfg.num_challenges * qdf
+    # a constraint violation is still caught on the subsampled domain
+    w = circ.witness(seed=rate_bits)
+    w[0, circ.pi_row] = 5
+    bad, _ = D.prove_cpu(circ, w)
+    with pytest.raises(AssertionError):
+        D.verify(circ, bad)
