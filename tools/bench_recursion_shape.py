@@ -4,7 +4,9 @@ standard_recursion_config_gl (num_challenges 2; 3 above 2^14 rows).  One row of 
 evaluates every gate of the set at every LDE point whatever sits in the rows, so the time is that of a full recursion circuit of
 the same size; the proof is verified.  The reference's one published number is for this shape: "about 170 ms" for a recursion
 proof (~2^12 rows) on a MacBook Pro (plonky2/README.md:5).
-usage: python tools/bench_recursion_shape.py [--babybear] [--inflight K] [log_n ...]
+usage: python tools/bench_recursion_shape.py [--babybear] [--high-rate] [--inflight K] [log_n ...]
+--high-rate: the `high_rate_config` of the reference's size-optimised recursion test (recursion/recursive_verifier.rs:573-583: rate_bits 7,
+12 query rounds; the quotient then runs on every 16th LDE point) instead of the stock rate_bits 3 / 28 query rounds.
 --inflight K: K independent circuits proved concurrently, one context (= one HIP stream) and one host thread each - what an
 aggregation layer with many recursion proofs to make does; a proof of this size cannot fill the GPU on its own."""
 import json
@@ -27,7 +29,7 @@ def many_in_flight(log_n, k):
     lanes = []
     for i in range(k):
         ctx = GpuContext(0)
-        b, pw, _ = recursion_gates_circuit(FIELD, seed=100 + i, num_challenges=_challenges(log_n))
+        b, pw, _ = recursion_gates_circuit(FIELD, seed=100 + i, num_challenges=_challenges(log_n), **CFG_KW)
         while b.num_gates() < (1 << log_n) - 8:
             b.add_gate(NoopGate())
         c = b.build(ctx)
@@ -59,6 +61,7 @@ def many_in_flight(log_n, k):
         ctx.close()
 
 
+CFG_KW = {}      # --high-rate: rate_bits 7, 12 query rounds
 FIELD = 0        # GB_GOLDILOCKS; --babybear: recursion_config_bb_narrow, 6 challenges (8 above 2^14 rows)
 VIEW = np.int64
 
@@ -74,6 +77,9 @@ def main():
     args = sys.argv[1:]
     if args and args[0] == "--babybear":
         FIELD, VIEW, args = 1, np.int32, args[1:]
+    if args and args[0] == "--high-rate":
+        CFG_KW.update(rate_bits=7, num_query_rounds=12)
+        args = args[1:]
     if args and args[0] == "--inflight":
         k = int(args[1])
         for log_n in [int(a) for a in args[2:]] or [12]:
@@ -83,7 +89,7 @@ def main():
     ctx.set_profiling(True)
     for log_n in [int(a) for a in args] or [12, 13, 14]:
         # circuit_builder.rs:1190-1192: (64 - degree_bits) * num_challenges >= 100 needs a third challenge above 2^14 rows
-        b, pw, _ = recursion_gates_circuit(FIELD, seed=log_n, num_challenges=_challenges(log_n))
+        b, pw, _ = recursion_gates_circuit(FIELD, seed=log_n, num_challenges=_challenges(log_n), **CFG_KW)
         while b.num_gates() < (1 << log_n) - 8:
             b.add_gate(NoopGate())
         c = b.build(ctx)
@@ -108,7 +114,7 @@ def main():
             ms, cnt = ctx.scope_ms(name)
             scopes[name] = round(ms / 20, 3)
         print(json.dumps({"workload": "recursion-shaped circuit, %d gates in the set" % len(c.gate_table),
-                          "field": "babybear" if FIELD else "goldilocks", "log_n": log_n,
+                          "field": "babybear" if FIELD else "goldilocks", "log_n": log_n, "rate_bits": CFG_KW.get("rate_bits", 3),
                           "prove_ms_median": round(1e3 * float(np.median(ts)), 3), "prove_ms_min": round(1e3 * min(ts), 3),
                           "proofs_per_s": round(1.0 / float(np.median(ts)), 1), "proof_bytes": len(proof), "verified": True,
                           "scopes_ms_per_proof": scopes}), flush=True)
