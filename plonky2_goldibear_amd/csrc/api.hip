@@ -613,8 +613,17 @@ struct Stager {
                     return drain();
                 c = e;
             }
-            if (!slot_done[s] && hipEventCreateWithFlags(&slot_done[s], hipEventDisableTiming) != hipSuccess) { slot_done[s] = nullptr; return false; }
-            if (hipEventRecord(slot_done[s], copy_stream) != hipSuccess) return false;
+            // no event to guard the slot with: the copies out of it are in flight, so wait for them here before anybody may write
+            // into the slot again (the caller falls back to plain copies for the rest)
+            if (!slot_done[s] && hipEventCreateWithFlags(&slot_done[s], hipEventDisableTiming) != hipSuccess) {
+                slot_done[s] = nullptr;
+                (void)hipStreamSynchronize(copy_stream);
+                return false;
+            }
+            if (hipEventRecord(slot_done[s], copy_stream) != hipSuccess) {
+                (void)hipStreamSynchronize(copy_stream);
+                return false;
+            }
             slot_used[s] = true;
         }
         return true;
