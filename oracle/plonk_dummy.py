@@ -43,10 +43,15 @@ class CircuitConfig:
 
 
 def reduction_arity_bits(cfg, degree_bits):
-    """fri/reduction_strategies.rs:44-56 ConstantArityBits"""
+    """fri/reduction_strategies.rs:39-50 ConstantArityBits, with its assert (the reference panics on an arity that does not fit
+    what is left of the degree)"""
     out, db = [], degree_bits
-    while db > cfg.final_poly_bits and db + cfg.rate_bits - cfg.arity_bits >= cfg.cap_height:
+    while db > cfg.final_poly_bits:
+        assert db + cfg.rate_bits >= cfg.arity_bits, "usize underflow of degree_bits + rate_bits - arity_bits (:42)"
+        if db + cfg.rate_bits - cfg.arity_bits < cfg.cap_height:
+            break
         out.append(cfg.arity_bits)
+        assert db >= cfg.arity_bits, "ConstantArityBits: degree_bits >= arity_bits (fri/reduction_strategies.rs:45)"
         db -= cfg.arity_bits
     return out
 

@@ -8,9 +8,14 @@ def constant_arity_bits(arity_bits, final_poly_bits, degree_bits, rate_bits, cap
     """ConstantArityBits(arity_bits, final_poly_bits) (:44-56): reduce by 2^arity_bits until the degree is at most 2^final_poly_bits
     or one more reduction would make the last FRI tree lower than cap_height."""
     out = []
-    while degree_bits > final_poly_bits and degree_bits + rate_bits - arity_bits >= cap_height:
+    while degree_bits > final_poly_bits:
+        # usize arithmetic there: the subtraction panics in a debug build and wraps in a release build, where the assert below
+        # then fails - the reference does not survive this configuration either way
+        assert degree_bits + rate_bits >= arity_bits, "attempt to subtract with overflow (fri/reduction_strategies.rs:42)"
+        if degree_bits + rate_bits - arity_bits < cap_height:
+            break
         out.append(arity_bits)
-        assert degree_bits >= arity_bits
+        assert degree_bits >= arity_bits, "assertion failed: degree_bits >= arity_bits (fri/reduction_strategies.rs:45)"
         degree_bits -= arity_bits
     return out
 

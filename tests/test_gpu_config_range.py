@@ -181,7 +181,7 @@ def test_challenge_counts_that_cannot_be_sound_are_rejected(ctx):
 
 # ---------------------------------------------------------------------------------------------- FRI arities up to 2^8
 @pytest.mark.parametrize("field_name,degree_bits,arity_bits,final_poly_bits", [
-    ("goldilocks", 12, 5, 2), ("goldilocks", 13, 6, 1), ("goldilocks", 14, 7, 0), ("goldilocks", 16, 8, 0), ("goldilocks", 9, 8, 0),
+    ("goldilocks", 12, 5, 2), ("goldilocks", 13, 6, 1), ("goldilocks", 14, 7, 0), ("goldilocks", 16, 8, 0), ("goldilocks", 10, 8, 2),
     ("babybear", 12, 5, 2), ("babybear", 13, 6, 1), ("babybear", 14, 7, 0), ("babybear", 16, 8, 0),
 ])
 def test_proof_bytes_with_constant_arities_above_16(ctx, field_name, degree_bits, arity_bits, final_poly_bits):
