@@ -199,3 +199,32 @@ def test_proof_bytes_with_fixed_lists_of_wide_arities(ctx, field_name, degree_bi
     circ = D.DummyCircuit(degree_bits, mk(num_challenges=2 if F is GL else 6), F=F)
     circ.reduction_arity_bits = list(bits)
     _prove_and_compare(ctx, circ, tag, bits=bits, seed=degree_bits)
+
+
+# ---------------------------------------------------------------------------------------------- the stage-level entry points
+@pytest.mark.parametrize("field_name,degree_bits,rate_bits,num_challenges", [("goldilocks", 9, 6, 5), ("goldilocks", 11, 7, 2),
+                                                                             ("babybear", 8, 5, 11), ("babybear", 10, 8, 6)])
+def test_stage_entry_points_on_the_subsampled_quotient_domain(ctx, field_name, degree_bits, rate_bits, num_challenges):
+    """gb_zs_partial_products / gb_quotient_polys / gb_prove_openings driven from a host loop (tests/test_gpu_stage_abi.py) with
+    step > 1 and sliced challenge counts: the Z / partial-product values and the quotient chunk coefficients equal the oracle
+    prover's own intermediates, the bytes equal gb_prove's and the oracle's."""
+    from test_gpu_stage_abi import prove_by_stages
+    F, tag, mk = _field(field_name)
+    circ = D.DummyCircuit(degree_bits, mk(num_challenges=num_challenges, rate_bits=rate_bits), F=F)
+    gpu = _gpu(ctx, circ, tag)
+    for attempt in range(6):
+        w = circ.witness(seed=77 + attempt)
+        dump, mid = {}, {}
+        try:
+            want, _ = D.prove_cpu(circ, w, dump=dump)
+        except RuntimeError as e:
+            assert "rc=1" in str(e)
+            continue
+        got = prove_by_stages(gpu, circ, w, [], tag, mid)
+        assert (mid["zs_partial_products"] == dump["zs_partial_products"]).all()
+        assert (mid["quotient_chunks"] == dump["quotient_chunks"]).all()
+        assert got == want and got == gpu.prove_once(w)
+        break
+    else:
+        raise AssertionError("six witnesses in a row met a zero denominator")
+    gpu.free()
