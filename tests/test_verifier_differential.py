@@ -1,0 +1,86 @@
+"""gb_verify (csrc/verifier_host.inc, host C++, no device) against the independently written oracle verifier (oracle/verifier.py +
+oracle/plonk_dummy.verify, pinned by the reference's regression proof) on MUTATED proofs: single bytes flipped at random
+positions, truncations, extensions, words replaced by non-canonical representatives.  The two must give the same verdict on
+every mutant, and no mutant may be accepted: every byte of a proof is bound by the transcript, a Merkle path or the shape check
+(plonk/validate_shape.rs, fri/validate_shape.rs).  Configurations cover both fields, salted proofs, rate_bits above the quotient
+degree and Fixed arity lists.  No GPU."""
+import numpy as np
+import pytest
+
+from oracle import plonk_dummy as D
+from oracle.fields import BB, GL
+from plonky2_goldibear_amd import VerifierCircuitData, VerifyError, native as N
+
+CONFIGS = [
+    ("goldilocks", 4, dict(num_challenges=2, num_query_rounds=5), None, False),
+    ("goldilocks", 5, dict(num_challenges=3, num_query_rounds=3, rate_bits=6, cap_height=2), [2, 1], False),
+    ("goldilocks", 4, dict(num_challenges=2, num_query_rounds=4, cap_height=1), None, True),
+    ("babybear", 5, dict(num_challenges=6, num_query_rounds=4), None, False),
+    ("babybear", 4, dict(num_challenges=5, num_query_rounds=3, rate_bits=5, cap_height=0), [3], True),
+]
+
+
+def _make(field_name, lg, kw, bits, zk):
+    F = GL if field_name == "goldilocks" else BB
+    cfg = D.CircuitConfig(**kw) if F is GL else D.CircuitConfig.babybear(**kw)
+    circ = D.DummyCircuit(lg, cfg, F=F)
+    if bits is not None:
+        circ.reduction_arity_bits = list(bits)
+    salts = None
+    if zk:
+        circ.zero_knowledge = True
+        salts = F.fill(0xABC, 12 * (circ.n << cfg.rate_bits)).reshape(3, 4, -1)
+    for attempt in range(6):
+        try:
+            proof, _ = D.prove_cpu(circ, circ.witness(seed=3 + attempt), salts=salts)
+            break
+        except RuntimeError as e:
+            assert "rc=1" in str(e)
+    ver = VerifierCircuitData(lg, circ.gate_table, circ.k_is, circ.constants_sigmas_cap, circ.circuit_digest,
+                              num_wires=cfg.num_wires, num_routed_wires=cfg.num_routed_wires, num_constants=cfg.num_constants,
+                              num_challenges=cfg.num_challenges, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height,
+                              proof_of_work_bits=cfg.proof_of_work_bits, num_query_rounds=cfg.num_query_rounds,
+                              arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits, num_selectors=circ.num_selectors,
+                              zero_knowledge=zk, field=N.GB_GOLDILOCKS if F is GL else N.GB_BABYBEAR, reduction_arity_bits=bits)
+    return F, circ, ver, proof
+
+
+def _verdicts(circ, ver, data):
+    try:
+        lib = bool(ver.verify(data))
+    except (VerifyError, N.GoldibearError):
+        lib = False
+    try:
+        ora = bool(D.verify(circ, data))
+    except Exception:   # the oracle verifier asserts / raises on anything it does not like, malformed input included
+        ora = False
+    return lib, ora
+
+
+@pytest.mark.parametrize("which", range(len(CONFIGS)))
+def test_mutants_get_the_same_verdict_and_none_is_accepted(which):
+    F, circ, ver, proof = _make(*CONFIGS[which])
+    assert _verdicts(circ, ver, proof) == (True, True)
+    rng = np.random.default_rng(500 + which)
+    es = F.elem_bytes
+    mutants = []
+    for _ in range(120):     # one byte, anywhere
+        pos = int(rng.integers(0, len(proof)))
+        m = bytearray(proof)
+        m[pos] ^= 1 << int(rng.integers(0, 8))
+        mutants.append(("flip byte %d" % pos, bytes(m)))
+    for _ in range(20):      # an element replaced by a non-canonical representative of the same residue (x + p where it fits)
+        pos = int(rng.integers(0, len(proof) // es - 2)) * es
+        x = int.from_bytes(proof[pos:pos + es], "little")
+        if x + F.P < 1 << (8 * es):
+            m = bytearray(proof)
+            m[pos:pos + es] = (x + F.P).to_bytes(es, "little")
+            mutants.append(("non-canonical element at %d" % pos, bytes(m)))
+    mutants.append(("truncated by one byte", proof[:-1]))
+    mutants.append(("truncated to half", proof[:len(proof) // 2]))
+    mutants.append(("one byte appended", proof + b"\x00"))
+    mutants.append(("empty", b""))
+    for what, data in mutants:
+        lib, ora = _verdicts(circ, ver, data)
+        assert lib == ora, "verdicts differ on %s: gb_verify %r, oracle verifier %r" % (what, lib, ora)
+        assert not lib, "a mutant was accepted by both verifiers: %s" % what
