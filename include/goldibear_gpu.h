@@ -77,8 +77,8 @@ gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out);
  *                    default 4; 0 = the calling thread copies; -1 = no ring, hipMemcpyAsync straight from pageable memory
  *   "retry_verify"   1: gb_prove_retry first compares the caller's whole matrix with the copy the failed attempt kept and
  *                    returns GB_ERR_INVALID if they differ in more than witness[wire][row] (one read-back of the witness)
- *   "upload_legacy_chunks", "lde_group", "pa_log_split", "intt_group"   A/B switches of DESIGN.md section 4 (the last three
- *                    are process-wide) */
+ *   "upload_legacy_chunks", "lde_group", "pa_log_split", "intt_group", "fuse_intt_lde", "overlap_hash"   A/B switches of
+ *                    DESIGN.md section 4 (the NTT ones are process-wide) */
 gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value);
 
 /* ---- host memory ---------------------------------------------------------------------------

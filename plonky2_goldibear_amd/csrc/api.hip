@@ -67,6 +67,7 @@ struct gb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host -> device uploads that overlap kernels on `stream` (commit() of host input)
+    hipStream_t hash_stream = nullptr;  // "overlap_hash": the leaf-sponge segments of a chunked commit, beside the transforms of the next chunks
     std::string err;
     bool profiling = false;
     std::map<std::string, ScopeAcc> scopes;
@@ -91,6 +92,7 @@ struct gb_ctx {
     int copy_threads = 4;                                   // "copy_threads": -1 = no staging ring (hipMemcpyAsync straight from pageable memory)
     bool upload_legacy_chunks = false;                      // "upload_legacy_chunks": rounds 2-3 upload chunking 4, 12, 16, ... (A/B)
     bool retry_verify = false;                              // "retry_verify": gb_prove_retry compares the whole matrix with the kept copy
+    bool overlap_hash = false;                              // "overlap_hash": see hash_stream
 };
 static void drop_all_retry_state(gb_ctx* ctx);              // prover_host.inc
 
@@ -123,14 +125,15 @@ struct Scope {
     gb_ctx* ctx;
     hipEvent_t a = nullptr, b = nullptr;
     const char* name;
-    Scope(gb_ctx* c, const char* n) : ctx(c), name(n) {
+    hipStream_t on;
+    Scope(gb_ctx* c, const char* n, hipStream_t stream = nullptr) : ctx(c), name(n), on(stream ? stream : c->stream) {
         if (!ctx->profiling) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        hipEventRecord(a, ctx->stream);
+        hipEventRecord(a, on);
     }
     ~Scope() {
         if (!a) return;
-        hipEventRecord(b, ctx->stream);
+        hipEventRecord(b, on);
         ctx->scopes[name].spans.emplace_back(a, b);
     }
 };
@@ -165,6 +168,7 @@ gb_status finish_host_commit(gb_ctx* ctx, gb_status s, gb_batch** out) {
         return s;
     }
     (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->hash_stream) (void)hipStreamSynchronize(ctx->hash_stream);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->upload_marked = false;
     return s;
@@ -731,7 +735,11 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
     if (!b) return fail(ctx, GB_ERR_OOM, "host allocation failed");
     b->ctx = ctx; b->field = field; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
     b->nsalt = nsalt; b->ncols = ncols;
-    auto cleanup = [&](gb_status s) { gb_batch_free(b); return s; };
+    auto cleanup = [&](gb_status s) {   // error exits: nothing of the second stream may still touch blocks that go back to the pool
+        if (ctx->hash_stream) (void)hipStreamSynchronize(ctx->hash_stream);
+        gb_batch_free(b);
+        return s;
+    };
 
     void* p = nullptr;
     const size_t es = esize(field);
@@ -791,20 +799,46 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         gb_ctx* ctx; void** p; size_t bytes;
         ~SegGuard() { if (*p) pool_free(ctx, *p, bytes); }
     } seg_guard{ctx, &seg_state, seg_state_bytes};
+    // "overlap_hash": the segments go to a second stream, behind an event that marks the LDE of the chunk that completed them, and
+    // run beside the transforms of the chunks after it (the sponge is pure VALU work, the transforms wait on HBM half of the time);
+    // the main stream waits for the last of them before the final segment.  Off: everything on the main stream, in order.
+    hipStream_t hs = st;
+    if (ctx->overlap_hash && !dev_in) {
+        if (!ctx->hash_stream && hipStreamCreateWithFlags(&ctx->hash_stream, hipStreamNonBlocking) != hipSuccess) ctx->hash_stream = nullptr;
+        if (ctx->hash_stream) hs = ctx->hash_stream;
+    }
+    EventList hash_evs;
+    bool hash_overlapped = false;
     auto hash_ready_segments = [&](size_t cols_ready) -> bool {   // every full segment that is not the last one
+        bool first = true;
         for (u32 sz = seg_size(seg_done); segmented && seg_done + sz < ncols && seg_done + sz <= cols_ready; sz = seg_size(seg_done)) {
             if (!seg_state && pool_alloc(ctx, seg_state_bytes, &seg_state) != hipSuccess) { seg_state = nullptr; return false; }
-            Scope sm(ctx, "build Merkle tree");
-            Scope sl(ctx, "hash leaves");
+            if (hs != st && first) {   // the columns of these segments are complete once the main stream gets here
+                bool ok = true;
+                hipEvent_t ready = hash_evs.make(ok);
+                if (!ok || hipEventRecord(ready, st) != hipSuccess || hipStreamWaitEvent(hs, ready, 0) != hipSuccess) hs = st;
+                else hash_overlapped = true;
+                first = false;
+            }
+            Scope sm(ctx, "build Merkle tree", hs);
+            Scope sl(ctx, "hash leaves", hs);
             const u32 next_cols = (u32)(width - (seg_done + sz));
             if (field == GB_GOLDILOCKS)
-                gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, seg_done + sz, N, (u64*)seg_state, false, next_cols, b->levels, st);
+                gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, seg_done + sz, N, (u64*)seg_state, false, next_cols, b->levels, hs);
             else
                 gbk::bb_merkle_leaves_segment((const u32*)b->lde, N, seg_done, seg_done + sz, N, (u32*)seg_state, false, next_cols,
-                                              (u32*)b->levels, st);
+                                              (u32*)b->levels, hs);
             seg_done += sz;
         }
         return true;
+    };
+    auto join_hash_stream = [&]() -> bool {   // before the last segment (and before any error return hands blocks back to the pool)
+        if (!hash_overlapped) return true;
+        hash_overlapped = false;
+        bool ok = true;
+        hipEvent_t done = hash_evs.make(ok);
+        if (ok && hipEventRecord(done, ctx->hash_stream) == hipSuccess && hipStreamWaitEvent(st, done, 0) == hipSuccess) return true;
+        return hipStreamSynchronize(ctx->hash_stream) == hipSuccess;
     };
     if (field == GB_BABYBEAR) {
         // same flow over u32 Montgomery words; inputs are converted on the way in
@@ -893,6 +927,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
                 gbk::bb_bitrev_copy_to_mont(sdev, lde + ncols * N, log_N, nsalt, st);
             }
         }
+        if (!join_hash_stream()) return cleanup(fail(ctx, GB_ERR_HIP, "joining the leaf-hash stream failed"));
         {
             Scope sc(ctx, "build Merkle tree");
             u32* lv = (u32*)b->levels;
@@ -982,6 +1017,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
             gbk::u64_bitrev_copy(sdev, b->lde + ncols * N, log_N, nsalt, st);
         }
     }
+    if (!join_hash_stream()) return cleanup(fail(ctx, GB_ERR_HIP, "joining the leaf-hash stream failed"));
     {
         Scope sc(ctx, "build Merkle tree");
         {
@@ -1048,6 +1084,7 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     for (auto& kv : ctx->pool) hipFree(kv.second);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     delete ctx->stager;   // joins the copy threads, frees the page-locked ring
+    if (ctx->hash_stream) { hipStreamSynchronize(ctx->hash_stream); hipStreamDestroy(ctx->hash_stream); }
     hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
@@ -1212,6 +1249,8 @@ gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) try {
         ctx->upload_legacy_chunks = value != 0;
     } else if (k == "retry_verify") {
         ctx->retry_verify = value != 0;
+    } else if (k == "overlap_hash") {
+        ctx->overlap_hash = value != 0;
     } else if (k == "lde_group" || k == "pa_log_split" || k == "intt_group" || k == "fuse_intt_lde") {   // process-wide (kernels_ntt.hip)
         if (value < 0 || value > 4096) return fail(ctx, GB_ERR_INVALID, "option value out of range");
         gbk::NttKnobs& kn = gbk::ntt_knobs_mut();
