@@ -80,6 +80,32 @@ def test_prove_2pow21_rows_verifies(ctx):
     ctx.trim()
 
 
+@pytest.mark.parametrize("lg,ch", [(21, 10), (22, 12)])
+def test_babybear_prove_above_2pow20_rows_verifies(ctx, lg, ch):
+    """BabyBear at 2^21 / 2^22 rows: (31 - degree_bits) c >= 100 (circuit_builder.rs:1190-1192) asks for 10 / 12 challenges -
+    twelve run as two slices of six in the quotient kernel (csrc/challenge_slices.hpp).  The proof may need the reference's
+    retry (a zero denominator meets ~35 % of the attempts at these sizes); gb_verify and the oracle verifier accept it."""
+    from oracle.fields import BB
+    cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(lg)
+    gpu = CircuitData(ctx, lg, cs, k_is, num_wires=167, num_routed_wires=41, num_challenges=ch, arity_bits=3, field=GB_BABYBEAR)
+    del cs
+    proof = None
+    for seed in range(8):
+        try:
+            proof = gpu.prove_once(DC.dummy_witness_bb(lg, pi_row, seed=seed))
+            break
+        except N.PermArgZeroError:
+            continue
+    assert proof is not None
+    assert gpu.verify(proof)
+    view = D.DummyCircuit.verifier_view(lg, D.CircuitConfig.babybear(ch), BB, k_is)
+    view.set_cap(gpu.constants_sigmas_cap)
+    assert (view.circuit_digest == gpu.circuit_digest).all()
+    assert D.verify(view, proof)
+    gpu.free()
+    ctx.trim()
+
+
 def test_zs_running_product_above_1024_blocks(ctx):
     """wires_permutation_partial_products_and_zs at 2^21 rows (plonk/prover.rs:480-546): the running product is a scan over 2048
     blocks of 1024 rows - more than one thread per block total.  The dummy circuit's sigma is the identity almost everywhere (every
