@@ -1,5 +1,8 @@
-"""More of tests/test_gpu_config_fuzz.py: seeds FIRST .. LAST of the same draw(), every proof's bytes against the CPU oracle prover,
-gb_verify and the oracle verifier.  usage (GPU box): python tools/fuzz_configs.py 48 348 > gpurun_out/config_fuzz.txt"""
+"""More seeds of the GPU suite's seeded fuzz tests, every result against the CPU oracle as in the tests themselves:
+  python tools/fuzz_configs.py 48 348                  # tests/test_gpu_config_fuzz.py: configurations of prove(), proof bytes
+  python tools/fuzz_configs.py commit 60 460           # tests/test_gpu_commit_fuzz.py: batch shapes, every coefficient / leaf / digest
+  python tools/fuzz_configs.py circuit 24 174          # tests/test_gpu_circuit_fuzz.py: random circuits, proof bytes
+usage (GPU box): ... > gpurun_out/config_fuzz.txt"""
 import os
 import sys
 import time
@@ -11,7 +14,27 @@ import test_gpu_config_fuzz as T  # noqa: E402
 from plonky2_goldibear_amd import GpuContext  # noqa: E402
 
 
+def other_family(kind, first, last):
+    mod = __import__("test_gpu_commit_fuzz" if kind == "commit" else "test_gpu_circuit_fuzz")
+    fn = mod.test_random_commit_shape if kind == "commit" else mod.test_random_circuit
+    ctx = GpuContext(0)
+    t0, bad = time.time(), 0
+    for seed in range(first, last):
+        try:
+            fn(ctx, seed)
+        except Exception as e:   # keep going: the point is the list
+            bad += 1
+            print("FAIL %s seed %d: %s" % (kind, seed, repr(e)[:300]), flush=True)
+        if (seed - first) % 50 == 49:
+            print("... %d, %d failures, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
+    print("%s fuzz: %d seeds (%d..%d), %d failures, %.0f s" % (kind, last - first, first, last - 1, bad, time.time() - t0))
+    ctx.close()
+    return 1 if bad else 0
+
+
 def main():
+    if sys.argv[1] in ("commit", "circuit"):
+        return other_family(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
     first, last = int(sys.argv[1]), int(sys.argv[2])
     ctx = GpuContext(0)
     t0, bad = time.time(), []
