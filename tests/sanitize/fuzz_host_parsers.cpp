@@ -137,10 +137,20 @@ int main(int argc, char** argv) {
     };
     for (long it = 0; it < iterations; it++) {
         const std::vector<uint8_t> m = mutate(proof);
-        tally(0, gb_verify(c, m.data(), m.size()), "gb_verify");
+        const gb_status vs = gb_verify(c, m.data(), m.size());
+        tally(0, vs, "gb_verify");
+        if (vs == GB_OK && m != proof) {   // a mutation may be the identity (a byte overwritten with itself); nothing else may verify
+            std::fprintf(stderr, "gb_verify ACCEPTED a mutated proof (iteration %ld)\n", it);
+            return 1;
+        }
         if (it % 4 == 0) tally(1, gb_proof_compress(c, m.data(), m.size(), out.data(), out.size(), &n), "gb_proof_compress");
         const std::vector<uint8_t> mc = mutate(compressed);
-        tally(2, gb_verify_compressed(c, mc.data(), mc.size()), "gb_verify_compressed");
+        const gb_status cs = gb_verify_compressed(c, mc.data(), mc.size());
+        tally(2, cs, "gb_verify_compressed");
+        if (cs == GB_OK && mc != compressed) {
+            std::fprintf(stderr, "gb_verify_compressed ACCEPTED a mutated proof (iteration %ld)\n", it);
+            return 1;
+        }
         if (it % 4 == 1) tally(2, gb_proof_decompress(c, mc.data(), mc.size(), out.data(), it % 8 == 1 ? 16 : out.size(), &n), "gb_proof_decompress");
     }
     // empty and tiny inputs

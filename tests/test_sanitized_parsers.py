@@ -88,3 +88,32 @@ def test_dummy_circuit_proof_mutations(harness, tmp_path, F):
     case = str(tmp_path / "dummy.case")
     _case(case, words, circ.gate_table, circ.k_is, circ.constants_sigmas_cap, circ.circuit_digest, proof, F.dtype)
     _run(harness, case, 300, 7 + F.D)
+
+
+@pytest.mark.parametrize("F,lg,kw,zk", [
+    (GL, 6, dict(rate_bits=6, cap_height=0, arity_bits=6, final_poly_bits=0, num_query_rounds=6), False),
+    (BB, 4, dict(rate_bits=5, cap_height=2, num_challenges=11, num_query_rounds=5), True),
+], ids=["goldilocks-rate6-arity64", "babybear-rate5-11challenges-zk"])
+def test_other_configurations_mutations(harness, tmp_path, F, lg, kw, zk):
+    """rate_bits above the quotient degree, a FRI arity of 2^6, cap_height 0, eleven challenges, salted leaves: the parsers' length
+    arithmetic depends on all of them.  The harness also refuses any accepted mutant that is not the identity."""
+    cfg = D.CircuitConfig(**kw) if F is GL else D.CircuitConfig.babybear(**kw)
+    circ = D.DummyCircuit(lg, cfg, F=F)
+    salts = None
+    if zk:
+        circ.zero_knowledge = True
+        salts = F.fill(77, 12 * (circ.n << cfg.rate_bits)).reshape(3, 4, -1)
+    for attempt in range(6):
+        try:
+            proof, _ = D.prove_cpu(circ, circ.witness(seed=3 + attempt), salts=salts)
+            break
+        except RuntimeError as e:
+            assert "rc=1" in str(e)
+    assert D.verify(circ, proof)
+    c = circ.cfg
+    words = [0 if F is GL else 1, circ.degree_bits, c.num_wires, c.num_routed_wires, c.num_constants, c.num_challenges,
+             c.max_quotient_degree_factor, c.rate_bits, c.cap_height, c.proof_of_work_bits, c.num_query_rounds, c.arity_bits,
+             c.final_poly_bits, circ.num_selectors, 0, 0, 1 if zk else 0, 0]
+    case = str(tmp_path / "other.case")
+    _case(case, words, circ.gate_table, circ.k_is, circ.constants_sigmas_cap, circ.circuit_digest, proof, F.dtype)
+    _run(harness, case, 200, 31 + lg)
