@@ -61,6 +61,12 @@ def _verdicts(circ, ver, data):
 def test_mutants_get_the_same_verdict_and_none_is_accepted(which):
     F, circ, ver, proof = _make(*CONFIGS[which])
     assert _verdicts(circ, ver, proof) == (True, True)
+    # the compressed form (fri/proof.rs:137-384, hash/path_compression.rs): gb_proof_compress == the oracle's, byte for byte, and back
+    from oracle import compression as Z
+    small = ver.compress(proof)
+    assert small == Z.compress_bytes(proof, circ.circuit_digest, circ.common_data(), F)
+    assert ver.decompress(small) == proof == Z.decompress_bytes(small, circ.circuit_digest, circ.common_data(), F)
+    assert ver.verify_compressed(small)
     rng = np.random.default_rng(500 + which)
     es = F.elem_bytes
     mutants = []
