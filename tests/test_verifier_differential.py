@@ -90,3 +90,35 @@ def test_mutants_get_the_same_verdict_and_none_is_accepted(which):
         lib, ora = _verdicts(circ, ver, data)
         assert lib == ora, "verdicts differ on %s: gb_verify %r, oracle verifier %r" % (what, lib, ora)
         assert not lib, "a mutant was accepted by both verifiers: %s" % what
+
+
+@pytest.mark.parametrize("which", range(len(CONFIGS)))
+def test_compressed_mutants_get_the_same_verdict(which):
+    """the same for the compressed form: gb_verify_compressed against oracle decompression + verification"""
+    from oracle import compression as Z
+    F, circ, ver, proof = _make(*CONFIGS[which])
+    small = ver.compress(proof)
+    rng = np.random.default_rng(900 + which)
+
+    def verdicts(data):
+        try:
+            lib = bool(ver.verify_compressed(data))
+        except (VerifyError, N.GoldibearError):
+            lib = False
+        try:
+            ora = bool(D.verify(circ, Z.decompress_bytes(data, circ.circuit_digest, circ.common_data(), F)))
+        except Exception:
+            ora = False
+        return lib, ora
+
+    assert verdicts(small) == (True, True)
+    mutants = [("truncated", small[:-1]), ("extended", small + b"\x00"), ("half", small[:len(small) // 2])]
+    for _ in range(80):
+        pos = int(rng.integers(0, len(small)))
+        m = bytearray(small)
+        m[pos] ^= 1 << int(rng.integers(0, 8))
+        mutants.append(("flip byte %d" % pos, bytes(m)))
+    for what, data in mutants:
+        lib, ora = verdicts(data)
+        assert lib == ora, "verdicts differ on %s: gb_verify_compressed %r, oracle %r" % (what, lib, ora)
+        assert not lib, "a compressed mutant was accepted by both: %s" % what
