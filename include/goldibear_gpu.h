@@ -72,13 +72,11 @@ gb_status gb_ctx_synchronize(gb_ctx* ctx);
 gb_status gb_ctx_trim(gb_ctx* ctx);
 /* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
 gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out);
-/* Tuning and debugging switches; none changes a result.  Unknown key / value out of range: GB_ERR_INVALID.
+/* Tuning and debugging switches of THIS context; none changes a result.  Unknown key / value out of range: GB_ERR_INVALID.
  *   "copy_threads"   threads of the context that stage PAGEABLE host columns into the library's page-locked ring (below):
  *                    default 4; 0 = the calling thread copies; -1 = no ring, hipMemcpyAsync straight from pageable memory
  *   "retry_verify"   1: gb_prove_retry first compares the caller's whole matrix with the copy the failed attempt kept and
- *                    returns GB_ERR_INVALID if they differ in more than witness[wire][row] (one read-back of the witness)
- *   "upload_legacy_chunks", "lde_group", "pa_log_split", "intt_group", "fuse_intt_lde", "overlap_hash"   A/B switches of
- *                    DESIGN.md section 4 (the NTT ones are process-wide) */
+ *                    returns GB_ERR_INVALID if they differ in more than witness[wire][row] (one read-back of the witness) */
 gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value);
 
 /* ---- host memory ---------------------------------------------------------------------------

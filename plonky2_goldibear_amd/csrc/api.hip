@@ -67,7 +67,6 @@ struct gb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host -> device uploads that overlap kernels on `stream` (commit() of host input)
-    hipStream_t hash_stream = nullptr;  // "overlap_hash": the leaf-sponge segments of a chunked commit, beside the transforms of the next chunks
     std::string err;
     bool profiling = false;
     std::map<std::string, ScopeAcc> scopes;
@@ -82,7 +81,7 @@ struct gb_ctx {
     std::multimap<size_t, void*> pool;                      // freed batch blocks by size (stream-ordered reuse)
     DeviceBuf scratch;                                      // grow-only workspace
     DeviceBuf small;                                        // small gather staging (rows, siblings)
-    DeviceBuf big_work;                                     // log_n > 20: work buffer of the outer radix step (ntt_outer.hpp)
+    DeviceBuf big_work[3];                                  // log_n > 22: work buffers of the outer radix steps (ntt_outer.hpp), one per nesting level
     hipEvent_t upload_mark = nullptr;                       // recorded on `stream` after the last host -> device copy of a commit
     bool upload_marked = false;
     std::vector<gb_circuit*> circuits;                      // live circuits of this context: what they keep for gb_prove_retry is
@@ -90,9 +89,7 @@ struct gb_ctx {
     Stager* stager = nullptr;                               // made on first use by a pageable host input
     // gb_ctx_set_option
     int copy_threads = 4;                                   // "copy_threads": -1 = no staging ring (hipMemcpyAsync straight from pageable memory)
-    bool upload_legacy_chunks = false;                      // "upload_legacy_chunks": rounds 2-3 upload chunking 4, 12, 16, ... (A/B)
     bool retry_verify = false;                              // "retry_verify": gb_prove_retry compares the whole matrix with the kept copy
-    bool overlap_hash = false;                              // "overlap_hash": see hash_stream
 };
 static void drop_all_retry_state(gb_ctx* ctx);              // prover_host.inc
 
@@ -112,6 +109,33 @@ gb_status fail(gb_ctx* ctx, gb_status code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_null_ctx_error = msg;
     return code;
 }
+
+// ---- "never unwinds" (include/goldibear_gpu.h): EVERY extern "C" definition of this library is a function-try-block that ends in
+// GB_CATCH / GB_CATCH_CIRCUIT (tests/test_abi_guards.py parses csrc/ and fails on one that does not) - a Rust caller's
+// `panic = unwind` never crosses extern "C" either.  std::bad_alloc -> GB_ERR_OOM, any other std::exception -> GB_ERR_INVALID,
+// anything else -> GB_ERR_HIP; device blocks and retry state are released by the guards of the frames the exception unwinds
+// through (TmpAlloc, the batch / pool guards of commit() and prove()).  Writing the message must not throw either.
+gb_status unwound(gb_ctx* ctx, const char* fn) noexcept {
+    gb_status code = GB_ERR_HIP;
+    std::string& dst = ctx ? ctx->err : g_null_ctx_error;
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            code = GB_ERR_OOM;
+            dst = std::string(fn) + ": host allocation failed";
+        } catch (const std::exception& e) {
+            code = GB_ERR_INVALID;
+            dst = std::string(fn) + ": " + e.what();
+        } catch (...) {
+            dst = std::string(fn) + ": unknown exception";
+        }
+    } catch (...) {
+        dst.clear();   // no memory for the message either: the status code says it
+    }
+    return code;
+}
+#define GB_CATCH(CTX) catch (...) { return unwound((CTX), __func__); }
 
 #define HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                           \
@@ -168,7 +192,6 @@ gb_status finish_host_commit(gb_ctx* ctx, gb_status s, gb_batch** out) {
         return s;
     }
     (void)hipStreamSynchronize(ctx->copy_stream);
-    if (ctx->hash_stream) (void)hipStreamSynchronize(ctx->hash_stream);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->upload_marked = false;
     return s;
@@ -208,8 +231,13 @@ hipError_t pool_alloc(gb_ctx* ctx, size_t bytes, void** out) {
     }
     return e;
 }
-void pool_free(gb_ctx* ctx, void* p, size_t bytes) {
-    if (p) ctx->pool.emplace(bytes, p);
+void pool_free(gb_ctx* ctx, void* p, size_t bytes) noexcept {   // (called from destructors of guards: must not throw)
+    if (!p) return;
+    try {
+        ctx->pool.emplace(bytes, p);
+    } catch (...) {   // no memory for the map node: hand the block back to HIP instead (hipFree waits for the device)
+        (void)hipFree(p);
+    }
 }
 
 gb_status upload(gb_ctx* ctx, const std::vector<u64>& host, u64** dev, std::vector<void*>* owned) {
@@ -266,10 +294,16 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
     GlTableSet set;
     set.t.log_n = log_n;
     set.t.sub = nullptr;
-    if (log_n > 20) {   // the outer radix step (ntt_outer.hpp) runs the 2^20-row passes: their tables first (std::map nodes do not move)
-        const gbk::GlNttTables* sub20;
-        if (gb_status s20 = gl_tables_for(ctx, 20, &sub20)) return s20;
-        set.t.sub = sub20;
+    set.t.tw16k_inv_m = nullptr;
+    set.t.outer_bits = gbk::ntt_outer_bits(log_n);
+    if (set.t.outer_bits) {   // the outer radix step (ntt_outer.hpp) runs smaller transforms: their tables first (std::map nodes do not move)
+        const gbk::GlNttTables* sub;
+        if (gb_status s2 = gl_tables_for(ctx, log_n - set.t.outer_bits, &sub)) return s2;
+        set.t.sub = sub;
+    } else if (log_n > 20) {  // 2^21 / 2^22 rows: the middle inverse pass is a radix-32 / radix-64 DFT with twiddles w_{2^14}^-j
+        u64* t16;
+        if (gb_status s2 = upload(ctx, times_r(powers(gl::inv(gl::two_adic_generator(14)), (size_t)1 << 14)), &t16, &set.owned)) return s2;
+        set.t.tw16k_inv_m = t16;
     }
     set.t.tw4096_fwd = ctx->tw4096_fwd;
     set.t.tw4096_inv = ctx->tw4096_inv;
@@ -305,23 +339,23 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
 // coset c (block c of n leaves) has shift s_c = shift * w_N^bitrev_r(c): leaf j = c*n + jl is the LDE
 // point shift * w_N^bitrev_logN(j) (fri/oracle.rs:109 + polynomial/mod.rs:282-295; shift = 7, or
 // 7^(arity^l) for FRI layer l, fri/prover.rs:122-123).  inverse: tables of s_c^-1 instead.
-// log_n > 20: the work buffer of the outer radix step (de-interleaved coefficients + sub-LDEs of a group of columns), grown on demand
-gb_status ensure_big_work(gb_ctx* ctx, u32 log_n, u32 rate_bits, size_t es, void** p, size_t* elems) {
-    const size_t n = (size_t)1 << log_n, per_col = n + (n << rate_bits), cols = log_n > 22 ? 2 : 8;
-    if (gb_status s = ensure(ctx, ctx->big_work, cols * per_col * es)) return s;
-    *p = ctx->big_work.p;
-    *elems = ctx->big_work.bytes / es;
+// log_n > 22: the work buffers of the outer radix steps (de-interleaved coefficients + sub-LDEs of a group of columns), one per nesting
+// level, grown on demand before every use: the coset tables hold the ADDRESS of the context's pointer, not the pointer
+inline u32 big_work_level(u32 log_n) { return (log_n - gbk::NTT_NATIVE_LOG - 1) / gbk::NTT_OUTER_MAX_BITS; }
+gb_status ensure_big_work(gb_ctx* ctx, u32 log_n, u32 rate_bits, size_t es) {
+    for (; log_n > gbk::NTT_NATIVE_LOG; log_n -= gbk::ntt_outer_bits(log_n)) {
+        const size_t n = (size_t)1 << log_n, per_col = (n + (n << rate_bits)) * es;
+        const size_t cols = std::min<size_t>(8, std::max<size_t>(1, ((size_t)8 << 30) / per_col));   // groups of up to 8 columns within 8 GiB
+        if (gb_status s = ensure(ctx, ctx->big_work[big_work_level(log_n)], cols * per_col)) return s;
+    }
     return GB_OK;
 }
 gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u64 shift, bool inverse, const gbk::GlCosetTables** out) {
     auto key = std::make_tuple(log_n, rate_bits, shift, inverse ? 1 : 0);
     auto it = ctx->gl_cosets.find(key);
     if (it != ctx->gl_cosets.end()) {
-        if (log_n > 20) {   // the work buffer may have moved since (ensure() grows by reallocating)
-            void* w; size_t we;
-            if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u64), &w, &we)) return sw;
-            it->second.t.work = (u64*)w; it->second.t.work_elems = we;
-        }
+        if (!inverse)   // (released by gb_ctx_trim)
+            if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u64))) return sw;
         *out = &it->second.t;
         return GB_OK;
     }
@@ -339,14 +373,15 @@ gb_status gl_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u64 shift, bool i
     }
     GlCosetSet set;
     set.t.rate_bits = rate_bits;
-    set.t.sub = nullptr; set.t.work = nullptr; set.t.work_elems = 0;
-    if (log_n > 20) {   // sub-transforms of 2^20 rows on the shift s_c^R, R = n / 2^20 (ntt_outer.hpp)
-        const gbk::GlCosetTables* sub20;
-        if (gb_status s20 = gl_cosets_for(ctx, 20, rate_bits, gl::pow(shift, (u64)1 << (log_n - 20)), inverse, &sub20)) return s20;
-        set.t.sub = sub20;
-        void* w; size_t we;
-        if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u64), &w, &we)) return sw;
-        set.t.work = (u64*)w; set.t.work_elems = we;
+    set.t.sub = nullptr; set.t.work = nullptr; set.t.work_bytes = nullptr;
+    // inverse tables are read as power tables only (the quotient's coset_ifft); the LDE kernels never see them
+    if (const u32 K = gbk::ntt_outer_bits(log_n); K && !inverse) {   // sub-transforms of n / R rows on the shift s_c^R, R = 2^K (ntt_outer.hpp)
+        const gbk::GlCosetTables* sub;
+        if (gb_status s2 = gl_cosets_for(ctx, log_n - K, rate_bits, gl::pow(shift, (u64)1 << K), false, &sub)) return s2;
+        set.t.sub = sub;
+        if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u64))) return sw;
+        DeviceBuf& wb = ctx->big_work[big_work_level(log_n)];
+        set.t.work = &wb.p; set.t.work_bytes = &wb.bytes;
     }
     u64 *dlo, *dhi;
     gb_status s;
@@ -393,11 +428,22 @@ gb_status bb_tables_for(gb_ctx* ctx, u32 log_n, const gbk::BbNttTables** out) {
     }
     BbTableSet set;
     set.t.log_n = log_n;
-    set.t.sub = nullptr;
-    if (log_n > 20) {
-        const gbk::BbNttTables* sub20;
-        if (gb_status s20 = bb_tables_for(ctx, 20, &sub20)) return s20;
-        set.t.sub = sub20;
+    set.t.sub = set.t.wide = nullptr;
+    set.t.tw16k_inv = nullptr;
+    set.t.outer_bits = gbk::ntt_outer_bits(log_n);
+    if (set.t.outer_bits) {
+        const gbk::BbNttTables* sub;
+        if (gb_status s2 = bb_tables_for(ctx, log_n - set.t.outer_bits, &sub)) return s2;
+        set.t.sub = sub;
+    } else if (log_n > 20) {
+        if (log_n == 22) {   // the strided LDE pass of 2^22 rows works with the 2^20-row twiddles (k_bb_lde_pa16x2w)
+            const gbk::BbNttTables* w20;
+            if (gb_status s2 = bb_tables_for(ctx, 20, &w20)) return s2;
+            set.t.wide = w20;
+        }
+        u32* t16;
+        if (gb_status s2 = upload32(ctx, bb_powers(bb::inv(bb::two_adic_generator(14)), (size_t)1 << 14), &t16, &set.owned)) return s2;
+        set.t.tw16k_inv = t16;
     }
     set.t.tw4096_fwd = ctx->bb_tw4096_fwd;
     set.t.tw4096_inv = ctx->bb_tw4096_inv;
@@ -418,11 +464,8 @@ gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u32 shift_mont, b
     auto key = std::make_tuple(log_n, rate_bits, shift_mont, inverse ? 1 : 0);
     auto it = ctx->bb_cosets.find(key);
     if (it != ctx->bb_cosets.end()) {
-        if (log_n > 20) {
-            void* w; size_t we;
-            if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u32), &w, &we)) return sw;
-            it->second.t.work = (u32*)w; it->second.t.work_elems = we;
-        }
+        if (!inverse)
+            if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u32))) return sw;
         *out = &it->second.t;
         return GB_OK;
     }
@@ -440,14 +483,18 @@ gb_status bb_cosets_for(gb_ctx* ctx, u32 log_n, u32 rate_bits, u32 shift_mont, b
     }
     BbCosetSet set;
     set.t.rate_bits = rate_bits;
-    set.t.sub = nullptr; set.t.work = nullptr; set.t.work_elems = 0;
-    if (log_n > 20) {
-        const gbk::BbCosetTables* sub20;
-        if (gb_status s20 = bb_cosets_for(ctx, 20, rate_bits, bb::pow(shift_mont, (u64)1 << (log_n - 20)), inverse, &sub20)) return s20;
-        set.t.sub = sub20;
-        void* w; size_t we;
-        if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u32), &w, &we)) return sw;
-        set.t.work = (u32*)w; set.t.work_elems = we;
+    set.t.sub = set.t.fine = nullptr; set.t.work = nullptr; set.t.work_bytes = nullptr;
+    if (const u32 K = gbk::ntt_outer_bits(log_n); K && !inverse) {
+        const gbk::BbCosetTables* sub;
+        if (gb_status s2 = bb_cosets_for(ctx, log_n - K, rate_bits, bb::pow(shift_mont, (u64)1 << K), false, &sub)) return s2;
+        set.t.sub = sub;
+        if (gb_status sw = ensure_big_work(ctx, log_n, rate_bits, sizeof(u32))) return sw;
+        DeviceBuf& wb = ctx->big_work[big_work_level(log_n)];
+        set.t.work = &wb.p; set.t.work_bytes = &wb.bytes;
+    } else if (log_n == 22 && !inverse) {   // the finer cosets of 2^20 rows (k_bb_lde_pa16x2w)
+        const gbk::BbCosetTables* fine;
+        if (gb_status s2 = bb_cosets_for(ctx, 20, rate_bits + 2, shift_mont, false, &fine)) return s2;
+        set.t.fine = fine;
     }
     u32 *dlo, *dhi;
     gb_status s;
@@ -694,10 +741,7 @@ struct SegKeep {
 // Upload chunks of a host batch, in columns: 4, 4, 8, then `full`.  The GPU's per-column work (transform + leaf hashing) is slower
 // than PCIe delivers columns, so after a short ramp the upload is hidden - what is not hidden is the wait for the FIRST columns:
 // with 4 + 4 the first 8-column hashing segment starts after ~1.5 ms of a 2^20-row Goldilocks witness (4 + 12: ~3.5 ms).
-static inline size_t first_chunks(size_t c0, size_t full, bool legacy) {   // legacy (rounds 2-3, A/B option): 4, 12, then `full`
-    if (legacy) return c0 == 0 ? 4 : c0 == 4 ? full - 4 : full;
-    return c0 < 8 ? 4 : c0 < 16 ? 8 : full;
-}
+static inline size_t first_chunks(size_t c0, size_t full) { return c0 < 8 ? 4 : c0 < 16 ? 8 : full; }
 
 gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                  uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out, void* values_dev = nullptr,
@@ -722,7 +766,6 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         return fail(ctx, GB_ERR_INVALID, "LDE size exceeds the field's two-adicity (32 Goldilocks / 27 BabyBear)");
     if (cap_height > log_n + rate_bits)
         return fail(ctx, GB_ERR_INVALID, "cap_height should be at most log2(leaves.len()) (merkle_tree.rs:154-157)");
-    if (log_n > 24) return fail(ctx, GB_ERR_UNSUPPORTED, "log_n > 24 not implemented");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
@@ -735,8 +778,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
     if (!b) return fail(ctx, GB_ERR_OOM, "host allocation failed");
     b->ctx = ctx; b->field = field; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
     b->nsalt = nsalt; b->ncols = ncols;
-    auto cleanup = [&](gb_status s) {   // error exits: nothing of the second stream may still touch blocks that go back to the pool
-        if (ctx->hash_stream) (void)hipStreamSynchronize(ctx->hash_stream);
+    auto cleanup = [&](gb_status s) {
         gb_batch_free(b);
         return s;
     };
@@ -799,46 +841,20 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         gb_ctx* ctx; void** p; size_t bytes;
         ~SegGuard() { if (*p) pool_free(ctx, *p, bytes); }
     } seg_guard{ctx, &seg_state, seg_state_bytes};
-    // "overlap_hash": the segments go to a second stream, behind an event that marks the LDE of the chunk that completed them, and
-    // run beside the transforms of the chunks after it (the sponge is pure VALU work, the transforms wait on HBM half of the time);
-    // the main stream waits for the last of them before the final segment.  Off: everything on the main stream, in order.
-    hipStream_t hs = st;
-    if (ctx->overlap_hash && !dev_in) {
-        if (!ctx->hash_stream && hipStreamCreateWithFlags(&ctx->hash_stream, hipStreamNonBlocking) != hipSuccess) ctx->hash_stream = nullptr;
-        if (ctx->hash_stream) hs = ctx->hash_stream;
-    }
-    EventList hash_evs;
-    bool hash_overlapped = false;
     auto hash_ready_segments = [&](size_t cols_ready) -> bool {   // every full segment that is not the last one
-        bool first = true;
         for (u32 sz = seg_size(seg_done); segmented && seg_done + sz < ncols && seg_done + sz <= cols_ready; sz = seg_size(seg_done)) {
             if (!seg_state && pool_alloc(ctx, seg_state_bytes, &seg_state) != hipSuccess) { seg_state = nullptr; return false; }
-            if (hs != st && first) {   // the columns of these segments are complete once the main stream gets here
-                bool ok = true;
-                hipEvent_t ready = hash_evs.make(ok);
-                if (!ok || hipEventRecord(ready, st) != hipSuccess || hipStreamWaitEvent(hs, ready, 0) != hipSuccess) hs = st;
-                else hash_overlapped = true;
-                first = false;
-            }
-            Scope sm(ctx, "build Merkle tree", hs);
-            Scope sl(ctx, "hash leaves", hs);
+            Scope sm(ctx, "build Merkle tree");
+            Scope sl(ctx, "hash leaves");
             const u32 next_cols = (u32)(width - (seg_done + sz));
             if (field == GB_GOLDILOCKS)
-                gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, seg_done + sz, N, (u64*)seg_state, false, next_cols, b->levels, hs);
+                gbk::gl_merkle_leaves_segment(b->lde, N, seg_done, seg_done + sz, N, (u64*)seg_state, false, next_cols, b->levels, st);
             else
                 gbk::bb_merkle_leaves_segment((const u32*)b->lde, N, seg_done, seg_done + sz, N, (u32*)seg_state, false, next_cols,
-                                              (u32*)b->levels, hs);
+                                              (u32*)b->levels, st);
             seg_done += sz;
         }
         return true;
-    };
-    auto join_hash_stream = [&]() -> bool {   // before the last segment (and before any error return hands blocks back to the pool)
-        if (!hash_overlapped) return true;
-        hash_overlapped = false;
-        bool ok = true;
-        hipEvent_t done = hash_evs.make(ok);
-        if (ok && hipEventRecord(done, ctx->hash_stream) == hipSuccess && hipStreamWaitEvent(st, done, 0) == hipSuccess) return true;
-        return hipStreamSynchronize(ctx->hash_stream) == hipSuccess;
     };
     if (field == GB_BABYBEAR) {
         // same flow over u32 Montgomery words; inputs are converted on the way in
@@ -864,7 +880,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
             hipEvent_t e0 = evs.make(ok);                           // values_dev / coeffs may be a pool block still in use on `st`
             ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
             for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
-                cc = std::min(c0 < 32 ? 2 * first_chunks(c0 / 2, per / 2, ctx->upload_legacy_chunks) : per, ncols - c0);   // 4-byte words: the same bytes per chunk as Goldilocks' 4, 4, 8
+                cc = std::min(c0 < 32 ? 2 * first_chunks(c0 / 2, per / 2) : per, ncols - c0);   // 4-byte words: the same bytes per chunk as Goldilocks' 4, 4, 8
                 hipEvent_t copied = evs.make(ok);
                 ok = ok && upload_columns(ctx, cols, pinned, c0, cc, n * 4, vals + c0 * n) &&
                      hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
@@ -900,7 +916,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         } else if ((flags & GB_INPUT_DEVICE_FORM) || p3) {  // already Montgomery words on the device (prover-internal; a host's p3 words)
             if (hipMemcpyAsync(coeffs, in_dev, in_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
-        } else if (!is_coeffs && log_n >= 16 && log_n <= 20) {
+        } else if (!is_coeffs && log_n >= 16 && log_n <= gbk::NTT_NATIVE_LOG) {
             // canonical values on the device (a resident witness, a small host batch): the inverse transform takes them as they are
             Scope sc(ctx, "IFFT");
             (void)gbk::bb_intt_columns_canonical(const_cast<u32*>(in_dev), coeffs, scr + scr_bytes / 4, ncols, 0, *bt, st);
@@ -927,7 +943,6 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
                 gbk::bb_bitrev_copy_to_mont(sdev, lde + ncols * N, log_N, nsalt, st);
             }
         }
-        if (!join_hash_stream()) return cleanup(fail(ctx, GB_ERR_HIP, "joining the leaf-hash stream failed"));
         {
             Scope sc(ctx, "build Merkle tree");
             u32* lv = (u32*)b->levels;
@@ -956,7 +971,6 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
 
     const u64* src = static_cast<const u64*>(cols.base);
     const bool staged = !dev_in && !is_coeffs && log_n >= 12;
-    const bool fused_ntt = !is_coeffs && log_n == 20 && gbk::ntt_knobs().fuse_intt_lde;
     if (staged) {
         // column chunks: H2D into values_dev on the copy stream, then (main stream, behind an event) inverse NTT and LDE of the chunk
         const size_t CH = 16;
@@ -967,19 +981,14 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         hipEvent_t e0 = evs.make(ok);                               // values_dev may be a pool block still in use on `st`
         ok = ok && hipEventRecord(e0, st) == hipSuccess && hipStreamWaitEvent(ctx->copy_stream, e0, 0) == hipSuccess;
         for (size_t c0 = 0, cc = 0; c0 < ncols && ok; c0 += cc) {
-            cc = std::min(first_chunks(c0, CH, ctx->upload_legacy_chunks), ncols - c0);
+            cc = std::min(first_chunks(c0, CH), ncols - c0);
             hipEvent_t copied = evs.make(ok);
             ok = ok && upload_columns(ctx, cols, pinned, c0, cc, n * sizeof(u64), vals + c0 * n) &&
                  hipEventRecord(copied, ctx->copy_stream) == hipSuccess && hipStreamWaitEvent(st, copied, 0) == hipSuccess;
             if (!ok) break;
             if (p3) gbk::gl_canonicalize(vals + c0 * n, cc * n, st);   // p3-goldilocks keeps any u64 representative in memory
-            if (fused_ntt) {   // 2^20 rows: the inverse transform's last pass and the LDE's first are one kernel (timed under the LDE's scope)
-                Scope sc(ctx, "FFT + blinding");
-                gbk::gl_from_values_columns(vals + c0 * n, b->coeffs + c0 * n, b->lde + c0 * N, (u64*)ctx->scratch.p, cc, *tabs, *cos, st);
-            } else {
-                { Scope sc(ctx, "IFFT"); gbk::gl_intt_columns(vals + c0 * n, b->coeffs + c0 * n, (u64*)ctx->scratch.p, cc, *tabs, st); }
-                { Scope sc(ctx, "FFT + blinding"); gbk::gl_lde_columns(b->coeffs + c0 * n, b->lde + c0 * N, cc, *tabs, *cos, st); }
-            }
+            { Scope sc(ctx, "IFFT"); gbk::gl_intt_columns(vals + c0 * n, b->coeffs + c0 * n, (u64*)ctx->scratch.p, cc, *tabs, st); }
+            { Scope sc(ctx, "FFT + blinding"); gbk::gl_lde_columns(b->coeffs + c0 * n, b->lde + c0 * N, cc, *tabs, *cos, st); }
             if (!hash_ready_segments(c0 + cc)) return cleanup(fail(ctx, GB_ERR_OOM, "sponge state"));
         }
         if (!ok) return cleanup(fail(ctx, GB_ERR_HIP, "chunked upload of the input columns failed"));
@@ -993,15 +1002,12 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
     }
     if (!is_coeffs && !staged) {
         if ((s = ensure(ctx, ctx->scratch, ncols * n * sizeof(u64)))) return cleanup(s);
-        if (!fused_ntt) {
-            Scope sc(ctx, "IFFT");
-            gbk::gl_intt_columns(src, b->coeffs, (u64*)ctx->scratch.p, ncols, *tabs, st);
-        }
+        Scope sc(ctx, "IFFT");
+        gbk::gl_intt_columns(src, b->coeffs, (u64*)ctx->scratch.p, ncols, *tabs, st);
     }
     {
         Scope sc(ctx, "FFT + blinding");
-        if (!staged && fused_ntt) gbk::gl_from_values_columns(src, b->coeffs, b->lde, (u64*)ctx->scratch.p, ncols, *tabs, *cos, st);
-        else if (!staged) gbk::gl_lde_columns(b->coeffs, b->lde, ncols, *tabs, *cos, st);
+        if (!staged) gbk::gl_lde_columns(b->coeffs, b->lde, ncols, *tabs, *cos, st);
         if (nsalt) {
             // salt columns arrive in LDE-point order (like lde_values' extra columns, oracle.rs:144-148)
             // and are stored, like everything else, in leaf order: leaf j <- point bitrev(j)
@@ -1017,7 +1023,6 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
             gbk::u64_bitrev_copy(sdev, b->lde + ncols * N, log_N, nsalt, st);
         }
     }
-    if (!join_hash_stream()) return cleanup(fail(ctx, GB_ERR_HIP, "joining the leaf-hash stream failed"));
     {
         Scope sc(ctx, "build Merkle tree");
         {
@@ -1043,7 +1048,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
 
 extern "C" {
 
-gb_status gb_ctx_create(int device, gb_ctx** out) {
+gb_status gb_ctx_create(int device, gb_ctx** out) try {
     if (!out) return fail(nullptr, GB_ERR_INVALID, "null out");
     *out = nullptr;
     int count = 0;
@@ -1060,9 +1065,9 @@ gb_status gb_ctx_create(int device, gb_ctx** out) {
     }
     *out = ctx;
     return GB_OK;
-}
+} GB_CATCH(nullptr)
 
-gb_status gb_ctx_destroy(gb_ctx* ctx) {
+gb_status gb_ctx_destroy(gb_ctx* ctx) try {
     if (!ctx) return GB_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
@@ -1079,54 +1084,61 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) {
     if (ctx->tw4096_inv_m) hipFree(ctx->tw4096_inv_m);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->small.p) hipFree(ctx->small.p);
-    if (ctx->big_work.p) hipFree(ctx->big_work.p);
+    for (DeviceBuf& wb : ctx->big_work) if (wb.p) hipFree(wb.p);
     if (ctx->upload_mark) hipEventDestroy(ctx->upload_mark);
     for (auto& kv : ctx->pool) hipFree(kv.second);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     delete ctx->stager;   // joins the copy threads, frees the page-locked ring
-    if (ctx->hash_stream) { hipStreamSynchronize(ctx->hash_stream); hipStreamDestroy(ctx->hash_stream); }
     hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
     return GB_OK;
+} GB_CATCH(nullptr)   // (the object may be gone: the message goes to the thread's own slot)
+
+const char* gb_last_error(const gb_ctx* ctx) try {
+    return ctx ? ctx->err.c_str() : g_null_ctx_error.c_str();
+} catch (...) {
+    return "";
 }
 
-const char* gb_last_error(const gb_ctx* ctx) { return ctx ? ctx->err.c_str() : g_null_ctx_error.c_str(); }
-
-gb_status gb_ctx_synchronize(gb_ctx* ctx) {
+gb_status gb_ctx_synchronize(gb_ctx* ctx) try {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_ctx_trim(gb_ctx* ctx) {
+gb_status gb_ctx_trim(gb_ctx* ctx) try {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     drop_all_retry_state(ctx);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     ctx->pool.clear();
+    for (DeviceBuf& wb : ctx->big_work) {   // the coset tables hold these fields' addresses; the next lookup grows them again
+        if (wb.p) (void)hipFree(wb.p);
+        wb.p = nullptr; wb.bytes = 0;
+    }
     if (ctx->stager) {   // the page-locked staging ring and its copy threads come back with the next pageable input
         HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
         delete ctx->stager;
         ctx->stager = nullptr;
     }
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out) {
+gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out) try {
     if (!ctx || !stream_out) return fail(ctx, GB_ERR_INVALID, "null argument");
     *stream_out = (void*)ctx->stream;
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_ctx_set_profiling(gb_ctx* ctx, int32_t on) {
+gb_status gb_ctx_set_profiling(gb_ctx* ctx, int32_t on) try {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     ctx->profiling = on != 0;
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_ctx_scope_ms(gb_ctx* ctx, const char* scope, double* ms_out, uint64_t* count_out) {
+gb_status gb_ctx_scope_ms(gb_ctx* ctx, const char* scope, double* ms_out, uint64_t* count_out) try {
     if (!ctx || !scope || !ms_out) return fail(ctx, GB_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     double total = 0;
@@ -1143,9 +1155,9 @@ gb_status gb_ctx_scope_ms(gb_ctx* ctx, const char* scope, double* ms_out, uint64
     *ms_out = total;
     if (count_out) *count_out = cnt;
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_ctx_scope_reset(gb_ctx* ctx) {
+gb_status gb_ctx_scope_reset(gb_ctx* ctx) try {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->scopes)
@@ -1155,7 +1167,7 @@ gb_status gb_ctx_scope_reset(gb_ctx* ctx) {
         }
     ctx->scopes.clear();
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
 static gb_status commit_entry(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                               uint32_t cap_height, const void* salts, uint32_t flags, bool is_coeffs, gb_batch** out) {
@@ -1169,28 +1181,28 @@ static gb_status commit_entry(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t n
 }
 
 gb_status gb_commit_values(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) try {
     return commit_entry(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, false, out);
-}
+} GB_CATCH(ctx)
 
 gb_status gb_commit_coeffs(gb_ctx* ctx, uint32_t field, const void* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+                           uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) try {
     return commit_entry(ctx, field, cols, ncols, log_n, rate_bits, cap_height, salts, flags, true, out);
-}
+} GB_CATCH(ctx)
 
 // Vec<PolynomialValues<F>> / Vec<PolynomialCoeffs<F>> as the reference holds them: ncols separately allocated columns
 gb_status gb_commit_values_cols(gb_ctx* ctx, uint32_t field, const void* const* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                                uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+                                uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) try {
     return commit_entry(ctx, field, ColSrc::columns(cols), ncols, log_n, rate_bits, cap_height, salts, flags, false, out);
-}
+} GB_CATCH(ctx)
 
 gb_status gb_commit_coeffs_cols(gb_ctx* ctx, uint32_t field, const void* const* cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                                uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) {
+                                uint32_t cap_height, const void* salts, uint32_t flags, gb_batch** out) try {
     return commit_entry(ctx, field, ColSrc::columns(cols), ncols, log_n, rate_bits, cap_height, salts, flags, true, out);
-}
+} GB_CATCH(ctx)
 
 // ---- page-locked host memory for a host that builds its columns where the copy engine can read them
-gb_status gb_host_alloc(gb_ctx* ctx, size_t bytes, void** out) {
+gb_status gb_host_alloc(gb_ctx* ctx, size_t bytes, void** out) try {
     if (!ctx || !out) return fail(ctx, GB_ERR_INVALID, "null argument");
     *out = nullptr;
     if (!bytes) return fail(ctx, GB_ERR_INVALID, "zero-sized allocation");
@@ -1202,17 +1214,17 @@ gb_status gb_host_alloc(gb_ctx* ctx, size_t bytes, void** out) {
     }
     *out = p;
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_host_free(gb_ctx* ctx, void* p) {
+gb_status gb_host_free(gb_ctx* ctx, void* p) try {
     if (!ctx) return fail(nullptr, GB_ERR_INVALID, "null ctx");
     if (!p) return GB_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipHostFree(p));
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_host_register(gb_ctx* ctx, void* p, size_t bytes) {
+gb_status gb_host_register(gb_ctx* ctx, void* p, size_t bytes) try {
     if (!ctx || !p || !bytes) return fail(ctx, GB_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
@@ -1220,9 +1232,9 @@ gb_status gb_host_register(gb_ctx* ctx, void* p, size_t bytes) {
         return fail(ctx, GB_ERR_HIP, "hipHostRegister failed (already registered, or RLIMIT_MEMLOCK)");
     }
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_host_unregister(gb_ctx* ctx, void* p) {
+gb_status gb_host_unregister(gb_ctx* ctx, void* p) try {
     if (!ctx || !p) return fail(ctx, GB_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));   // no upload of this context is still reading it
@@ -1231,9 +1243,9 @@ gb_status gb_host_unregister(gb_ctx* ctx, void* p) {
         return fail(ctx, GB_ERR_INVALID, "hipHostUnregister failed (not a registered range)");
     }
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
-// Tuning and debugging switches (none changes a result).  Per context unless noted.
+// Tuning and debugging switches (none changes a result), all of them per context.
 gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) try {
     if (!ctx || !key) return fail(ctx, GB_ERR_INVALID, "null argument");
     const std::string k(key);
@@ -1245,25 +1257,15 @@ gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value) try {
             ctx->stager = nullptr;
         }
         ctx->copy_threads = (int)value;
-    } else if (k == "upload_legacy_chunks") {
-        ctx->upload_legacy_chunks = value != 0;
     } else if (k == "retry_verify") {
         ctx->retry_verify = value != 0;
-    } else if (k == "overlap_hash") {
-        ctx->overlap_hash = value != 0;
-    } else if (k == "lde_group" || k == "pa_log_split" || k == "intt_group" || k == "fuse_intt_lde") {   // process-wide (kernels_ntt.hip)
-        if (value < 0 || value > 4096) return fail(ctx, GB_ERR_INVALID, "option value out of range");
-        gbk::NttKnobs& kn = gbk::ntt_knobs_mut();
-        (k == "lde_group" ? kn.lde_group : k == "pa_log_split" ? kn.pa_log_split : k == "intt_group" ? kn.intt_group : kn.fuse_intt_lde) = (u32)value;
     } else {
         return fail(ctx, GB_ERR_INVALID, "unknown option: " + k);
     }
     return GB_OK;
-} catch (...) {
-    return GB_ERR_OOM;
-}
+} GB_CATCH(ctx)
 
-gb_status gb_batch_free(gb_batch* b) {
+gb_status gb_batch_free(gb_batch* b) try {
     if (!b) return GB_OK;
     if (b->ctx) {
         pool_free(b->ctx, b->coeffs, b->coeffs_bytes);
@@ -1272,10 +1274,10 @@ gb_status gb_batch_free(gb_batch* b) {
     }
     delete b;
     return GB_OK;
-}
+} GB_CATCH(nullptr)   // (the object may be gone: the message goes to the thread's own slot)
 
 gb_status gb_batch_info(const gb_batch* b, uint32_t* field, size_t* ncols, uint32_t* degree_log, uint32_t* rate_bits,
-                        uint32_t* cap_height, uint32_t* blinding) {
+                        uint32_t* cap_height, uint32_t* blinding) try {
     if (!b) return fail(nullptr, GB_ERR_INVALID, "null batch");
     if (field) *field = b->field;
     if (ncols) *ncols = b->ncols;
@@ -1284,9 +1286,9 @@ gb_status gb_batch_info(const gb_batch* b, uint32_t* field, size_t* ncols, uint3
     if (cap_height) *cap_height = b->cap_height;
     if (blinding) *blinding = b->nsalt ? 1 : 0;
     return GB_OK;
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
-gb_status gb_batch_cap(gb_batch* b, void* out) {
+gb_status gb_batch_cap(gb_batch* b, void* out) try {
     if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
     gb_ctx* ctx = b->ctx;
     const u64 N = (u64)1 << (b->log_n + b->rate_bits);
@@ -1294,9 +1296,9 @@ gb_status gb_batch_cap(gb_batch* b, void* out) {
     HIP_TRY(ctx, hipMemcpyAsync(out, cap, ((size_t)1 << b->cap_height) * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
-gb_status gb_batch_coeffs(gb_batch* b, size_t col, void* out) {
+gb_status gb_batch_coeffs(gb_batch* b, size_t col, void* out) try {
     if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
     gb_ctx* ctx = b->ctx;
     if (col >= b->ncols) return fail(ctx, GB_ERR_INVALID, "polynomial index out of range");
@@ -1312,7 +1314,7 @@ gb_status gb_batch_coeffs(gb_batch* b, size_t col, void* out) {
     HIP_TRY(ctx, hipMemcpyAsync(out, b->coeffs + col * n, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
 static gb_status read_row(gb_batch* b, u64 leaf, u32 width, void* out) {
     gb_ctx* ctx = b->ctx;
@@ -1329,7 +1331,7 @@ static gb_status read_row(gb_batch* b, u64 leaf, u32 width, void* out) {
     return GB_OK;
 }
 
-gb_status gb_batch_lde_values(gb_batch* b, uint64_t index, uint64_t step, void* out) {
+gb_status gb_batch_lde_values(gb_batch* b, uint64_t index, uint64_t step, void* out) try {
     if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
     const u32 bits = b->log_n + b->rate_bits;
     const u64 N = (u64)1 << bits;
@@ -1338,9 +1340,9 @@ gb_status gb_batch_lde_values(gb_batch* b, uint64_t index, uint64_t step, void* 
     u64 leaf = 0;
     for (u32 k = 0; k < bits; k++) leaf |= ((i >> k) & 1ull) << (bits - 1 - k);
     return read_row(b, leaf, (u32)b->ncols, out);
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
-gb_status gb_batch_leaf(gb_batch* b, uint64_t leaf_index, void* row, void* siblings, uint32_t* nsib) {
+gb_status gb_batch_leaf(gb_batch* b, uint64_t leaf_index, void* row, void* siblings, uint32_t* nsib) try {
     if (!b) return fail(nullptr, GB_ERR_INVALID, "null batch");
     gb_ctx* ctx = b->ctx;
     const u32 bits = b->log_n + b->rate_bits;
@@ -1359,9 +1361,9 @@ gb_status gb_batch_leaf(gb_batch* b, uint64_t leaf_index, void* row, void* sibli
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return GB_OK;
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
-gb_status gb_batch_digests(gb_batch* b, void* out) {
+gb_status gb_batch_digests(gb_batch* b, void* out) try {
     if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
     gb_ctx* ctx = b->ctx;
     const u32 bits = b->log_n + b->rate_bits;
@@ -1375,9 +1377,9 @@ gb_status gb_batch_digests(gb_batch* b, void* out) {
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
-gb_status gb_batch_leaves(gb_batch* b, void* out) {
+gb_status gb_batch_leaves(gb_batch* b, void* out) try {
     if (!b || !out) return fail(b ? b->ctx : nullptr, GB_ERR_INVALID, "null argument");
     gb_ctx* ctx = b->ctx;
     const u64 N = (u64)1 << (b->log_n + b->rate_bits);
@@ -1392,17 +1394,17 @@ gb_status gb_batch_leaves(gb_batch* b, void* out) {
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
-gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** digest_levels) {
+gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** digest_levels) try {
     if (!b) return fail(nullptr, GB_ERR_INVALID, "null batch");
     if (coeffs) *coeffs = b->coeffs;
     if (lde) *lde = b->lde;
     if (digest_levels) *digest_levels = b->levels;
     return GB_OK;
-}
+} GB_CATCH(b ? b->ctx : nullptr)
 
-gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uint64_t count) {
+gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uint64_t count) try {
     if (!ctx || !in || !out) return fail(ctx, GB_ERR_INVALID, "null argument");
     if (field != GB_GOLDILOCKS && field != GB_BABYBEAR) return fail(ctx, GB_ERR_INVALID, "unknown field tag");
     if (!count) return GB_OK;
@@ -1429,7 +1431,7 @@ gb_status gb_permute(gb_ctx* ctx, uint32_t field, const void* in, void* out, uin
     HIP_TRY(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GB_OK;
-}
+} GB_CATCH(ctx)
 
 }  // extern "C"
 

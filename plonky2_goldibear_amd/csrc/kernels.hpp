@@ -28,8 +28,16 @@ struct GlNttTables {
     // tw4096_fwd_m is [8192]: the powers, then the same powers in k_gl_lde_pb16's stage-1 order [slot][tid]
     const u64 *tw4096_fwd_m, *tw4096_inv_m, *tw_lo_fwd_m, *tw_hi_fwd_m, *tw_lo_inv_m, *tw_hi_inv_m;
     u64 n_inv_m;
-    const GlNttTables* sub;  // log_n > 20: the tables of the 2^20-row transforms the outer radix step runs (ntt_outer.hpp); else null
+    // 2^21 and 2^22 rows run the same three + two passes as 2^20 (round 6): the inverse transform's middle pass is a radix-32 / radix-64
+    // DFT with twiddles w_{2^14}^-j (tw16k_inv_m, [2^14], Montgomery form)
+    const u64* tw16k_inv_m;
+    // log_n > 22: one outer radix-2^outer_bits step (ntt_outer.hpp) around transforms of log_n - outer_bits rows (`sub`); else null / 0
+    const GlNttTables* sub;
+    u32 outer_bits;
 };
+static constexpr u32 NTT_NATIVE_LOG = 22;   // largest transform the passes run without an outer step
+static constexpr u32 NTT_OUTER_MAX_BITS = 4;
+inline u32 ntt_outer_bits(u32 log_n) { return log_n <= NTT_NATIVE_LOG ? 0 : (log_n - NTT_NATIVE_LOG < NTT_OUTER_MAX_BITS ? log_n - NTT_NATIVE_LOG : NTT_OUTER_MAX_BITS); }
 
 // Coset tables for the LDE of rate 2^rate_bits: coset c (leaf block c) has shift
 // s_c = 7 * w_N^bitrev_r(c);  pow_lo[c][l] = s_c^l (l < 4096 or n), pow_hi[c][h] = s_c^(4096 h).
@@ -38,22 +46,17 @@ struct GlCosetTables {
     const u64* pow_lo;  // [2^r][min(n,4096)]
     const u64* pow_hi;  // [2^r][max(1, n/4096)]
     const u64 *pow_lo_m, *pow_hi_m;  // the same times R (Montgomery form), for kernels_ntt16.hip
-    // log_n > 20 (ntt_outer.hpp): the coset tables of the 2^20-row sub-transforms (shift^R) and a work buffer of the context
+    // log_n > 22 (ntt_outer.hpp): the coset tables of the sub-transforms (shift^R) and the context's work buffer of this level - the
+    // ADDRESS of the context's pointer / size, read at the call: the block moves when it grows
     const GlCosetTables* sub;
-    u64* work;
-    size_t work_elems;
+    void* const* work;
+    const size_t* work_bytes;
 };
 
-// Column groups of the multi-pass transforms (kernels_ntt.hip): 0 = one launch per pass over all columns.  Defaults are the
-// measured optimum; gb_ctx_set_option("lde_group" / "pa_log_split" / "intt_group") overrides them for ablations.
-struct NttKnobs {
-    u32 lde_group;     // Goldilocks columns per PA -> PB group (BabyBear: twice as many)
-    u32 pa_log_split;  // log2 of the workgroups that share a PA tile's cosets
-    u32 intt_group;    // Goldilocks columns per inverse-transform group (BabyBear: twice as many)
-    u32 fuse_intt_lde; // 1: from_values at 2^20 rows runs the inverse transform's last pass and the LDE's strided pass as one kernel
-};
-const NttKnobs& ntt_knobs();
-NttKnobs& ntt_knobs_mut();
+// Columns per group of the inverse transform's passes from 2^18 rows up (BabyBear: twice as many): the scratch block of one group is
+// reused by the next and never leaves the Infinity Cache - measured -8 % on the three memory-bound passes (HISTORY.md, round 3); the
+// LDE passes are bound by VALU issue and run all columns per launch.
+static constexpr size_t INTT_GROUP = 16;
 
 // values on H_n (natural order) -> coefficients (natural order), in `coeffs` [ncols][n].
 // `scratch` must hold ncols*n elements. src may equal coeffs.
@@ -62,9 +65,6 @@ void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, co
 // any u64 representative -> the canonical one, in place (GB_INPUT_P3_REPR: p3-goldilocks' in-memory words)
 void gl_canonicalize(u64* p, size_t count, hipStream_t stream);
 
-// values -> coefficients (kept) -> LDE, with the last inverse pass and the first LDE pass fused where the shape allows (2^20 rows)
-void gl_from_values_columns(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
-                            hipStream_t stream);
 // coefficients [ncols][n] -> LDE [ncols][N] in LEAF order: lde[c][j] = P_c(7 * w_N^bitrev_logN(j))
 // (fri/oracle.rs:108-109 order, no transpose / bit-reverse pass needed afterwards).
 void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
@@ -100,14 +100,18 @@ struct BbNttTables {
     u32 log_n;
     const u32 *tw4096_fwd, *tw4096_inv, *tw_lo_fwd, *tw_hi_fwd, *tw_lo_inv, *tw_hi_inv;
     u32 n_inv;
-    const BbNttTables* sub;   // log_n > 20: see GlNttTables::sub
+    const u32* tw16k_inv;      // log_n 21, 22: see GlNttTables
+    const BbNttTables* wide;   // log_n 22: the tables of the 2^20-row transform (k_bb_lde_pa16x2w's twiddles)
+    const BbNttTables* sub;    // log_n > 22
+    u32 outer_bits;
 };
 struct BbCosetTables {
     u32 rate_bits;
     const u32 *pow_lo, *pow_hi;
-    const BbCosetTables* sub;  // log_n > 20: see GlCosetTables
-    u32* work;
-    size_t work_elems;
+    const BbCosetTables* fine;   // log_n 22: the cosets of the rate 2^(rate_bits + 2) over 2^20 rows, same shift (k_bb_lde_pa16x2w)
+    const BbCosetTables* sub;    // log_n > 22
+    void* const* work;
+    const size_t* work_bytes;
 };
 void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
 bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncols, size_t mont_cols, const BbNttTables& t, hipStream_t stream);

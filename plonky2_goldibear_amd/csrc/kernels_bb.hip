@@ -385,17 +385,15 @@ static inline u32 nblk(size_t n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 // radix-16 register kernels (kernels_bb16.hip); return false when the shape is not covered
 bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream,
                          u32* canonical_src = nullptr, size_t mont_cols = 0);
-bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, u32 log_split,
-                   hipStream_t stream);
-// column groups sized for the Infinity Cache: ntt_knobs() (kernels_ntt.hip)
+bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream);
 
 static void bb_intt_group(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream);
 // values -> coefficients from CANONICAL values (kernels_bb16.hip, k_bb_intt16_p1<true>): no conversion pass; the first mont_cols
 // columns of `vals` are left in Montgomery form, the rest canonical.  false: shape not covered (2^16..2^20 rows are), nothing done.
 bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncols, size_t mont_cols, const BbNttTables& t, hipStream_t stream) {
-    if (t.log_n < 16 || t.log_n > 20) return false;
-    const size_t g = 2 * (size_t)ntt_knobs().intt_group, n = (size_t)1 << t.log_n;
-    if (g == 0 || t.log_n < 18 || ncols <= g) {   // the grouping rule of bb_intt_columns: 0 = one launch per pass, groups from 2^18 rows
+    if (t.log_n < 16 || t.log_n > NTT_NATIVE_LOG) return false;
+    const size_t g = t.log_n > 20 ? (2 * INTT_GROUP) >> (t.log_n - 20) : 2 * INTT_GROUP, n = (size_t)1 << t.log_n;
+    if (t.log_n < 18 || ncols <= g) {   // the grouping rule of bb_intt_columns: groups from 2^18 rows
         bb_intt_columns_r16(nullptr, coeffs, scratch, ncols, t, stream, vals, mont_cols);
         return true;
     }
@@ -404,13 +402,13 @@ bool bb_intt_columns_canonical(u32* vals, u32* coeffs, u32* scratch, size_t ncol
     return true;
 }
 void bb_intt_columns(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream) {
-    if (t.log_n > 20) {   // one outer radix step around the 2^20-row passes (ntt_outer.hpp)
-        outer::intt_columns<BbF>(src, coeffs, scratch, ncols, t.log_n, t.tw_hi_inv, t.tw_lo_inv,
+    if (t.sub) {   // more than 2^22 rows: one outer radix step around the sub-transforms (ntt_outer.hpp)
+        outer::intt_columns<BbF>(src, coeffs, scratch, ncols, t.log_n, t.outer_bits, t.tw_hi_inv, t.tw_lo_inv,
                                  [&](const u32* s, u32* d, u32* scr, size_t nc) { bb_intt_columns(s, d, scr, nc, *t.sub, stream); }, stream);
         return;
     }
-    const size_t g = 2 * (size_t)ntt_knobs().intt_group, n = (size_t)1 << t.log_n;   // 4-byte words: twice Goldilocks' columns per group
-    if (g == 0 || t.log_n < 18 || ncols <= g) return bb_intt_group(src, coeffs, scratch, ncols, t, stream);
+    const size_t g = t.log_n > 20 ? (2 * INTT_GROUP) >> (t.log_n - 20) : 2 * INTT_GROUP, n = (size_t)1 << t.log_n;   // 4-byte words: twice Goldilocks' columns per group
+    if (t.log_n < 18 || ncols <= g) return bb_intt_group(src, coeffs, scratch, ncols, t, stream);
     for (size_t c0 = 0; c0 < ncols; c0 += g)
         bb_intt_group(src + c0 * n, coeffs + c0 * n, scratch, std::min(g, ncols - c0), t, stream);
 }
@@ -438,8 +436,8 @@ static void bb_intt_group(const u32* src, u32* coeffs, u32* scratch, size_t ncol
 void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream) {
     const u32 L = t.log_n, r = ct.rate_bits;
     if (!ncols) return;
-    if (L > 20) {
-        outer::lde_columns<BbF>(coeffs, lde, ncols, L, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.work, ct.work_elems,
+    if (t.sub) {
+        outer::lde_columns<BbF>(coeffs, lde, ncols, L, t.outer_bits, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, (u32*)*ct.work, *ct.work_bytes / sizeof(u32),
                                 [&](const u32* c, u32* o, size_t nc) { bb_lde_columns(c, o, nc, *t.sub, *ct.sub, stream); }, stream);
         return;
     }
@@ -448,17 +446,10 @@ void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables
                            ct.pow_lo);
         return;
     }
-    size_t g = 2 * (size_t)ntt_knobs().lde_group;
-    if (g == 0 || L < 18) g = ncols;
-    for (size_t c0 = 0; c0 < ncols; c0 += g) {
-        const size_t cc = std::min(g, ncols - c0);
-        const u32* cg = coeffs + (c0 << L);
-        u32* lg = lde + (c0 << (L + r));
-        if (!bb_lde_pa_r16(cg, lg, cc, t, ct, ntt_knobs().pa_log_split, stream))
-            hipLaunchKernelGGL(k_bb_lde_pa, dim3((u32)(cc << 8)), dim3(THREADS), 0, stream, cg, lg, L, r, t.tw4096_fwd,
-                               t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-        bb_lde_pb_r16(lg, cc << (r + L - 12), t, stream);
-    }
+    if (!bb_lde_pa_r16(coeffs, lde, ncols, t, ct, stream))
+        hipLaunchKernelGGL(k_bb_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd, t.tw_hi_fwd,
+                           t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+    bb_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
 }
 // as for Goldilocks (kernels_merkle.hip): below this many states the lane-per-state kernels are latency-bound
 static constexpr u64 BB_COOP_MAX_STATES = 16384;

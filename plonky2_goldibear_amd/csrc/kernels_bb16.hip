@@ -99,6 +99,37 @@ __device__ __forceinline__ constexpr u32 brevk(u32 x, int k) {
     return r;
 }
 
+namespace bbc {
+constexpr u32 W64 = cpow(bb::TWO_ADIC_GEN_27, 1u << 21), W64_INV = cpow(W64, 63);
+static_assert(cpow(W64, 4) == W16 && cpow(W64, 32) == bb::P - 1, "W64 must be the 64th root above W16");
+template <bool INV, int M>
+constexpr int tw64_centred() {
+    const u32 t = mont(cpow(INV ? W64_INV : W64, M));
+    return t > bb::P / 2 ? (int)t - (int)bb::P : (int)t;
+}
+}  // namespace bbc
+template <bool INV, int H, int O, int J = 0>
+__device__ __forceinline__ void layer64(u32* x) {   // one DIF layer of half-size H (32 or 16) on x[O .. O + 2H): twiddle w_64^(J * 32 / H)
+    if constexpr (J < H) {
+        const u32 a = x[O + J], b = x[O + J + H];
+        x[O + J] = bb::add(a, b);
+        if constexpr (J == 0) x[O + J + H] = bb::sub(a, b);
+        else {
+            const int r = bb::mul_signed((int)(a - b), bbc::tw64_centred<INV, J*(32 / H)>());
+            const u32 e = (u32)r + bb::P;
+            x[O + J + H] = e < (u32)r ? e : (u32)r;
+        }
+        layer64<INV, H, O, J + 1>(x);
+    }
+}
+// 32-point DFT in registers, natural input order, output X[k] in slot brev5(k): one DIF layer, then two 16-point blocks
+template <bool INV>
+__device__ __forceinline__ void dft32(u32 (&x)[32]) {
+    layer64<INV, 16, 0>(x);
+    dft16<INV>(*reinterpret_cast<u32(*)[16]>(&x[0]));
+    dft16<INV>(*reinterpret_cast<u32(*)[16]>(&x[16]));
+}
+
 __device__ __forceinline__ u32 bb_tw_split16(const u32* __restrict__ hi, const u32* __restrict__ lo, u32 e) {
     u32 eh = e >> 10, el = e & 1023;
     u32 w = lo[el];
@@ -179,15 +210,12 @@ template <u32 JW>
 __global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 L, u32 rate_bits,
                                                             const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
                                                             const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
-                                                            const u32* __restrict__ pow_hi, u32 log_split) {
+                                                            const u32* __restrict__ pow_hi) {
     constexpr u32 ROW = 16 * JW;  // one k_a1 slot: [a0][j]; 4-byte words, consecutive j -> consecutive banks
     __shared__ u32 sh[16 * ROW];
     constexpr u32 TPC = 4096 / JW;  // tiles per column
-    // log_split > 0: a tile's cosets are shared among 2^log_split workgroups 8 blocks apart (same XCD: kernels_ntt16.hip)
-    const u32 bt = ((blockIdx.x >> (3 + log_split)) << 3) | (blockIdx.x & 7);
-    const u32 split = (blockIdx.x >> 3) & ((1u << log_split) - 1);
-    const size_t col = bt / TPC;
-    const u32 tg = bt % TPC;
+    const size_t col = blockIdx.x / TPC;
+    const u32 tg = blockIdx.x % TPC;
     const u32 tid = threadIdx.x, hi4 = tid / JW, j = tid % JW;
     const u32 l = tg * JW + j;
     const size_t n = (size_t)1 << L;
@@ -195,12 +223,11 @@ __global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict
     u32 orig[16];
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
-    const u32 cpw = (1u << rate_bits) >> log_split;  // cosets per workgroup
     const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 16 * l);
     const u32 f0 = bb_tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // w_n^(k_a1 l)
     u32 tw[16];
     load_tw16(tw, tw4096, hi4 * 16);  // w_256^(k_a1 a0): the same for every coset
-    for (u32 c = split * cpw; c < (split + 1) * cpw; c++) {
+    for (u32 c = 0; c < (1u << rate_bits); c++) {
         const u32* ph = pow_hi + (size_t)c * 256 + hi4;
         u32 x[16];
 #pragma unroll
@@ -223,6 +250,170 @@ __global__ __launch_bounds__(16 * JW) void k_bb_lde_pa16x2(const u32* __restrict
         for (u32 k = 0; k < 16; k++) {  // k' = k: slot brev4(k), row position = brev8(k_a)
             out[(size_t)(hi4 * 16 + brev4(k)) << 12] = bb::mul(x[brev4(k)], f);
             if (k < 15) f = bb::mul(f, ratio);
+        }
+        __syncthreads();
+    }
+}
+
+// LA = 10 (2^22 rows, round 6; K = 2 is what the library launches): the strided pass as a 1024-point DFT over a' = 256 i1 + 16 a1 + a0
+// in THREE DIF stages - radix 4 over the top digit i1, twiddle w_1024^(k1 a), then the two radix-16 stages of k_bb_lde_pa16x2 once
+// per k1.  Output digit k1 is the LEAST significant one of k_a' = k1 + 4 k_a, so the rows of (c, k1) land in block brev_2(k1) of coset
+// block c: the 2^(r+2) blocks of 2^20 leaves ARE the cosets of a rate-2^(r+2) LDE of 2^20 rows, and everything after stage 0 is the
+// 2^20-row pass on that finer coset c' = 4 c + brev_2(k1) - output twiddle (s_c w_n^k1)^l w_m^(k_a l) from the tables of m = 2^20 rows
+// and of the rate r + 2.  One general multiplication per output more than at 2^20 rows, no extra pass over the data.
+// 1024 threads: lanes 0..31 are the 32 columns of a 128-byte row segment, lane bit 5 is digit bit b of i1, the sixteen waves are a0.
+// A thread holds i1 = b and b + 2 (32 words), does their butterfly itself and the second one ACROSS the wave's halves
+// (v_permlane32_swap hands every lane both operands: no LDS), and goes through the radix-16 stages twice (k1 = 2 b and 2 b + 1).
+// Measured against the two-stage form below (k_bb_lde_pa32<2>, same box, profiles/r06_large_sizes.txt): 13.0 against 14.8 ms per 167
+// columns - the other three (field, size) pairs go the other way.
+__device__ __forceinline__ void lane_pair32(u32 x, u32& lower, u32& upper) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // upper half of the first operand <-> lower half of the second
+    lower = r[0];   // (the builtin, not inline asm: the swap needs wait states after a vector write of its operands, which the compiler's
+    upper = r[1];   //  hazard recognizer inserts for its own instructions only - the asm form returned stale halves on the GPU)
+}
+template <int K>
+__global__ __launch_bounds__(1024) void k_bb_lde_pa16x2w(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 rate_bits,
+                                                          const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                          const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
+                                                          const u32* __restrict__ pow_hi) {
+    constexpr u32 R = 1u << K, L = 20 + K, W = 64, SLOT = 16 * W;   // LDS: [k_a1 slot][a0][b][j]
+    __shared__ u32 sh[16 * SLOT];
+    __shared__ u32 tw0[R * 256];   // the stage-0 twiddles w_{256R}^(k a), [k][a]: in LDS so that they are not 32 more live registers
+    const size_t col = blockIdx.x >> 7;
+    const u32 tg = blockIdx.x & 127;
+    const u32 tid = threadIdx.x, hi4 = tid >> 6, jl = tid & 63, b = jl >> 5, j = jl & 31;
+    if (tid < R * 256) tw0[tid] = tw4096[((tid >> 8) * (tid & 255)) << (4 - K)];
+    const u32 l = tg * 32 + j;
+    const size_t n = (size_t)1 << L;
+    const u32* cin = coeffs + col * n + l;
+    constexpr u32 H = K == 1 ? 1 : 2;   // digits i1 a thread holds: b (+ 2)
+    u32 orig[H][16];
+#pragma unroll
+    for (u32 h = 0; h < H; h++)
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) orig[h][a1] = cin[(size_t)((b + 2 * h) * 256 + a1 * 16 + hi4) << 12];
+    const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 16 * l);          // tables of m = 2^20 rows
+    const u32 f0 = bb_tw_split16(tw_hi, tw_lo, brev4(hi4) * l);
+    u32 tw[16];
+    load_tw16(tw, tw4096, hi4 * 16);  // w_256^(k_a1 a0)
+    // lane mask of the digit bit, opaque to the optimiser: written as selects on a lane-varying bool the butterflies below made the
+    // compiler spill registers (it unswitched around them); as bit blends (v_bfi) they cost the same and spill nothing
+    u32 m5 = b ? ~0u : 0u;
+    asm("" : "+v"(m5));
+    __syncthreads();                  // tw0 visible
+    for (u32 c = 0; c < (1u << rate_bits); c++) {
+        const u32* ph = pow_hi + (size_t)c * (256 * R) + hi4;
+        u32 y[H][16];
+#pragma unroll
+        for (u32 h = 0; h < H; h++)
+#pragma unroll
+            for (u32 a1 = 0; a1 < 16; a1++) y[h][a1] = bb::mul(orig[h][a1], ph[(b + 2 * h) * 256 + a1 * 16]);  // s_c^(4096 a')
+#pragma unroll
+        for (u32 a1 = 0; a1 < 16; a1++) {
+            u32 p, q;
+            if constexpr (K == 2) {   // (x_b, x_(b+2)) in the thread: sum for the even k1, difference (times w_4 where b = 1) for the odd ones
+                const u32 sm = bb::add(y[0][a1], y[1][a1]), d = bb::sub(y[0][a1], y[1][a1]);
+                const u32 dw = bb::mul(d, bbc::tw<false, 4>());
+                y[0][a1] = sm;
+                y[1][a1] = (d & ~m5) | (dw & m5);
+                lane_pair32(y[1][a1], p, q);
+                const u32 s1 = bb::add(p, q), d1 = bb::sub(p, q);
+                y[1][a1] = (s1 & ~m5) | (d1 & m5);          // k1 = 2 b + 1
+            }
+            lane_pair32(y[0][a1], p, q);
+            const u32 s0 = bb::add(p, q), d0 = bb::sub(p, q);
+            y[0][a1] = (s0 & ~m5) | (d0 & m5);              // k1 = b (K = 1) / 2 b (K = 2)
+        }
+#pragma nounroll
+        for (u32 h = 0; h < H; h++) {   // (a real loop: unrolled, the two passes' addresses and twiddles were live together and spilled)
+            const u32 k1 = K == 1 ? b : 2 * b + h;
+            const u32 cf = c * R + (K == 1 ? b : b + 2 * h);   // brev_K(k1)
+            u32 x[16];
+#pragma unroll
+            for (u32 a1 = 0; a1 < 16; a1++) x[a1] = bb::mul(y[0][a1], tw0[k1 * 256 + a1 * 16 + hi4]);   // w_{256R}^(k1 a) (k1 = 0: 1)
+            if constexpr (K == 2) {
+#pragma unroll
+                for (u32 a1 = 0; a1 < 16; a1++) y[0][a1] = y[1][a1];
+            }
+            const u32 sl = pow_lo[(size_t)cf * 4096 + l];
+            dft16<false>(x);
+#pragma unroll
+            for (u32 s = 0; s < 16; s++) sh[s * SLOT + tid] = s ? bb::mul(x[s], tw[s]) : x[s];  // [k_a1 slot][a0][b][j]
+            __syncthreads();
+#pragma unroll
+            for (u32 a0 = 0; a0 < 16; a0++) x[a0] = sh[hi4 * SLOT + a0 * W + jl];
+            dft16<false>(x);
+            u32* out = lde + (col << (L + rate_bits)) + ((size_t)cf << 20) + l;
+            u32 f = bb::mul(sl, f0);
+#pragma unroll
+            for (u32 k = 0; k < 16; k++) {
+                out[(size_t)(hi4 * 16 + brev4(k)) << 12] = bb::mul(x[brev4(k)], f);
+                if (k < 15) f = bb::mul(f, ratio);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// LA = 8 + K (2^21 rows: K = 1 is what the library launches; see k_gl_lde_pa32): two stages with 32 points per thread - 32 x 16 at
+// 2^21 rows (512 threads: 16 a0 x 32 columns), 32 x 32 at 2^22 rows (1024 threads); the multiplications per output are those of the
+// 2^20-row pass plus the fifteen constant twiddles of the extra butterfly layer per 32 points.
+template <int K>
+__global__ __launch_bounds__(256 << K, 4) void k_bb_lde_pa32(const u32* __restrict__ coeffs, u32* __restrict__ lde, u32 rate_bits,
+                                                          const u32* __restrict__ tw4096, const u32* __restrict__ tw_hi,
+                                                          const u32* __restrict__ tw_lo, const u32* __restrict__ pow_lo,
+                                                          const u32* __restrict__ pow_hi) {
+    constexpr u32 L = 20 + K, A0 = 8u << K, NT = 256u << K, SLOT = NT, ROWS = 256u << K, JW = 32;
+    __shared__ u32 sh[32 * SLOT];      // [k_a1 slot][a0][j]
+    __shared__ u32 twl[ROWS];          // w_ROWS^m: the inter-stage twiddles
+    const size_t col = blockIdx.x >> 7;
+    const u32 tg = blockIdx.x & 127;
+    const u32 tid = threadIdx.x, hi = tid >> 5, j = tid & 31;
+    const u32 l = tg * JW + j;
+    const size_t n = (size_t)1 << L;
+    const u32* cin = coeffs + col * n + l;
+    for (u32 i = tid; i < ROWS; i += NT) twl[i] = tw4096[i << (4 - K)];
+    u32 orig[32];
+#pragma unroll
+    for (u32 a1 = 0; a1 < 32; a1++) orig[a1] = cin[(size_t)(a1 * A0 + hi) << 12];
+    __syncthreads();
+    const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 32 * l);   // w_n^(32 l)
+    for (u32 c = 0; c < (1u << rate_bits); c++) {
+        const u32* ph = pow_hi + (size_t)c * ROWS + hi;
+        u32 x[32];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 32; a1++) x[a1] = bb::mul(orig[a1], ph[a1 * A0]);  // s_c^(4096 a'), a' = a1 A0 + a0
+        const u32 sl = pow_lo[(size_t)c * 4096 + l];
+        dft32<false>(x);
+#pragma unroll
+        for (u32 s = 0; s < 32; s++) sh[s * SLOT + tid] = s ? bb::mul(x[s], twl[(brevk(s, 5) * hi) & (ROWS - 1)]) : x[s];
+        __syncthreads();
+        u32* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+        if constexpr (K == 2) {
+#pragma unroll
+            for (u32 a0 = 0; a0 < 32; a0++) x[a0] = sh[hi * SLOT + a0 * JW + j];
+            dft32<false>(x);
+            u32 f = bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, brevk(hi, 5) * l));
+#pragma unroll
+            for (u32 k = 0; k < 32; k++) {
+                out[(size_t)(hi * 32 + brevk(k, 5)) << 12] = bb::mul(x[brevk(k, 5)], f);
+                if (k < 31) f = bb::mul(f, ratio);
+            }
+        } else {
+#pragma unroll
+            for (u32 u = 0; u < 2; u++) {
+                const u32 slot = hi + 16 * u;
+                u32 y[16];
+#pragma unroll
+                for (u32 a0 = 0; a0 < 16; a0++) y[a0] = sh[slot * SLOT + a0 * JW + j];
+                dft16<false>(y);
+                u32 f = bb::mul(sl, bb_tw_split16(tw_hi, tw_lo, brevk(slot, 5) * l));
+#pragma unroll
+                for (u32 k = 0; k < 16; k++) {
+                    out[(size_t)(slot * 16 + brev4(k)) << 12] = bb::mul(y[brev4(k)], f);
+                    if (k < 15) f = bb::mul(f, ratio);
+                }
+            }
         }
         __syncthreads();
     }
@@ -436,6 +627,34 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p2s(const u32* __restrict
         dst[cbase + ((size_t)brevk(s, K) << 16) + ((size_t)ka << 8) + c] = s ? bb::mul(x[s], tw[s]) : x[s];
 }
 
+// P2 for LB = 5, 6 (2^21 and 2^22 rows, round 6): the middle pass as a radix-32 / radix-64 DFT over b in registers - one or two DIF
+// layers with compile-time twiddles w_64^-j, then 16-point blocks.  src [k_a][b][c] -> dst [k_b][k_a][c]; tw16k = w_{2^14}^-j, j < 2^14.
+template <int LB>
+__global__ __launch_bounds__(THREADS) void k_bb_intt16_p2w(const u32* __restrict__ src, u32* __restrict__ dst, const u32* __restrict__ tw16k) {
+    constexpr u32 L = 16 + LB, R = 1u << LB;
+    const size_t col = blockIdx.x >> 8;
+    const u32 ga = (blockIdx.x >> 4) & 15, gc = blockIdx.x & 15;
+    const size_t cbase = col << L;
+    const u32 ka = 16 * ga + (threadIdx.x >> 4), c = 16 * gc + (threadIdx.x & 15);
+    u32 x[R];
+#pragma unroll
+    for (u32 b = 0; b < R; b++) x[b] = src[cbase + ((size_t)ka << (8 + LB)) + ((size_t)b << 8) + c];
+    if constexpr (LB == 6) {
+        layer64<true, 32, 0>(x);
+        layer64<true, 16, 0>(x);
+        layer64<true, 16, 32>(x);
+    } else {
+        layer64<true, 16, 0>(x);
+    }
+#pragma unroll
+    for (u32 o = 0; o < R; o += 16) dft16<true>(*reinterpret_cast<u32(*)[16]>(&x[o]));
+#pragma unroll
+    for (u32 s = 0; s < R; s++) {
+        const u32 kb = brevk(s, LB);
+        dst[cbase + ((size_t)kb << 16) + ((size_t)ka << 8) + c] = s ? bb::mul(x[s], tw16k[(kb * c) << (6 - LB)]) : x[s];   // w_{2^(8+LB)}^-(c k_b)
+    }
+}
+
 // P3: grid = ncols * 2^LB * 16; tile 16 k_a x 256 c (c = 16 c1 + c0); src [k_b][k_a][c];
 // dst natural k = k_a + 256 k_b + 2^(8+LB) k_c, scaled by n^-1
 __global__ __launch_bounds__(THREADS) void k_bb_intt16_p3(const u32* __restrict__ src, u32* __restrict__ dst, BbInv16Geom g,
@@ -477,7 +696,7 @@ __global__ __launch_bounds__(THREADS) void k_bb_intt16_p3(const u32* __restrict_
 bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols, const BbNttTables& t, hipStream_t stream,
                          u32* canonical_src, size_t mont_cols) {
     const u32 L = t.log_n;
-    if (L < 16 || L > 20) return false;
+    if (L < 16 || L > 22) return false;
     BbInv16Geom g{L, L - 16};
     const u32 LL = g.LB + 8;
     u32* p1_dst = g.LB ? coeffs : scratch;
@@ -489,7 +708,9 @@ bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols
         hipLaunchKernelGGL(k_bb_intt16_p1<false>, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv,
                            t.tw_hi_inv, t.tw_lo_inv, (u32*)nullptr, 0u);
     const dim3 g2((u32)(ncols << 8));
-    if (g.LB == 4) hipLaunchKernelGGL(k_bb_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv);
+    if (g.LB == 6) hipLaunchKernelGGL(k_bb_intt16_p2w<6>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw16k_inv);
+    else if (g.LB == 5) hipLaunchKernelGGL(k_bb_intt16_p2w<5>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw16k_inv);
+    else if (g.LB == 4) hipLaunchKernelGGL(k_bb_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv);
     else if (g.LB == 3) hipLaunchKernelGGL(k_bb_intt16_p2s<3>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
     else if (g.LB == 2) hipLaunchKernelGGL(k_bb_intt16_p2s<2>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
     else if (g.LB == 1) hipLaunchKernelGGL(k_bb_intt16_p2s<1>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv);
@@ -498,13 +719,22 @@ bool bb_intt_columns_r16(const u32* src, u32* coeffs, u32* scratch, size_t ncols
     return true;
 }
 
-bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, u32 log_split,
-                   hipStream_t stream) {
+bool bb_lde_pa_r16(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables& t, const BbCosetTables& ct, hipStream_t stream) {
     const u32 L = t.log_n;
     if (L == 20) {
-        if (log_split > ct.rate_bits) log_split = ct.rate_bits;
-        hipLaunchKernelGGL(k_bb_lde_pa16x2<32>, dim3((u32)(ncols << (7 + log_split))), dim3(512), 0, stream, coeffs, lde, L, ct.rate_bits,
-                           t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi, log_split);
+        hipLaunchKernelGGL(k_bb_lde_pa16x2<32>, dim3((u32)(ncols << 7)), dim3(512), 0, stream, coeffs, lde, L, ct.rate_bits,
+                           t.tw4096_fwd, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        return true;
+    }
+    if (L == 21 || L == 22) {
+        if (L == 21) {
+            hipLaunchKernelGGL(k_bb_lde_pa32<1>, dim3((u32)(ncols << 7)), dim3(512), 0, stream, coeffs, lde, ct.rate_bits, t.tw4096_fwd,
+                               t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+        } else {   // twiddles of the 2^20-row transform (t.wide), cosets of the rate r + 2 (ct.fine), s_c^(4096 a') of this size
+            if (!t.wide || !ct.fine) return false;
+            hipLaunchKernelGGL(k_bb_lde_pa16x2w<2>, dim3((u32)(ncols << 7)), dim3(1024), 0, stream, coeffs, lde, ct.rate_bits, t.tw4096_fwd,
+                               t.wide->tw_hi_fwd, t.wide->tw_lo_fwd, ct.fine->pow_lo, ct.pow_hi);
+        }
         return true;
     }
 #define GB_PAS(KK)                                                                                                        \

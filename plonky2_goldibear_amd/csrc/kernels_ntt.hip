@@ -240,8 +240,7 @@ __global__ __launch_bounds__(256) void k_gl_canonicalize(u64* __restrict__ p, si
 
 // radix-16 register kernels (kernels_ntt16.hip); return false when the shape is not covered
 bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
-bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, u32 log_split,
-                   hipStream_t stream);
+bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, hipStream_t stream);
 void gl_lde_pb_r16(u64* lde, size_t ntiles, const GlNttTables& t, hipStream_t stream);
 
 void gl_canonicalize(u64* p, size_t count, hipStream_t stream) {
@@ -264,29 +263,16 @@ static InvGeom inv_geom(u32 L) {
     return g;
 }
 
-// Column groups (2^18 rows and up): the passes of one transform can run group by group, so that what one pass writes is still in
-// the 256 MiB Infinity Cache when the next pass reads it - a 2^23-point LDE column is 64 MiB between PA and PB, a 2^20-row inverse
-// transform 8 MiB per column and buffer.  Measured (profiles/r03_ntt_column_group_sweep_*.txt, 135 x 2^20 Goldilocks): the LDE
-// passes do NOT gain from it - they are bound by VALU issue and latency, not by HBM, and small groups only add launch tails
-// (8.55 ms with all columns per launch, 8.7-14.5 ms in groups of 16..1) - so the LDE default stays "all columns"; the three
-// memory-bound passes of the inverse transform gain 8 % in groups of 16 columns (1.49 -> 1.36 ms).  The knobs remain for ablations
-// (gb_ctx_set_option).
-NttKnobs& ntt_knobs_mut() {   // gb_ctx_set_option("lde_group" / "pa_log_split" / "intt_group" / "fuse_intt_lde"): process-wide
-    static NttKnobs k{0, 0, 16, 0};   // fuse_intt_lde off: measured no faster (profiles/r05_ntt_fused_p3_pa_ablation_goldilocks.txt)
-    return k;
-}
-const NttKnobs& ntt_knobs() { return ntt_knobs_mut(); }
-
 static void gl_intt_group(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream);
 
 void gl_intt_columns(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream) {
-    if (t.log_n > 20) {   // one outer radix step around the 2^20-row passes (ntt_outer.hpp)
-        outer::intt_columns<GlF>(src, coeffs, scratch, ncols, t.log_n, t.tw_hi_inv, t.tw_lo_inv,
+    if (t.sub) {   // more than 2^22 rows: one outer radix step around the sub-transforms (ntt_outer.hpp)
+        outer::intt_columns<GlF>(src, coeffs, scratch, ncols, t.log_n, t.outer_bits, t.tw_hi_inv, t.tw_lo_inv,
                                  [&](const u64* s, u64* d, u64* scr, size_t nc) { gl_intt_columns(s, d, scr, nc, *t.sub, stream); }, stream);
         return;
     }
-    const size_t g = ntt_knobs().intt_group, n = (size_t)1 << t.log_n;
-    if (g == 0 || t.log_n < 18 || ncols <= g) return gl_intt_group(src, coeffs, scratch, ncols, t, stream);
+    const size_t g = t.log_n > 20 ? INTT_GROUP >> (t.log_n - 20) : INTT_GROUP, n = (size_t)1 << t.log_n;   // the same bytes per group from 2^20 rows up
+    if (t.log_n < 18 || ncols <= g) return gl_intt_group(src, coeffs, scratch, ncols, t, stream);
     for (size_t c0 = 0; c0 < ncols; c0 += g)   // the scratch block of one group is reused by the next: it never leaves the cache
         gl_intt_group(src + c0 * n, coeffs + c0 * n, scratch, std::min(g, ncols - c0), t, stream);
 }
@@ -313,34 +299,12 @@ static void gl_intt_group(const u64* src, u64* coeffs, u64* scratch, size_t ncol
                        g, t.tw4096_inv, t.n_inv);
 }
 
-bool gl_intt_pa_fused_r16(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
-                          hipStream_t stream);
-
-// from_values in one go: values -> coefficients (kept: a required output) -> LDE.  With the option "fuse_intt_lde" = 1 the inverse
-// transform's last pass and the LDE's strided pass are ONE kernel per group of columns at 2^20 rows (k_gl_intt16_p3_pa16x2: the
-// coefficient tile goes on in registers, PA's re-read of the column and a launch disappear: 31 -> 30 n s of physical traffic per
-// column).  Round 5 built and measured it: 4.70-4.71 ms fused against 4.24-4.29 (PA) + 0.47 (P3) ms apart, the whole NTT 10.42-10.44
-// against 10.34-10.40 ms per 135 columns - the strided pass is bound by VALU issue, not by the read it saves.  Default: off.
-void gl_from_values_columns(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
-                            hipStream_t stream) {
-    const u32 L = t.log_n, r = ct.rate_bits;
-    if (L != 20 || !ntt_knobs().fuse_intt_lde || ntt_knobs().lde_group || ntt_knobs().pa_log_split) {
-        gl_intt_columns(src, coeffs, scratch, ncols, t, stream);
-        gl_lde_columns(coeffs, lde, ncols, t, ct, stream);
-        return;
-    }
-    const size_t g = ntt_knobs().intt_group ? ntt_knobs().intt_group : ncols, n = (size_t)1 << L;
-    for (size_t c0 = 0; c0 < ncols; c0 += g)   // the scratch block of one group is reused by the next: it never leaves the cache
-        gl_intt_pa_fused_r16(src + c0 * n, coeffs + c0 * n, lde + (c0 << (L + r)), scratch, std::min(g, ncols - c0), t, ct, stream);
-    gl_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
-}
-
 void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
                     hipStream_t stream) {
     const u32 L = t.log_n, r = ct.rate_bits;
     if (ncols == 0) return;
-    if (L > 20) {
-        outer::lde_columns<GlF>(coeffs, lde, ncols, L, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.work, ct.work_elems,
+    if (t.sub) {
+        outer::lde_columns<GlF>(coeffs, lde, ncols, L, t.outer_bits, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, (u64*)*ct.work, *ct.work_bytes / sizeof(u64),
                                 [&](const u64* c, u64* o, size_t nc) { gl_lde_columns(c, o, nc, *t.sub, *ct.sub, stream); }, stream);
         return;
     }
@@ -349,17 +313,12 @@ void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables
                            t.tw4096_fwd, ct.pow_lo);
         return;
     }
-    size_t g = ntt_knobs().lde_group;
-    if (g == 0 || L < 18) g = ncols;
-    for (size_t c0 = 0; c0 < ncols; c0 += g) {
-        const size_t cc = std::min(g, ncols - c0);
-        const u64* cg = coeffs + (c0 << L);
-        u64* lg = lde + (c0 << (L + r));
-        if (!gl_lde_pa_r16(cg, lg, cc, t, ct, ntt_knobs().pa_log_split, stream))
-            hipLaunchKernelGGL(k_gl_lde_pa, dim3((u32)(cc << 8)), dim3(THREADS), 0, stream, cg, lg, L, r, t.tw4096_fwd,
-                               t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
-        gl_lde_pb_r16(lg, cc << (r + L - 12), t, stream);
-    }
+    // both passes over all columns per launch: they are bound by VALU issue, not by HBM (column groups sized for the Infinity Cache
+    // measured slower in every setting, HISTORY.md round 3)
+    if (!gl_lde_pa_r16(coeffs, lde, ncols, t, ct, stream))
+        hipLaunchKernelGGL(k_gl_lde_pa, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, r, t.tw4096_fwd, t.tw_hi_fwd,
+                           t.tw_lo_fwd, ct.pow_lo, ct.pow_hi);
+    gl_lde_pb_r16(lde, ncols << (r + L - 12), t, stream);
 }
 
 }  // namespace gbk

@@ -122,6 +122,33 @@ __device__ __forceinline__ constexpr u32 brevk(u32 x, int k) {
     return r;
 }
 
+// (a - b) * w_64^(+-M): w_64 = 2^39 (w_64^4 = w_16 = 2^156), w_64^-1 = 2^153 - shifts like the roots of the 16-point DFT
+template <bool INV, int M>
+__device__ __forceinline__ u64 sub_twiddle64(u64 a, u64 b) {
+    constexpr int e = (INV ? 153 * M : 39 * M) % 192;
+    if constexpr (e == 0) return gl::sub(a, b);
+    else if constexpr (e < 96) return mul_pow2<e>(gl::sub(a, b));
+    else return mul_pow2<e - 96>(gl::sub(b, a));  // 2^96 = -1
+}
+// one DIF layer of half-size H (32 or 16) on x[O .. O + 2H): twiddle w_{2H}^J = w_64^(J * 32 / H)
+template <bool INV, int H, int O, int J = 0>
+__device__ __forceinline__ void layer64(u64* x) {
+    if constexpr (J < H) {
+        const u64 s = gl::add(x[O + J], x[O + J + H]);
+        x[O + J + H] = sub_twiddle64<INV, J*(32 / H)>(x[O + J], x[O + J + H]);
+        x[O + J] = s;
+        layer64<INV, H, O, J + 1>(x);
+    }
+}
+
+// 32-point DFT in registers, natural input order, output X[k] in slot brev5(k): one DIF layer, then two 16-point blocks
+template <bool INV>
+__device__ __forceinline__ void dft32(u64 (&x)[32]) {
+    layer64<INV, 16, 0>(x);
+    dft16<INV>(*reinterpret_cast<u64(*)[16]>(&x[0]));
+    dft16<INV>(*reinterpret_cast<u64(*)[16]>(&x[16]));
+}
+
 __device__ __forceinline__ u64 tw_split16(const u64* __restrict__ hi, const u64* __restrict__ lo, u32 e) {
     u32 eh = e >> 10, el = e & 1023;
     u64 w = lo[el];
@@ -141,50 +168,6 @@ __device__ __forceinline__ void load_tw16(u64 (&tw)[16], const u64* __restrict__
 // The inter-stage twiddles cost as much as the butterflies here (ablations in DESIGN.md: without their loads and products the pass
 // runs 33 % faster, close to a plain copy): the first stage reads them from a copy of the table laid out [slot][tid] (coalesced),
 // the second from a 256-entry table in LDS.
-#ifdef GB_PB_OCC5
-// Experiment (round 5, NOT the product): five workgroups per CU instead of four - the tile in exactly 32 KB of LDS (no row padding:
-// the transposes rotate columns within their 16-blocks instead), the stage-2 twiddles read from the table (L2) instead of a 2 KB
-// LDS copy, 96 VGPRs, no scratch.  Bit-identical; measured 5.36 ms against 4.72 ms per 135 columns (same box, alternating,
-// tools/ab_kernel_times.sh pbbase pbocc5): the fifth workgroup does not pay for the stage-2 twiddles coming from L2.
-__global__ __launch_bounds__(THREADS, 5) void k_gl_lde_pb16(u64* __restrict__ lde, const u64* __restrict__ tw4096) {
-    __shared__ u64 sh[16 * 256];
-    u64* p = lde + ((size_t)blockIdx.x << 12);
-    const u32 tid = threadIdx.x;
-    u64 x[16];
-#pragma unroll
-    for (u32 d = 0; d < 16; d++) x[d] = p[d * 256 + tid];
-    {
-        u64 tw[16];
-#pragma unroll
-        for (u32 s = 1; s < 16; s++) tw[s] = tw4096[4096 + s * 256 + tid];
-        dft16<false>(x);
-#pragma unroll
-        for (u32 s = 0; s < 16; s++) sh[s * 256 + tid] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
-    }
-    __syncthreads();
-    const u32 hi4 = tid >> 4, lo4 = tid & 15;
-#pragma unroll
-    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 256 + d * 16 + lo4];
-    dft16<false>(x);
-    __syncthreads();
-#pragma unroll
-    for (u32 s = 0; s < 16; s++)   // [k2 slot][d0][(k1 slot + d0) & 15]
-        sh[hi4 * 256 + lo4 * 16 + ((s + lo4) & 15)] = s ? gl::mul_mont(x[s], tw4096[((brev4(s) * lo4) & 255) * 16]) : x[s];
-    __syncthreads();
-#pragma unroll
-    for (u32 d = 0; d < 16; d++) x[d] = sh[hi4 * 256 + d * 16 + ((lo4 + d) & 15)];
-    dft16<false>(x);
-    __syncthreads();
-#pragma unroll
-    for (u32 s = 0; s < 16; s++) sh[tid * 16 + ((s + tid) & 15)] = x[s];
-    __syncthreads();
-#pragma unroll
-    for (u32 it = 0; it < 16; it++) {
-        const u32 q = it * 256 + tid;
-        p[q] = sh[(q >> 4) * 16 + (((q & 15) + (q >> 4)) & 15)];
-    }
-}
-#else
 __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, const u64* __restrict__ tw4096) {
     __shared__ u64 sh[16 * 272];
     __shared__ u64 tw2[256];  // the stage-2 twiddles as the threads read them: tw2[s][d0] = w_256^(brev4(s) d0) - consecutive lanes,
@@ -229,7 +212,6 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
     }
 }
 
-#endif
 // ------------------------------------------------------------------ LDE pass A
 // LA = 8: grid = ncols * 256, tile 256 rows (a = 16 a1 + a0) x 16 columns.  Per coset: scale by s^(4096 a),
 // two radix-16 stages over a, twiddle w_n^(k_a l) s^l, in-place DIF row order.
@@ -237,19 +219,14 @@ __global__ __launch_bounds__(THREADS) void k_gl_lde_pb16(u64* __restrict__ lde, 
 // wins everywhere else - same box, tools/ab_kernel_times.sh, profiles/r04_ab_kernel_times.txt.)
 // 3 waves/SIMD (<= 168 VGPRs, no spills): the tile's 16 coefficients per thread stay in registers across the coset
 // loop, so the coefficients cross HBM once (re-reading them per coset measured the same time but 7x the fetch bytes).
-// log_split > 0: the 2^rate_bits cosets of a tile are shared among 2^log_split workgroups (a column alone then fills the chip:
-// 256 << log_split workgroups), placed 8 blocks apart - blocks b and b + 8 share an XCD, so the tile's coefficients are re-read from
-// that XCD's L2.
 __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 L, u32 rate_bits,
                                                            const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
                                                            const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
-                                                           const u64* __restrict__ pow_hi, u32 log_split) {
+                                                           const u64* __restrict__ pow_hi) {
     __shared__ u64 sh[16 * 272];
     __shared__ u64 tw256[256];  // w_256^m: the stage-1 twiddles, read from LDS at their use (keeps 30 VGPRs free)
-    const u32 bt = ((blockIdx.x >> (3 + log_split)) << 3) | (blockIdx.x & 7);  // (column, tile) index
-    const u32 split = (blockIdx.x >> 3) & ((1u << log_split) - 1);
-    const size_t col = bt >> 8;
-    const u32 tg = bt & 255;
+    const size_t col = blockIdx.x >> 8;
+    const u32 tg = blockIdx.x & 255;
     const u32 tid = threadIdx.x, hi4 = tid >> 4, j = tid & 15;
     const u32 l = (tg << 4) + j;
     const size_t n = (size_t)1 << L;
@@ -259,10 +236,9 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
 #pragma unroll
     for (u32 a1 = 0; a1 < 16; a1++) orig[a1] = cin[(size_t)(a1 * 16 + hi4) << 12];  // stage-1 thread = (a0 = hi4, j)
     __syncthreads();  // tw256 visible
-    const u32 cpw = (1u << rate_bits) >> log_split;  // cosets per workgroup
     const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
     const u64 f0 = tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // w_n^(k_a1 l)
-    for (u32 c = split * cpw; c < (split + 1) * cpw; c++) {
+    for (u32 c = 0; c < (1u << rate_bits); c++) {
         const u64* ph = pow_hi + (size_t)c * 256 + hi4;
         u64 x[16];
 #pragma unroll
@@ -285,6 +261,78 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
         for (u32 k = 0; k < 16; k++) {  // k' = k: slot brev4(k), row position = brev8(k_a)
             out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul_mont<true>(x[brev4(k)], f);
             if (k < 15) f = gl::mul_mont_lazy<true>(f, ratio);
+        }
+        __syncthreads();
+    }
+}
+
+// LA = 8 + K, K = 1, 2 (2^21 and 2^22 rows, round 6; round 5 ran a de-interleave pass and a combine pass around the 2^20-row kernels):
+// the (256 R)-point strided DFT over a' as TWO stages with 32 points per thread - 32 x 16 at 2^21 rows (256 threads: radix 32 over a1,
+// then two radix-16 DFTs over a0 per thread), 32 x 32 at 2^22 rows (512 threads).  Every root of unity of order <= 64 is a shift, so
+// the radix-32 DFT costs one butterfly layer more and NO general multiplication more: the multiplications per output are those of
+// the 2^20-row pass (scale, inter-stage twiddle, output twiddle and its chain).  The price is registers - 32 coefficients + 32
+// working values per thread = two waves per SIMD - and a tile of 64 / 128 KB of LDS: 1.24x / 1.47x the 2^20-row pass per element.
+// (The alternative measured on the same box, profiles/r06_large_sizes.txt: 16 points per thread, four waves per SIMD, a radix-R stage
+// over the top digit as a butterfly ACROSS LANES - v_permlane16/32_swap - and one general twiddle more per output: 1.27x / 1.58x,
+// its instruction count.  BabyBear's 2^22-row pass is that form, kernels_bb16.hip: its words are half as wide.)
+template <int K>
+__global__ __launch_bounds__(128 << K, 2) void k_gl_lde_pa32(const u64* __restrict__ coeffs, u64* __restrict__ lde, u32 rate_bits,
+                                                             const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
+                                                             const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
+                                                             const u64* __restrict__ pow_hi) {
+    constexpr u32 L = 20 + K, A0 = 8u << K /* values of a0: 16 / 32 */, LA0 = 3 + K, NT = 128u << K, SLOT = NT + 16, ROWS = 256u << K;
+    __shared__ u64 sh[32 * SLOT];      // [k_a1 slot][a0][j], slots padded by 16 words
+    __shared__ u64 twl[ROWS];          // w_ROWS^m: the inter-stage twiddles
+    const size_t col = blockIdx.x >> 8;
+    const u32 tg = blockIdx.x & 255;
+    const u32 tid = threadIdx.x, hi = tid >> 4, j = tid & 15;   // stage 1: a0 = hi; stage 2: slot(s) from hi
+    const u32 l = (tg << 4) + j;
+    const size_t n = (size_t)1 << L;
+    const u64* cin = coeffs + col * n + l;
+    for (u32 i = tid; i < ROWS; i += NT) twl[i] = tw4096[i << (4 - K)];
+    u64 orig[32];
+#pragma unroll
+    for (u32 a1 = 0; a1 < 32; a1++) orig[a1] = cin[(size_t)(a1 * A0 + hi) << 12];
+    __syncthreads();  // twl visible
+    const u64 ratio = tw_split16(tw_hi, tw_lo, 32 * l);   // w_n^(32 l)
+    for (u32 c = 0; c < (1u << rate_bits); c++) {
+        const u64* ph = pow_hi + (size_t)c * ROWS + hi;
+        u64 x[32];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 32; a1++) x[a1] = ph[a1 * A0];  // s_c^(4096 a'), a' = a1 A0 + a0
+        const u64 sl = pow_lo[(size_t)c * 4096 + l];
+#pragma unroll
+        for (u32 a1 = 0; a1 < 32; a1++) x[a1] = gl::mul_mont<true>(orig[a1], x[a1]);
+        dft32<false>(x);
+#pragma unroll
+        for (u32 s = 0; s < 32; s++) sh[s * SLOT + tid] = s ? gl::mul_mont<true>(x[s], twl[(brevk(s, 5) * hi) & (ROWS - 1)]) : x[s];  // w_ROWS^(k_a1 a0)
+        __syncthreads();
+        u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
+        if constexpr (K == 2) {   // stage 2 thread = (k_a1 slot = hi, j): radix 32 over a0
+#pragma unroll
+            for (u32 a0 = 0; a0 < 32; a0++) x[a0] = sh[hi * SLOT + a0 * 16 + j];
+            dft32<false>(x);
+            u64 f = gl::mul_mont_lazy<true>(sl, tw_split16(tw_hi, tw_lo, brevk(hi, 5) * l));   // s^l w_n^(k_a1 l)
+#pragma unroll
+            for (u32 k = 0; k < 32; k++) {  // k_a' = k_a1 + 32 k: row position brev10(k_a') = hi * 32 + brev5(k)
+                out[(size_t)(hi * 32 + brevk(k, 5)) << 12] = gl::mul_mont<true>(x[brevk(k, 5)], f);
+                if (k < 31) f = gl::mul_mont_lazy<true>(f, ratio);
+            }
+        } else {                  // stage 2 thread = (k_a1 slots hi and hi + 16, j): two radix-16 DFTs over a0
+#pragma unroll
+            for (u32 u = 0; u < 2; u++) {
+                const u32 slot = hi + 16 * u;
+                u64 y[16];
+#pragma unroll
+                for (u32 a0 = 0; a0 < 16; a0++) y[a0] = sh[slot * SLOT + a0 * 16 + j];
+                dft16<false>(y);
+                u64 f = gl::mul_mont_lazy<true>(sl, tw_split16(tw_hi, tw_lo, brevk(slot, 5) * l));
+#pragma unroll
+                for (u32 k = 0; k < 16; k++) {  // row position brev9(k_a1 + 32 k) = slot * 16 + brev4(k)
+                    out[(size_t)(slot * 16 + brev4(k)) << 12] = gl::mul_mont<true>(y[brev4(k)], f);
+                    if (k < 15) f = gl::mul_mont_lazy<true>(f, ratio);
+                }
+            }
         }
         __syncthreads();
     }
@@ -488,6 +536,35 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p2s(const u64* __restrict
         dst[cbase + ((size_t)brevk(s, K) << 16) + ((size_t)ka << 8) + c] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
 }
 
+// P2 for LB = 5, 6 (2^21 and 2^22 rows, round 6): the middle pass as a radix-32 / radix-64 DFT over b in registers - every root of
+// unity of order <= 64 is a power of two, so the whole DFT is shifts; one or two DIF layers bring it down to 16-point blocks.
+// src [k_a][b][c] -> dst [k_b][k_a][c]; tw = w_{2^14}^-j (Montgomery form), j < 2^14.  X[k_b] ends up in slot brev_LB(k_b).
+template <int LB>
+__global__ __launch_bounds__(THREADS) void k_gl_intt16_p2w(const u64* __restrict__ src, u64* __restrict__ dst, const u64* __restrict__ tw16k) {
+    constexpr u32 L = 16 + LB, R = 1u << LB;
+    const size_t col = blockIdx.x >> 8;
+    const u32 ga = (blockIdx.x >> 4) & 15, gc = blockIdx.x & 15;
+    const size_t cbase = col << L;
+    const u32 ka = 16 * ga + (threadIdx.x >> 4), c = 16 * gc + (threadIdx.x & 15);
+    u64 x[R];
+#pragma unroll
+    for (u32 b = 0; b < R; b++) x[b] = src[cbase + ((size_t)ka << (8 + LB)) + ((size_t)b << 8) + c];
+    if constexpr (LB == 6) {
+        layer64<true, 32, 0>(x);
+        layer64<true, 16, 0>(x);
+        layer64<true, 16, 32>(x);
+    } else {
+        layer64<true, 16, 0>(x);
+    }
+#pragma unroll
+    for (u32 o = 0; o < R; o += 16) dft16<true>(*reinterpret_cast<u64(*)[16]>(&x[o]));
+#pragma unroll
+    for (u32 s = 0; s < R; s++) {
+        const u32 kb = brevk(s, LB);
+        dst[cbase + ((size_t)kb << 16) + ((size_t)ka << 8) + c] = s ? gl::mul_mont(x[s], tw16k[(kb * c) << (6 - LB)]) : x[s];   // w_{2^(8+LB)}^-(c k_b)
+    }
+}
+
 // P3: grid = ncols * 2^LB * 16; tile 16 k_a x 256 c (c = 16 c1 + c0); src [k_b][k_a][c];
 // dst natural k = k_a + 256 k_b + 2^(8+LB) k_c, scaled by n^-1
 __global__ __launch_bounds__(THREADS) void k_gl_intt16_p3(const u64* __restrict__ src, u64* __restrict__ dst, Inv16Geom g,
@@ -522,96 +599,22 @@ __global__ __launch_bounds__(THREADS) void k_gl_intt16_p3(const u64* __restrict_
     }
 }
 
-// P3 + PA in one kernel (2^20 rows; round 5): P3's output tile - coefficients l = 16 tg .. 16 tg + 15 at every stride-4096 position
-// a < 256, tg = 16 k_b + g_a - is exactly the tile k_gl_lde_pa16x2 reads, and P3's stage-2 thread (k_c1 slot hi4, i_a = lo4) ends
-// up holding the sixteen values PA's stage-1 thread (a0 = brev4(hi4), j = lo4) starts from (a = k_c = a0 + 16 brev4(s)).  So the
-// coefficients are written once, as the required output of from_values (fri/oracle.rs:82-90), and go on into the coset loop in
-// registers: PA's read of the column (n s bytes) and one launch disappear.  Thread roles of the PA half: stage 1 with a0 = brev4(hi4)
-// (its LDS row hi4 holds a0 = brev4(hi4)), stage 2 as in k_gl_lde_pa16x2.
-__global__ __launch_bounds__(THREADS, 3) void k_gl_intt16_p3_pa16x2(const u64* __restrict__ src, u64* __restrict__ coeffs, u64* __restrict__ lde,
-                                                                 u32 rate_bits, const u64* __restrict__ tw4096_inv, u64 n_inv,
-                                                                 const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
-                                                                 const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
-                                                                 const u64* __restrict__ pow_hi) {
-    constexpr u32 L = 20;
-    __shared__ u64 sh[16 * 272];
-    __shared__ u64 tw256[256];
-    const size_t col = blockIdx.x >> 8;
-    const u32 tg = blockIdx.x & 255, kb = tg >> 4, ga = tg & 15;
-    const size_t cbase = col << L;
-    const size_t sbase = cbase + ((size_t)kb << 16) + ((size_t)(16 * ga) << 8);
-    const u32 tid = threadIdx.x, hi4 = tid >> 4, lo4 = tid & 15;
-    tw256[tid] = tw4096[tid * 16];
-    u64 orig[16];
-    {   // ---- the inverse transform's last pass (k_gl_intt16_p3)
-        u64 x[16];
-#pragma unroll
-        for (u32 c1 = 0; c1 < 16; c1++) x[c1] = src[sbase + hi4 * 256 + c1 * 16 + lo4];
-        u64 tw[16];
-        load_tw16(tw, tw4096_inv, lo4 * 16);  // w_256^-(k_c1 c0)
-        dft16<true>(x);
-#pragma unroll
-        for (u32 s = 0; s < 16; s++) sh[s * 272 + lo4 * 17 + hi4] = s ? gl::mul_mont(x[s], tw[s]) : x[s];
-        __syncthreads();
-#pragma unroll
-        for (u32 c0 = 0; c0 < 16; c0++) x[c0] = sh[hi4 * 272 + c0 * 17 + lo4];
-        dft16<true>(x);
-        const u32 kc1 = brev4(hi4);
-#pragma unroll
-        for (u32 s = 0; s < 16; s++) {
-            const u32 kc = kc1 + 16 * brev4(s);
-            const u64 v = gl::mul_mont(x[s], n_inv);
-            coeffs[cbase + ((size_t)kc << 12) + ((size_t)kb << 8) + 16 * ga + lo4] = v;
-            orig[brev4(s)] = v;                     // a = k_c = a0 + 16 a1: a0 = brev4(hi4), a1 = brev4(s)
-        }
-    }
-    __syncthreads();   // sh is reused below; tw256 visible
-    // ---- the LDE's strided pass over the tile (k_gl_lde_pa16x2)
-    const u32 a0 = brev4(hi4), j = lo4;
-    const u32 l = (tg << 4) + j;
-    const size_t n = (size_t)1 << L;
-    const u64 ratio = tw_split16(tw_hi, tw_lo, 16 * l);
-    const u64 f0 = tw_split16(tw_hi, tw_lo, brev4(hi4) * l);  // stage 2: w_n^(k_a1 l), k_a1 slot = hi4
-    for (u32 c = 0; c < (1u << rate_bits); c++) {
-        const u64* ph = pow_hi + (size_t)c * 256 + a0;
-        u64 x[16];
-#pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = ph[a1 * 16];  // s_c^(4096 a)
-        const u64 sl = pow_lo[(size_t)c * 4096 + l];
-#pragma unroll
-        for (u32 a1 = 0; a1 < 16; a1++) x[a1] = gl::mul_mont<true>(orig[a1], x[a1]);
-        dft16<false>(x);
-#pragma unroll
-        for (u32 s = 0; s < 16; s++) sh[s * 272 + tid] = s ? gl::mul_mont<true>(x[s], tw256[(brev4(s) * a0) & 255]) : x[s];  // [k_a1 slot][row hi4 = brev4(a0)][j]
-        __syncthreads();
-#pragma unroll
-        for (u32 q = 0; q < 16; q++) x[q] = sh[hi4 * 272 + brev4(q) * 16 + j];   // digit a0 = q sits in row brev4(q)
-        dft16<false>(x);
-        u64* out = lde + (col << (L + rate_bits)) + (size_t)c * n + l;
-        u64 f = gl::mul_mont_lazy<true>(sl, f0);
-#pragma unroll
-        for (u32 k = 0; k < 16; k++) {
-            out[(size_t)(hi4 * 16 + brev4(k)) << 12] = gl::mul_mont<true>(x[brev4(k)], f);
-            if (k < 15) f = gl::mul_mont_lazy<true>(f, ratio);
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------ launchers (called from kernels_ntt.hip's dispatchers)
 // Every kernel of this file takes the MONTGOMERY-form copies of the tables (GlNttTables::*_m, GlCosetTables::*_m): all of their
 // general multiplications have a table value as one factor (gl::mul_mont).
 
 bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols, const GlNttTables& t, hipStream_t stream) {
     const u32 L = t.log_n;
-    if (L < 16 || L > 20) return false;
+    if (L < 16 || L > 22) return false;
     Inv16Geom g{L, L - 16};
     const u32 LL = g.LB + 8;
     u64* p1_dst = g.LB ? coeffs : scratch;
     hipLaunchKernelGGL(k_gl_intt16_p1, dim3((u32)(ncols << (LL - 4))), dim3(THREADS), 0, stream, src, p1_dst, g, t.tw4096_inv_m,
                        t.tw_hi_inv_m, t.tw_lo_inv_m);
     const dim3 g2((u32)(ncols << 8));
-    if (g.LB == 4) hipLaunchKernelGGL(k_gl_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv_m);
+    if (g.LB == 6) hipLaunchKernelGGL(k_gl_intt16_p2w<6>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw16k_inv_m);
+    else if (g.LB == 5) hipLaunchKernelGGL(k_gl_intt16_p2w<5>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw16k_inv_m);
+    else if (g.LB == 4) hipLaunchKernelGGL(k_gl_intt16_p2, g2, dim3(THREADS), 0, stream, coeffs, scratch, L, t.tw4096_inv_m);
     else if (g.LB == 3) hipLaunchKernelGGL(k_gl_intt16_p2s<3>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv_m);
     else if (g.LB == 2) hipLaunchKernelGGL(k_gl_intt16_p2s<2>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv_m);
     else if (g.LB == 1) hipLaunchKernelGGL(k_gl_intt16_p2s<1>, g2, dim3(THREADS), 0, stream, coeffs, scratch, t.tw4096_inv_m);
@@ -620,26 +623,20 @@ bool gl_intt_columns_r16(const u64* src, u64* coeffs, u64* scratch, size_t ncols
     return true;
 }
 
-// values -> coefficients AND the strided LDE pass, the last inverse pass fused with it (2^20 rows); false: shape not covered
-bool gl_intt_pa_fused_r16(const u64* src, u64* coeffs, u64* lde, u64* scratch, size_t ncols, const GlNttTables& t, const GlCosetTables& ct,
-                          hipStream_t stream) {
-    if (t.log_n != 20 || ncols == 0) return false;
-    Inv16Geom g{20, 4};
-    hipLaunchKernelGGL(k_gl_intt16_p1, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, src, coeffs, g, t.tw4096_inv_m, t.tw_hi_inv_m,
-                       t.tw_lo_inv_m);
-    hipLaunchKernelGGL(k_gl_intt16_p2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, scratch, 20u, t.tw4096_inv_m);
-    hipLaunchKernelGGL(k_gl_intt16_p3_pa16x2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, scratch, coeffs, lde, ct.rate_bits,
-                       t.tw4096_inv_m, t.n_inv_m, t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
-    return true;
-}
-
-bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, u32 log_split,
-                   hipStream_t stream) {
+bool gl_lde_pa_r16(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables& t, const GlCosetTables& ct, hipStream_t stream) {
     const u32 L = t.log_n;
     if (L == 20) {
-        if (log_split > ct.rate_bits) log_split = ct.rate_bits;
-        hipLaunchKernelGGL(k_gl_lde_pa16x2, dim3((u32)(ncols << (8 + log_split))), dim3(THREADS), 0, stream, coeffs, lde, L, ct.rate_bits,
-                           t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m, log_split);
+        hipLaunchKernelGGL(k_gl_lde_pa16x2, dim3((u32)(ncols << 8)), dim3(THREADS), 0, stream, coeffs, lde, L, ct.rate_bits,
+                           t.tw4096_fwd_m, t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
+        return true;
+    }
+    if (L == 21 || L == 22) {
+        if (L == 21)
+            hipLaunchKernelGGL(k_gl_lde_pa32<1>, dim3((u32)(ncols << 8)), dim3(256), 0, stream, coeffs, lde, ct.rate_bits, t.tw4096_fwd_m,
+                               t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
+        else
+            hipLaunchKernelGGL(k_gl_lde_pa32<2>, dim3((u32)(ncols << 8)), dim3(512), 0, stream, coeffs, lde, ct.rate_bits, t.tw4096_fwd_m,
+                               t.tw_hi_fwd_m, t.tw_lo_fwd_m, ct.pow_lo_m, ct.pow_hi_m);
         return true;
     }
 #define GB_PAS(KK)                                                                                                        \

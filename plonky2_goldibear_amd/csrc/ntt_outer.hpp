@@ -1,9 +1,10 @@
-// Transforms of more than 2^20 rows (round 5; the reference has no size cap below the field's two-adicity, field/src/fft.rs:168-205):
-// one outer radix-R step, R = 2^K = n / 2^20 <= 16 (2^21 .. 2^24 rows), around the 2^20-row passes.  With i = R i2 + i1 (decimation in time),
-//     X[k2 + m k1] = sum_i1 w_R^(i1 k1) * ( g(k2)^i1 * Y_i1[k2] ),     Y_i1 = the size-m = 2^20 transform of the stride-R subsequence i1,
+// Transforms of more than 2^22 rows (the reference has no size cap below the field's two-adicity, field/src/fft.rs:168-205): one outer
+// radix-R step, R = 2^K <= 16, around transforms of m = n / R rows - the passes themselves up to m = 2^22 (round 6; 2^20 in round 5),
+// another outer step above that (2^27 rows and more: the sub-transform is its own caller).  With i = R i2 + i1 (decimation in time),
+//     X[k2 + m k1] = sum_i1 w_R^(i1 k1) * ( g(k2)^i1 * Y_i1[k2] ),     Y_i1 = the size-m transform of the stride-R subsequence i1,
 // g(k2) = w_n^(k2) (times the coset shift s_c for the LDE, whose sub-transforms run on the shift s_c^R).  So: de-interleave the R
-// subsequences (one pass), run the existing kernels on R times as many columns of 2^20 rows, and combine (one pass: twiddle, R-point
-// DFT).  Two extra passes over the data per transform: a size outside BASELINE.json's configs, built for coverage, not for speed.
+// subsequences (one pass), run the sub-transforms on R times as many columns, and combine (one pass: twiddle, R-point DFT).  Two
+// extra passes over the data per transform: sizes far outside BASELINE.json's configs, built for coverage of the reference's range.
 // Written once against the field traits (GlF: canonical words and plain tables; BbF: Montgomery words and tables).
 #pragma once
 #include <algorithm>
@@ -108,13 +109,13 @@ __global__ __launch_bounds__(THREADS) void k_lde_combine(const typename F::T* __
     for (u32 k1 = 0; k1 < R; k1++) o[brev_bits(k1, K)] = z[k1];
 }
 
-// ---- host side.  `Sub` = callables running the 2^20-row transforms: intt(src, dst, scratch, ncols) / lde(coeffs, out, ncols).
+// ---- host side.  `Sub` = callables running the 2^(log_n - K)-row transforms: intt(src, dst, scratch, ncols) / lde(coeffs, out, ncols).
 // values [ncols][n] -> coefficients in `coeffs`; scratch holds ncols * n elements; src may equal coeffs.
 template <class F, class SubIntt>
-void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T* scratch, size_t ncols, u32 log_n, const typename F::T* tw_hi_inv,
+void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T* scratch, size_t ncols, u32 log_n, u32 K, const typename F::T* tw_hi_inv,
                   const typename F::T* tw_lo_inv, SubIntt sub_intt, hipStream_t st) {
     typedef typename F::T T;
-    const u32 K = log_n - 20, log_m = 20;
+    const u32 log_m = log_n - K;
     const size_t n = (size_t)1 << log_n;
     const u32 grid = (u32)((ncols << log_m) / THREADS);
     if (src != coeffs) {
@@ -130,10 +131,10 @@ void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T
 
 // coefficients [ncols][n] -> lde [ncols][2^r][n] (leaf order); work holds work_elems elements (>= (1 + 2^r) n for one column)
 template <class F, class SubLde>
-void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, u32 log_n, u32 rate_bits, const typename F::T* tw_hi, const typename F::T* tw_lo,
+void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, u32 log_n, u32 K, u32 rate_bits, const typename F::T* tw_hi, const typename F::T* tw_lo,
                  const typename F::T* pow_lo, typename F::T* work, size_t work_elems, SubLde sub_lde, hipStream_t st) {
     typedef typename F::T T;
-    const u32 K = log_n - 20, log_m = 20;
+    const u32 log_m = log_n - K;
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     const size_t group = std::max<size_t>(1, work_elems / (n + N));
     const T w4 = F::two_adic_generator(K < 2 ? 2 : K);   // the primitive R-th root

@@ -3,6 +3,10 @@
 // gb_verifier_create touches no device.  Includes nothing but the public header.
 //
 //   fuzz_host_parsers <case-file> <iterations> <seed>
+//   fuzz_host_parsers <case-file> alloc-fail <max-points>     (round 6: the "never unwinds" guards under a failing allocator - the
+//       global operator new of this binary throws std::bad_alloc on the N-th call while armed; every entry point is run with
+//       N = 1, 2, ... until a call gets through without reaching N: each interrupted call must come back as GB_ERR_OOM - not
+//       abort, not unwind into this file, not trip a sanitizer - and the object must still work afterwards)
 // case file (written by tests/test_sanitized_parsers.py from the reference's regression fixture or an oracle proof):
 //   gb_circuit_config | u32 num_gates | gb_gate[num_gates] | k_is[num_routed_wires] | cap[2^cap_height][H] | digest[H] |
 //   u64 proof_len | proof bytes            (elements: u64 Goldilocks / u32 BabyBear)
@@ -15,7 +19,62 @@
 #include <string>
 #include <vector>
 
+#include <new>
+
 #include "goldibear_gpu.h"
+
+// ---- the failing allocator (alloc-fail mode; the sanitizers' own operator new is replaced for the whole binary, malloc stays theirs)
+static long g_alloc_count = 0, g_alloc_fail_at = -1;
+static void* counted_alloc(size_t n, bool may_throw) {
+    if (g_alloc_fail_at >= 0 && ++g_alloc_count == g_alloc_fail_at) {
+        if (may_throw) throw std::bad_alloc();
+        return nullptr;
+    }
+    void* p = std::malloc(n ? n : 1);
+    if (!p && may_throw) throw std::bad_alloc();
+    return p;
+}
+void* operator new(size_t n) { return counted_alloc(n, true); }
+void* operator new[](size_t n) { return counted_alloc(n, true); }
+void* operator new(size_t n, const std::nothrow_t&) noexcept { return counted_alloc(n, false); }
+void* operator new[](size_t n, const std::nothrow_t&) noexcept { return counted_alloc(n, false); }
+void operator delete(void* p) noexcept { std::free(p); }
+void operator delete[](void* p) noexcept { std::free(p); }
+void operator delete(void* p, size_t) noexcept { std::free(p); }
+void operator delete[](void* p, size_t) noexcept { std::free(p); }
+
+// run `call` with the N-th allocation failing, N = 1, 2, ... (at most max_points values of N, spread over the call's allocations);
+// returns the number of interrupted calls, all of which answered GB_ERR_OOM
+template <class Fn>
+static long alloc_fail_sweep(const char* what, long max_points, gb_status expect, Fn&& call) {
+    g_alloc_fail_at = 0; g_alloc_count = 0;          // count only
+    gb_status s = call();
+    const long total = g_alloc_count;
+    g_alloc_fail_at = -1;
+    if (s != expect) { std::fprintf(stderr, "%s: %d instead of %d before any failure was injected\n", what, s, expect); std::exit(1); }
+    const long stride = total > max_points ? (total + max_points - 1) / max_points : 1;
+    long hit = 0;
+    for (long n = 1; n <= total; n += (n < 48 ? 1 : stride)) {
+        g_alloc_count = 0; g_alloc_fail_at = n;
+        s = call();
+        const bool reached = g_alloc_count >= n;
+        g_alloc_fail_at = -1;
+        if (reached) {
+            hit++;
+            if (s != GB_ERR_OOM) {
+                std::fprintf(stderr, "%s: allocation %ld of %ld failed and the call answered %d (%s), not GB_ERR_OOM\n", what, n, total, s, gb_last_error(nullptr));
+                std::exit(1);
+            }
+        } else if (s != expect) {
+            std::fprintf(stderr, "%s: %d instead of %d with no failure reached\n", what, s, expect);
+            std::exit(1);
+        }
+    }
+    s = call();                                      // and the object still works
+    if (s != expect) { std::fprintf(stderr, "%s: %d after the sweep\n", what, s); std::exit(1); }
+    std::printf("alloc-fail %s: %ld allocations per call, %ld interrupted calls -> GB_ERR_OOM\n", what, total, hit);
+    return hit;
+}
 
 static uint64_t rng_state;
 static uint64_t rnd() {  // splitmix64
@@ -88,7 +147,8 @@ int main(int argc, char** argv) {
     size_t got;
     while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
     std::fclose(f);
-    const long iterations = std::atol(argv[2]);
+    const bool alloc_fail = std::strcmp(argv[2], "alloc-fail") == 0;
+    const long iterations = alloc_fail ? 0 : std::atol(argv[2]);
     rng_state = std::strtoull(argv[3], nullptr, 0);
 
     size_t off = 0;
@@ -127,6 +187,28 @@ int main(int argc, char** argv) {
     if (s != GB_OK || n != proof.size() || std::memcmp(out.data(), proof.data(), n)) { std::fprintf(stderr, "round trip failed\n"); return 1; }
     if (gb_verify_compressed(c, compressed.data(), compressed.size()) != GB_OK) { std::fprintf(stderr, "verify_compressed failed\n"); return 1; }
 
+    if (alloc_fail) {
+        const long pts = std::atol(argv[3]);
+        long hit = 0;
+        hit += alloc_fail_sweep("gb_verifier_create", pts, GB_OK, [&] {
+            gb_circuit* c2 = nullptr;
+            const gb_status st = gb_verifier_create(nullptr, &cfg, gates.data(), num_gates, k_is.data(), cap.data(), digest.data(), &c2);
+            if (st == GB_OK) gb_circuit_free(c2);
+            else if (c2) { std::fprintf(stderr, "gb_verifier_create failed and left an object behind\n"); std::exit(1); }
+            return st;
+        });
+        hit += alloc_fail_sweep("gb_verify", pts, GB_OK, [&] { return gb_verify(c, proof.data(), proof.size()); });
+        hit += alloc_fail_sweep("gb_proof_compress", pts, GB_OK, [&] { return gb_proof_compress(c, proof.data(), proof.size(), out.data(), out.size(), &n); });
+        hit += alloc_fail_sweep("gb_proof_decompress", pts, GB_OK, [&] { return gb_proof_decompress(c, compressed.data(), compressed.size(), out.data(), out.size(), &n); });
+        hit += alloc_fail_sweep("gb_verify_compressed", pts, GB_OK, [&] { return gb_verify_compressed(c, compressed.data(), compressed.size()); });
+        std::vector<uint8_t> bad(proof);
+        bad[bad.size() / 2] ^= 1;     // a rejected proof: the error path allocates its message
+        const gb_status rej = gb_verify(c, bad.data(), bad.size());
+        hit += alloc_fail_sweep("gb_verify (rejected proof)", pts, rej, [&] { return gb_verify(c, bad.data(), bad.size()); });
+        gb_circuit_free(c);
+        std::printf("alloc-fail ok: %ld interrupted calls\n", hit);
+        return 0;
+    }
     long counts[3][4] = {};  // [entry point][ok, invalid, verify, too small]
     auto tally = [&](int e, gb_status st, const char* what) {
         if (!acceptable(st)) {

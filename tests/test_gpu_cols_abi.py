@@ -104,42 +104,6 @@ def test_staging_ring_thread_counts(ctx, threads):
     ctx.trim()
 
 
-@pytest.mark.parametrize("field_name,ncols", [("goldilocks", 70), ("babybear", 103)])
-def test_leaf_segments_on_a_second_stream(ctx, field_name, ncols):
-    """"overlap_hash" (an ablation, default off): the leaf-sponge segments of a chunked host commit run on a second stream beside
-    the transforms of the next upload chunks - same digests, same proof bytes as with everything on one stream, three times over
-    (the parked sponge state and the batch blocks come back from the pool)"""
-    log_n = 16
-    if field_name == "goldilocks":
-        vals, tag = O.splitmix64_fill(0xC0FFEE, ncols << log_n).reshape(ncols, 1 << log_n), N.GB_GOLDILOCKS
-        cpu = O.PolynomialBatch.from_values(vals, 3, 4)
-    else:
-        vals, tag = B.fill(0xC0FFEE, ncols << log_n).reshape(ncols, 1 << log_n), GB_BABYBEAR
-        cpu = B.PolynomialBatch.from_values(vals, 3, 4)
-    F = GL if tag == N.GB_GOLDILOCKS else BB
-    circ = D.DummyCircuit(16, D.CircuitConfig(num_challenges=3) if F is GL else D.CircuitConfig.babybear(7), F=F)
-    gpu_c = _gpu_circuit(ctx, circ, tag)
-    w = circ.witness(seed=5)
-    try:
-        base = gpu_c.prove_once(w)
-    except PermArgZeroError:
-        w = circ.witness(seed=6)
-        base = gpu_c.prove_once(w)
-    ctx.set_option("overlap_hash", 1)
-    try:
-        for src in (vals, columns_of(vals), vals):
-            gpu = PolynomialBatch.from_values(ctx, src, 3, 4, field=tag)
-            assert (gpu.merkle_tree.cap == cpu.cap).all()
-            assert (gpu.merkle_tree.digests == cpu.digests).all()
-            gpu.free()
-        assert gpu_c.prove_once(w) == base
-        assert gpu_c.prove_once(columns_of(w)) == base
-    finally:
-        ctx.set_option("overlap_hash", 0)
-    gpu_c.free()
-    ctx.trim()
-
-
 def test_page_locked_columns_and_device_columns(ctx):
     """columns a host placed in page-locked memory (gb_host_alloc, gb_host_register) go to the copy engine directly; separately
     allocated DEVICE columns are gathered"""

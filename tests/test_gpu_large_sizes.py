@@ -1,8 +1,13 @@
-"""More than 2^20 rows (round 5): the reference's transforms have no size cap below the field's two-adicity (field/src/fft.rs:168-205);
-the library runs 2^21 and 2^22 rows as one outer radix-2 / radix-4 step around its 2^20-row passes (csrc/ntt_outer.hpp).  -m gpu only.
+"""More than 2^20 rows: the reference's transforms have no size cap below the field's two-adicity (field/src/fft.rs:168-205) and
+prove() none either (plonk/prover.rs:228-447).  2^21 and 2^22 rows run the library's own passes (round 6: a radix-32 / radix-64 middle
+pass of the inverse transform, a 512- / 1024-row strided pass of the LDE); from 2^23 rows one outer radix step per four bits around
+them (csrc/ntt_outer.hpp).  -m gpu only.
 * PolynomialBatch::from_values at 2^21 rows: EVERY coefficient, EVERY leaf, EVERY digest and the cap against the CPU oracle's batch
   (Goldilocks 5 columns = one sponge permutation per leaf; BabyBear 9 columns), host and device input; 2^22 rows: coefficients + cap.
-* prove() of the 2^21-row dummy circuit: accepted by gb_verify and by the independently written oracle verifier (oracle/verifier.py)."""
+* prove() of the 2^21-row dummy circuit, both fields: proof BYTES == the CPU oracle prover's, and the oracle prover's own Z /
+  partial-product values and quotient chunk coefficients == the stage entry points' outputs.
+* prove() at 2^22 and 2^23 rows: accepted by gb_verify and by the independently written oracle verifier (oracle/verifier.py).
+* from_values at 2^23 ... 2^26 rows (Goldilocks; BabyBear's two-adicity ends at 2^24 rows with rate_bits 3): size-independent properties."""
 import numpy as np
 import pytest
 
@@ -56,15 +61,47 @@ def test_from_values_above_2pow20_rows(ctx, field_name, log_n, ncols):
     ctx.trim()
 
 
-def test_prove_2pow21_rows_verifies(ctx):
-    """prove() of the 2^21-row Goldilocks dummy circuit (num_challenges 3): gb_verify and the oracle's verifier accept the proof, a
-    flipped byte in the opening set is rejected by both"""
-    lg, ch = 21, 3
+@pytest.mark.parametrize("field_name,ch", [("goldilocks", 3), ("babybear", 10)])
+def test_prove_2pow21_rows_bytes_equal_oracle(ctx, field_name, ch):
+    """prove() of the 2^21-row dummy circuit: the proof BYTES equal the CPU oracle prover's (round 5 only verified proofs of this
+    size: 28 queried leaves per tree say nothing about the other 2^24), and - through the stage entry points, driven like the
+    reference's prover loop (tests/test_gpu_stage_abi.py) - the oracle prover's own intermediates equal the GPU's element for
+    element: the Z / partial-product values (a running product over 2048 blocks) and the quotient chunk coefficients."""
+    from oracle.fields import BB
+    from test_gpu_stage_abi import _gpu_circuit, prove_by_stages
+    lg = 21
+    F, tag, cfg = (GL, N.GB_GOLDILOCKS, D.CircuitConfig(num_challenges=ch)) if field_name == "goldilocks" else (BB, GB_BABYBEAR, D.CircuitConfig.babybear(ch))
+    circ = D.DummyCircuit(lg, cfg, F=F)
+    gpu = _gpu_circuit(ctx, circ, tag)
+    circ.set_cap(gpu.constants_sigmas_cap)     # prove_cpu() asserts that it IS the cap of the oracle's own commitment
+    assert (gpu.circuit_digest == circ.circuit_digest).all()
+    w = circ.witness(seed=lg)
+    got = gpu.prove(w, random_wire=(cfg.num_wires - 1, circ.pi_row), rng=np.random.default_rng(lg))   # (re-draws in place: InvZeroPermArg)
+    dump, mid = {}, {}
+    want, _ = D.prove_cpu(circ, w, dump=dump)
+    assert len(got) == len(want)
+    assert got == want, "first differing byte at %d" % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    assert (gpu.constants_sigmas_cap == D.prove_cpu.last_cs_cap).all()
+    assert gpu.verify(got)
+    assert prove_by_stages(gpu, circ, w, [], tag, mid) == want
+    assert (mid["zs_partial_products"] == dump["zs_partial_products"]).all()
+    assert (mid["quotient_chunks"] == dump["quotient_chunks"]).all()
+    gpu.free()
+    ctx.trim()
+
+
+@pytest.mark.parametrize("lg", [22, 23])
+def test_prove_above_2pow21_rows_verifies(ctx, lg):
+    """prove() of the 2^22- and 2^23-row Goldilocks dummy circuits (num_challenges 3; 2^23 rows: one outer radix-2 step around the
+    2^22-row passes, ~170 GB of commitments): gb_verify and the oracle's verifier accept the proof, a flipped byte in the opening set
+    is rejected by both"""
+    ch = 3
     cs, k_is, pi_row, _ = DC.build_dummy_circuit(lg)
     gpu = CircuitData(ctx, lg, cs, k_is, num_challenges=ch)
     del cs
     w = DC.dummy_witness(lg, pi_row, seed=5)
     proof = gpu.prove(w)
+    del w
     assert gpu.verify(proof)
     view = D.DummyCircuit.verifier_view(lg, D.CircuitConfig(num_challenges=ch), GL, k_is)
     view.set_cap(gpu.constants_sigmas_cap)
@@ -80,17 +117,17 @@ def test_prove_2pow21_rows_verifies(ctx):
     ctx.trim()
 
 
-@pytest.mark.parametrize("lg,ch", [(21, 10), (22, 12)])
-def test_babybear_prove_above_2pow20_rows_verifies(ctx, lg, ch):
-    """BabyBear at 2^21 / 2^22 rows: (31 - degree_bits) c >= 100 (circuit_builder.rs:1190-1192) asks for 10 / 12 challenges -
-    twelve run as two slices of six in the quotient kernel (csrc/challenge_slices.hpp).  The proof may need the reference's
-    retry (a zero denominator meets ~35 % of the attempts at these sizes); gb_verify and the oracle verifier accept it."""
+@pytest.mark.parametrize("lg,ch", [(22, 12), (23, 13)])
+def test_babybear_prove_above_2pow21_rows_verifies(ctx, lg, ch):
+    """BabyBear at 2^22 / 2^23 rows: (31 - degree_bits) c >= 100 (circuit_builder.rs:1190-1192) asks for 12 / 13 challenges -
+    run as two slices in the quotient kernel (csrc/challenge_slices.hpp).  The proof may need the reference's retry (a zero
+    denominator meets a third to a half of the attempts at these sizes); gb_verify and the oracle verifier accept it."""
     from oracle.fields import BB
     cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(lg)
     gpu = CircuitData(ctx, lg, cs, k_is, num_wires=167, num_routed_wires=41, num_challenges=ch, arity_bits=3, field=GB_BABYBEAR)
     del cs
     proof = None
-    for seed in range(8):
+    for seed in range(48):   # 2^23 rows, 13 challenges: ~2^23 * 41 * 13 / p = 2.1 zero denominators expected per attempt, 12 % of the attempts get through
         try:
             proof = gpu.prove_once(DC.dummy_witness_bb(lg, pi_row, seed=seed))
             break
@@ -141,9 +178,10 @@ def test_zs_running_product_above_1024_blocks(ctx):
     ctx.trim()
 
 
-@pytest.mark.parametrize("field_name,log_n", [("goldilocks", 23), ("babybear", 23), ("goldilocks", 24), ("babybear", 24)])
-def test_from_values_2pow23_and_2pow24_rows_sparse_polynomials(ctx, field_name, log_n):
-    """2^23 / 2^24 rows (outer radix 8 / 16; BabyBear's two-adicity ends at 2^24 rows with rate_bits 3) through size-independent
+@pytest.mark.parametrize("field_name,log_n", [("goldilocks", 23), ("babybear", 23), ("goldilocks", 24), ("babybear", 24), ("goldilocks", 26)])
+def test_from_values_2pow23_and_up_sparse_polynomials(ctx, field_name, log_n):
+    """2^23 ... 2^26 rows (one outer radix-2 ... radix-16 step around the 2^22-row passes; BabyBear's two-adicity ends at 2^24 rows
+    with rate_bits 3; round 5 stopped at 2^24) through size-independent
     properties, no oracle run of that size: the values of SPARSE polynomials a x^k1 + b x^k2 + c with exponents all over [0, n) are
     built on the host with vectorised powers; from_values must return exactly those coefficients (EVERY one of the n compared), the LDE
     rows must equal the polynomials evaluated directly at 7 w_N^i, and sampled Merkle paths must verify against the cap."""
@@ -161,10 +199,10 @@ def test_from_values_2pow23_and_2pow24_rows_sparse_polynomials(ctx, field_name, 
     w_n = pow(gen_N, 8, P)
     rng = np.random.default_rng(log_n)
     polys = []
-    for _ in range(2):
+    for _ in range(2 if log_n <= 24 else 1):     # (the host side of this test is numpy: one polynomial is enough work at 2^26 rows)
         ks = sorted({0, int(rng.integers(1, n)), n - 1 - int(rng.integers(0, 1000)), int(rng.integers(1, 1 << 20))})
         polys.append({k: int(rng.integers(1, P, dtype=np.uint64)) for k in ks})
-    vals = np.zeros((2, n), dtype=dt)
+    vals = np.zeros((len(polys), n), dtype=dt)
     for c, poly in enumerate(polys):
         acc = np.zeros(n, dtype=np.uint64)
         for k, a in poly.items():

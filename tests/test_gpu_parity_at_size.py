@@ -104,18 +104,14 @@ def test_full_batch_2pow20_every_leaf_and_digest(ctx, field_name):
     for i in (0, 1, (1 << 20) - 1, 777777):
         assert (gpu.get_lde_values(i, 8) == cpu.get_lde_values(i, 8)).all()
     gpu.free()
-    # the same batch from a device-resident matrix (one launch per pass over all columns instead of upload chunks), and with the
-    # fused last-inverse / first-LDE pass switched off (the two transforms one after the other): identical coefficients and tree
+    # the same batch from a device-resident matrix (one launch per pass over all columns instead of upload chunks): identical
+    # coefficients and tree
     import torch
     dev = torch.from_numpy(vals.view(np.int64 if vals.dtype == np.uint64 else np.int32)).cuda()
-    for fuse in (1, 0):
-        ctx.set_option("fuse_intt_lde", fuse)
-        for src in (dev, vals):
-            g2 = PolynomialBatch.from_values(ctx, src, 3, 4, field=N.GB_GOLDILOCKS if field_name == "goldilocks" else GB_BABYBEAR)
-            assert (g2.merkle_tree.cap == cpu.cap).all(), (fuse, type(src))
-            assert (g2.polynomial(ncols - 1) == cpu.polynomials[ncols - 1]).all() and (g2.polynomial(0) == cpu.polynomials[0]).all()
-            g2.free()
-    ctx.set_option("fuse_intt_lde", 0)   # the product's default
+    g2 = PolynomialBatch.from_values(ctx, dev, 3, 4, field=N.GB_GOLDILOCKS if field_name == "goldilocks" else GB_BABYBEAR)
+    assert (g2.merkle_tree.cap == cpu.cap).all()
+    assert (g2.polynomial(ncols - 1) == cpu.polynomials[ncols - 1]).all() and (g2.polynomial(0) == cpu.polynomials[0]).all()
+    g2.free()
     ctx.trim()
 
 

@@ -44,6 +44,18 @@ def _case(path, cfg_words, gates, k_is, cap, digest, proof, dtype):
         f.write(proof)
 
 
+def _run_alloc_fail(harness, case, points):
+    env = dict(os.environ)
+    env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=0:allocator_may_return_null=1"
+    env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([harness, case, "alloc-fail", str(points)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
+    assert "alloc-fail ok" in out.stdout
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-4000:]
+    return out.stdout
+
+
 def _run(harness, case, iterations, seed):
     env = dict(os.environ)
     env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=0:allocator_may_return_null=1"
@@ -74,6 +86,10 @@ def test_reference_recursion_proof_mutations(harness, golden_dir, tmp_path):
     # the loop must have reached both failure classes, not bounced off the first length check every time
     counts = [int(x) for x in line.split("verify ok/invalid/verify = ")[1].split(";")[0].split("/")]
     assert counts[1] > 0 and counts[2] > 0, line
+    # "never unwinds" under a failing allocator (round 6): gb_verifier_create / gb_verify / gb_proof_* / gb_verify_compressed with
+    # the N-th operator new throwing, N swept over each call's allocations - every interrupted call answers GB_ERR_OOM
+    out = _run_alloc_fail(harness, case, 60)
+    assert int(out.split("alloc-fail ok: ")[1].split()[0]) >= 100, out
 
 
 @pytest.mark.parametrize("F", [GL, BB], ids=["goldilocks", "babybear"])
@@ -88,6 +104,7 @@ def test_dummy_circuit_proof_mutations(harness, tmp_path, F):
     case = str(tmp_path / "dummy.case")
     _case(case, words, circ.gate_table, circ.k_is, circ.constants_sigmas_cap, circ.circuit_digest, proof, F.dtype)
     _run(harness, case, 300, 7 + F.D)
+    _run_alloc_fail(harness, case, 40)
 
 
 @pytest.mark.parametrize("F,lg,kw,zk", [
