@@ -11,6 +11,12 @@
 #include "gl_field.hpp"
 
 #define GB_HD __host__ __device__ __forceinline__
+// a table that exists twice (a __device__ copy and a host copy), named by the pass that compiles the expression
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GB_DEV_OR_HOST(dev, host) dev
+#else
+#define GB_DEV_OR_HOST(dev, host) host
+#endif
 
 namespace gbk {
 
@@ -32,13 +38,9 @@ struct GlF {
     // a * b as ANY u64 residue: for product chains whose result is only multiplied again (mul() accepts any u64 and
     // canonicalises its own output; add / sub need canonical operands)
     static GB_HD T mul_lazy(T a, T b) {
-#if defined(__HIP_DEVICE_COMPILE__)
         u32 r0, r1, hl, hh;
         gl::mul_limbs(a, b, r0, r1, hl, hh);
         return gl::fold128(r0, r1, hl, hh);
-#else
-        return gl::mul(a, b);
-#endif
     }
     // a + b for a result that is only multiplied (by a canonical partner): canonical here
     static GB_HD T add_lazy(T a, T b) { return gl::add(a, b); }
@@ -59,20 +61,8 @@ struct GlF {
         }();
         return t.v[len];
     }
-    static GB_HD T mul_chain(T acc, T f) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return gl::mul_mont_lazy(acc, f);
-#else
-        return gl::mul(gl::mul(acc, f), 0xFFFFFFFE00000001ULL);
-#endif
-    }
-    static GB_HD T mulc(T x, T c_form) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return gl::mul_mont(x, c_form);
-#else
-        return gl::mul(gl::mul(x, c_form), 0xFFFFFFFE00000001ULL);  // host: x (c R) R^-1; not on any hot path
-#endif
-    }
+    static GB_HD T mul_chain(T acc, T f) { return gl::mul_mont_lazy(acc, f); }
+    static GB_HD T mulc(T x, T c_form) { return gl::mul_mont(x, c_form); }
     // sum_t term_t * c_t with wave-uniform constants c_t in constant form (the quotient kernel's alpha fold): two sums side by
     // side, because BabyBear's form pairs them (below); here simply add(acc, mulc(term, c))
     typedef T Acc;

@@ -145,25 +145,18 @@ struct PoseidonTab {
      {GL_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX_LIST}}
 static const PoseidonTab POSEIDON_TAB_HOST = GB_POSEIDON_TAB_INIT;
 __device__ static const PoseidonTab POSEIDON_TAB_DEV = GB_POSEIDON_TAB_INIT;
-GB_HD const PoseidonTab& poseidon_tab() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return POSEIDON_TAB_DEV;
-#else
-    return POSEIDON_TAB_HOST;
-#endif
-}
+GB_HD const PoseidonTab& poseidon_tab() { return GB_DEV_OR_HOST(POSEIDON_TAB_DEV, POSEIDON_TAB_HOST); }
 
 template <class A>
 GB_HD typename A::V sbox7(typename A::V x) {  // sbox_monomial (hash/poseidon_goldilocks.rs:840-847)
     typename A::V x2 = A::mul(x, x), x4 = A::mul(x2, x2), x3 = A::mul(x, x2);
     return A::mul(x3, x4);
 }
-#if defined(__HIP_DEVICE_COMPILE__)
 // The MDS layer on base-field values in the quotient kernel: entries < 2^6, so each output is two 64-bit sums over the 32-bit
 // halves of the inputs and ONE reduction (the decomposition of the reference's mds_layer, hash/poseidon_goldilocks.rs:497-528) -
 // 24 v_mad_u64_u32 per output where twelve modular multiplications by small constants would be ~350 instructions.  Half of
 // PoseidonGate's multiplications are these.
-__device__ __forceinline__ void mds_layer_gl_base(u64 (&s)[12]) {
+GB_HD void mds_layer_gl_base(u64 (&s)[12]) {
     const PoseidonTab& t = poseidon_tab();
     u32 lo[12], hi[12];
 #pragma unroll
@@ -187,17 +180,14 @@ __device__ __forceinline__ void mds_layer_gl_base(u64 (&s)[12]) {
         s[r] = gl::canon(r2);
     }
 }
-#endif
 
 template <class A>
 GB_HD void mds_layer(typename A::V (&s)[12]) {  // mds_layer_field (:584-592)
     typedef typename A::V V;
-#if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (A::IS_GL_BASE) {
         mds_layer_gl_base(s);
         return;
     }
-#endif
     const PoseidonTab& t = poseidon_tab();
     V out[12];
 #pragma unroll
@@ -299,13 +289,7 @@ struct Poseidon2Tab {
 #define GB_POSEIDON2_TAB_INIT {{BB_POSEIDON2_EXTERNAL_CONSTANTS_LIST}, {BB_POSEIDON2_INTERNAL_CONSTANTS_LIST}}
 static const Poseidon2Tab POSEIDON2_TAB_HOST = GB_POSEIDON2_TAB_INIT;
 __device__ static const Poseidon2Tab POSEIDON2_TAB_DEV = GB_POSEIDON2_TAB_INIT;
-GB_HD const Poseidon2Tab& poseidon2_tab() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return POSEIDON2_TAB_DEV;
-#else
-    return POSEIDON2_TAB_HOST;
-#endif
-}
+GB_HD const Poseidon2Tab& poseidon2_tab() { return GB_DEV_OR_HOST(POSEIDON2_TAB_DEV, POSEIDON2_TAB_HOST); }
 template <class A>
 GB_HD void p2_external(typename A::V (&s)[16]) {  // permute_external_mut (:804-832), apply_mat4 (:903-917)
     typedef typename A::V V;

@@ -19,11 +19,17 @@ static constexpr u64 TWO_ADIC_GEN_32 = 1753635133440165772ULL;  // order 2^32
 
 __host__ __device__ __forceinline__ u64 canon(u64 x) { return x >= P ? x - P : x; }
 
-// a, b canonical -> canonical.  s - p == s + EPS (mod 2^64), so both the wrapped case (a + b >= 2^64) and the
-// s >= p case select s + EPS.  Device form on 32-bit limbs: four v_add(c)_co + two v_cndmask, all 32-bit-rate ops
-// (the u64 form lowers to two v_lshl_add_u64 and two v_cmp_u64, ~40 % more issue cycles per butterfly).
-__host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+// The ONE host / device split of this header: the forms that differ between the device pass (32-bit limbs, the instructions the
+// issue-cost model of DESIGN.md 4 prices) and the host pass (the table builders, the verifier; plain 64 / 128-bit C).
+//   add / sub: a, b canonical -> canonical.  s - p == s + EPS (mod 2^64), so both the wrapped case (a + b >= 2^64) and the s >= p
+//     case select s + EPS.  Device form: four v_add(c)_co + two v_cndmask, all 32-bit-rate ops (the u64 form lowers to two
+//     v_lshl_add_u64 and two v_cmp_u64, ~40 % more issue cycles per butterfly).
+//   mad_carry / addc_carry: a1 b0 + p01 as ONE v_mad_u64_u32 whose carry (weight 2^96) comes out in the scalar carry operand and
+//     enters the top limb through a v_addc (mul_limbs below); mad_one: x * 1 + acc, the mad as an adder.
+// Under hipcc both sets exist in both passes as __device__ / __host__ OVERLOADS (a __host__ __device__ caller binds to its own
+// side's); a plain C++ compiler (tests/host_shim) sees the host set only.
+#if defined(__HIPCC__)
+__device__ __forceinline__ u64 add(u64 a, u64 b) {
     u32 c0, c1, d0, d1;
     u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0);
     u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
@@ -31,15 +37,8 @@ __host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
     u32 t1 = __builtin_addc(s1, 0u, d0, &d1);
     const bool sel = (c1 | d1) != 0;
     return sel ? ((u64)t0 | ((u64)t1 << 32)) : ((u64)s0 | ((u64)s1 << 32));
-#else
-    u64 s, u;
-    bool c = __builtin_uaddll_overflow(a, b, &s);
-    bool c2 = __builtin_uaddll_overflow(s, EPS, &u);
-    return (c | c2) ? u : s;
-#endif
 }
-__host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u64 sub(u64 a, u64 b) {
     u32 b0, b1, k;
     u32 d0 = __builtin_subc((u32)a, (u32)b, 0u, &b0);
     u32 d1 = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b0, &b1);
@@ -47,21 +46,45 @@ __host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
     u32 e0 = __builtin_subc(d0, m, 0u, &k);
     u32 e1 = d1 - k;
     return (u64)e0 | ((u64)e1 << 32);
-#else
+}
+__device__ __forceinline__ u64 mulhi(u64 a, u64 b) { return __umul64hi(a, b); }
+__device__ __forceinline__ u64 mad_carry(u32 a, u32 b, u64 acc, u64& carry) {   // a b + acc = result + 2^64 [carry]
+    u64 m;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m), "=s"(carry) : "v"(a), "v"(b), "v"(acc));
+    return m;
+}
+__device__ __forceinline__ u32 addc_carry(u32 x, u64 carry) {                   // x + [carry]
+    u32 top;
+    u64 unused;
+    asm("v_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(top), "=s"(unused) : "v"(x), "s"(carry));
+    return top;
+}
+__device__ __forceinline__ u64 mad_one(u32 x, u64 acc) {                        // x * 1 + acc (< 2^64 where it is used)
+    u64 unused;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(acc), "=s"(unused) : "v"(x));
+    return acc;
+}
+#endif
+__host__ inline u64 add(u64 a, u64 b) {
+    u64 s, u;
+    bool c = __builtin_uaddll_overflow(a, b, &s);
+    bool c2 = __builtin_uaddll_overflow(s, EPS, &u);
+    return (c | c2) ? u : s;
+}
+__host__ inline u64 sub(u64 a, u64 b) {
     u64 d;
     bool br = __builtin_usubll_overflow(a, b, &d);
     return d - (br ? EPS : 0);  // + p
-#endif
 }
+__host__ inline u64 mulhi(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) >> 64); }
+__host__ inline u64 mad_carry(u32 a, u32 b, u64 acc, u64& carry) {
+    const unsigned __int128 t = (unsigned __int128)a * b + acc;
+    carry = (u64)(t >> 64);
+    return (u64)t;
+}
+__host__ inline u32 addc_carry(u32 x, u64 carry) { return x + (u32)(carry & 1); }
+__host__ inline u64 mad_one(u32 x, u64 acc) { return acc + x; }
 __host__ __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }
-
-__host__ __device__ __forceinline__ u64 mulhi(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
-#else
-    return (u64)(((unsigned __int128)a * b) >> 64);
-#endif
-}
 
 // (lo + 2^64 hi) mod p, any 128-bit input, canonical output.
 // 2^64 = 2^32 - 1 and 2^96 = -1 (mod p):  x = lo - hi_hi + hi_lo * (2^32 - 1)
@@ -80,7 +103,7 @@ __host__ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
 // (11 32-bit VALU ops) instead of 64-bit adds and compares: 64.4 vs 70.5 cycles per wave-multiply
 // (tools/microbench_mulmod.hip, M4 vs M2).  No second overflow is possible: after a carry the sum is < 2^64 - 2^32,
 // after a borrow it is > 2^64 - 2^33.
-__device__ __forceinline__ u64 fold128(u32 r0, u32 r1, u32 hl, u32 hh) {
+__host__ __device__ __forceinline__ u64 fold128(u32 r0, u32 r1, u32 hl, u32 hh) {
     u32 cs, c1, bw, B, k1, k2;
     u32 s0 = __builtin_addc(hl, hh, 0u, &cs);   // hl + hh (33 bits: s0, cs)
     u32 a1 = __builtin_addc(r1, hl, 0u, &c1);   // high word of lo + hl 2^32; c1 = one 2^64
@@ -110,50 +133,34 @@ __device__ __forceinline__ u64 fold160(u32 r0, u32 r1, u32 hl, u32 hh, u32 r4) {
     return (u64)f0 | ((u64)f1 << 32);
 }
 // a * b as four 32-bit limbs (gfx950 issue costs, measured: v_mad_u64_u32 4.5 cycles per wave, carry / select / 64-bit-add ops
-// ~2.9 in a mixed stream, v_mov 2.4; tools/microbench_*.hip).  Rounds 2-3 (GB_MUL_FIVE_MADS): four v_mad_u64_u32 for the partial
-// products and a fifth as an ADDER - the second carry word enters the top product as x * 1 + acc.
-#ifdef GB_MUL_FIVE_MADS
-static constexpr bool MUL_FIVE_MADS_DEFAULT = true;
-#else
-static constexpr bool MUL_FIVE_MADS_DEFAULT = false;
-#endif
-template <bool FIVE = MUL_FIVE_MADS_DEFAULT>
-__device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& hl, u32& hh) {
+// ~2.9 in a mixed stream, v_mov 2.4; tools/microbench_*.hip).
+// FIVE = false (round 4, the default): FOUR multiply-adds.  The second cross product takes the whole of p01 as its addend - a 64-bit
+//   register pair that is already in place - and the one carry that sum can produce (weight 2^96) comes out in the mad's scalar carry
+//   operand and enters the top limb through a v_addc: 4 mads + 3 plain.
+// FIVE = true (rounds 2-3): four mads for the partial products and a fifth as an ADDER - the second carry word enters the top
+//   product as x * 1 + acc.  The strided LDE pass (k_gl_lde_pa16x2, k_gl_lde_pa32) measured 3 % faster with this form: its
+//   140-register body loses more to the extra scalar carry pair than it gains from the mad.
+template <bool FIVE = false>
+__host__ __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32& r0, u32& r1, u32& hl, u32& hh) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (!FIVE) {
-    // Round 4: FOUR multiply-adds.  The second cross product takes the whole of p01 as its addend - a 64-bit register pair that
-    // is already in place, where the five-mad form splits p01 into two zero-extended halves (a v_mov each) - and the one carry
-    // that 64-bit sum can produce (weight 2^96) comes out in the mad's scalar carry operand and enters the top limb through a
-    // v_addc: 4 mads + 3 plain instead of 5 + 3 (v_mad_u64_u32 issues at 4.5 cycles per wave, the others at 2.4-2.9).
-    u64 m2, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(carry) : "v"(a1), "v"(b0), "v"(p01));   // a1 b0 + p01 = m2 + 2^64 [carry]
-    u64 p11 = (u64)a1 * b1 + (m2 >> 32);   // < 2^64 - 2^32: the carry still fits
-    u32 top, carry_unused_lo;
-    u64 carry_unused;
-    asm("v_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(top), "=s"(carry_unused) : "v"((u32)(p11 >> 32)), "s"(carry));
-    (void)carry_unused_lo;
-    r0 = (u32)p00; r1 = (u32)m2; hl = (u32)p11; hh = top;
-    return;
-  }
-#endif
-    u64 p10 = (u64)a1 * b0 + (u32)p01;
-    u64 p11 = (u64)a1 * b1 + (p01 >> 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-    u64 carry_unused;
-    asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(p11), "=s"(carry_unused) : "v"((u32)(p10 >> 32)));   // < 2^64: the product is < 2^128
-#else
-    p11 += p10 >> 32;
-#endif
-    r0 = (u32)p00; r1 = (u32)p10; hl = (u32)p11; hh = (u32)(p11 >> 32);
+    if constexpr (!FIVE) {
+        u64 carry;
+        const u64 m2 = mad_carry(a1, b0, p01, carry);   // a1 b0 + p01 = m2 + 2^64 [carry]
+        const u64 p11 = (u64)a1 * b1 + (m2 >> 32);      // < 2^64 - 2^32: the carry still fits
+        r0 = (u32)p00; r1 = (u32)m2; hl = (u32)p11; hh = addc_carry((u32)(p11 >> 32), carry);
+    } else {
+        const u64 p10 = (u64)a1 * b0 + (u32)p01;
+        const u64 p11 = mad_one((u32)(p10 >> 32), (u64)a1 * b1 + (p01 >> 32));   // < 2^64: the product is < 2^128
+        r0 = (u32)p00; r1 = (u32)p10; hl = (u32)p11; hh = (u32)(p11 >> 32);
+    }
 }
 // (x0 + 2^32 x1 + 2^64 x2 + 2^96 x3) / 2^64 mod p as SOME u64 congruent to it: Montgomery reduction with R = 2^64, for which
 // p = 2^64 - 2^32 + 1 needs no multiplication (-1/p = -(1 + 2^32) mod 2^64):  a = lo + (lo << 32), b = a - (a >> 32) - carry,
 // r = hi - b, minus EPS when that borrows.  b <= p - 1 for every 128-bit input, so the last step cannot borrow twice.
 // 8 carry ops against fold128's 11.
-__device__ __forceinline__ u64 mont_fold(u32 x0, u32 x1, u32 x2, u32 x3) {
+__host__ __device__ __forceinline__ u64 mont_fold(u32 x0, u32 x1, u32 x2, u32 x3) {
     u32 e, bw, k0, c0, c, k;
     const u32 a1 = __builtin_addc(x1, x0, 0u, &e);   // a = (x0, a1), carry e
     const u32 b0 = __builtin_subc(x0, a1, e, &bw);
@@ -170,8 +177,8 @@ __device__ __forceinline__ u64 mont_fold(u32 x0, u32 x1, u32 x2, u32 x3) {
 // further step (mul_mont): a, t R <= p - 1 makes the product's high word xh <= (p - 1)^2 / 2^64 < p, and mont_fold returns
 // xh - b without a borrow (<= xh < p) or xh - b + p with one (in [p - b, p - 1], b <= p - 1).  So a multiplication by a table
 // value costs 5 mads + 8 carry ops where gl::mul takes 5 + 11 + 4 (fold, then canonicalise).
-template <bool FIVE = MUL_FIVE_MADS_DEFAULT>
-__device__ __forceinline__ u64 mul_mont_lazy(u64 a, u64 t_mont) {
+template <bool FIVE = false>
+__host__ __device__ __forceinline__ u64 mul_mont_lazy(u64 a, u64 t_mont) {
     u32 r0, r1, hl, hh;
     mul_limbs<FIVE>(a, t_mont, r0, r1, hl, hh);
     return mont_fold(r0, r1, hl, hh);
@@ -181,20 +188,16 @@ __device__ __forceinline__ u64 mul_mont_lazy(u64 a, u64 t_mont) {
 // mul_mont), every table entry is canonical, and the running twiddles `f <- f * ratio` (computed with mul_mont_lazy) start from
 // canonical table entries and therefore stay canonical by induction.  A lazy operand (some residue >= p) would make the product a
 // non-canonical word in memory - and a Merkle leaf that differs from the reference's; keep add_lazy-style values out of these chains.
-template <bool FIVE = MUL_FIVE_MADS_DEFAULT>
-__device__ __forceinline__ u64 mul_mont(u64 a_canonical, u64 t_mont_canonical) { return mul_mont_lazy<FIVE>(a_canonical, t_mont_canonical); }
+template <bool FIVE = false>
+__host__ __device__ __forceinline__ u64 mul_mont(u64 a_canonical, u64 t_mont_canonical) { return mul_mont_lazy<FIVE>(a_canonical, t_mont_canonical); }
 // x R mod p on the host (table builders)
 __host__ __device__ inline u64 to_mont_slow(u64 x);
 
 // a * b mod p, any u64 in, canonical out.
 __host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
     u32 r0, r1, hl, hh;
     mul_limbs(a, b, r0, r1, hl, hh);
     return canon(fold128(r0, r1, hl, hh));
-#else
-    return reduce128(a * b, mulhi(a, b));
-#endif
 }
 __host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 __host__ __device__ inline u64 to_mont_slow(u64 x) { return mul(x, EPS); }   // R = 2^64 mod p = 2^32 - 1

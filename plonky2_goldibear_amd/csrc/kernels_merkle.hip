@@ -13,91 +13,33 @@ namespace gbk {
 
 using poseidon_gl::from_mont;
 using poseidon_gl::mds_mfma_matrix;
-using poseidon_gl::permute;
 using poseidon_gl::to_mont;
 // The lane-per-state kernels run the full rounds' MDS layers on the matrix pipe (poseidon_gl.hpp, mds_layer_mfma): an MFMA is a
 // wave-wide instruction, so no lane leaves early - lanes past the end work on a clamped index and skip the store.  Waves per SIMD:
-// the MFMA form holds 16-register result tiles next to the state (measured: tools/ab_kernel_times.sh, GB_POSEIDON_OCC).
-#ifndef GB_POSEIDON_OCC
-#define GB_POSEIDON_OCC 4
-#endif
-// Round 4: the 22 partial rounds run in GROUPS (poseidon_gl_grouped.hpp; GB_POSEIDON_GROUP rounds per group, default 4): one cut
-// into byte planes and one recombination per group instead of per round, the group's matrix M^G cut into G byte planes on the
-// matrix pipe, the words the group's later s-boxes see as VALU dot products - 11.3 k VALU instructions per permutation where the
-// form with 30 single layers (GB_POSEIDON_SINGLE_LAYERS: round 3's permute_mont_mfma_naive, kept for the ablation) takes 14.0 k.
+// the MFMA form holds 16-register result tiles next to the state - four (measured against three and five, HISTORY.md rounds 3-5).
+static constexpr int POSEIDON_OCC = 4;
+// Round 4: the 22 partial rounds run in GROUPS of four (poseidon_gl_grouped.hpp): one cut into byte planes and one recombination
+// per group instead of per round, the group's matrix M^4 cut into four byte planes on the matrix pipe, the words the group's later
+// s-boxes see as VALU dot products - 11.3 k VALU instructions per permutation where 30 single layers took 14.0 k.
 // The group operands live in LDS: every kernel fills its workgroup's table first (GB_POSEIDON_OPS, one barrier).
-#if defined(GB_POSEIDON_HYBRID)
-#define GB_POSEIDON_OPS() const poseidon_gl::v4i* gops = nullptr
-#define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma(s, amat)
-#elif defined(GB_POSEIDON_SINGLE_LAYERS)
-#define GB_POSEIDON_OPS() const poseidon_gl::v4i* gops = nullptr
-#define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma_naive(s, amat)
-#else
 #define GB_POSEIDON_OPS()                                            \
     __shared__ poseidon_gl::v4i gops_lds[poseidon_gl::GROUP_LDS_V4]; \
     poseidon_gl::group_ops_init(gops_lds);                           \
     const poseidon_gl::v4i* gops = gops_lds + (threadIdx.x & 63)
-#ifdef GB_NO_ZERO_CAP   // A/B: the four capacity s-boxes of a permutation that starts from a zero capacity computed like any other
-#define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma_grouped(s, amat, gops, cap_only, false)
-#else
 #define permute_mont_mfma(s, amat, cap_only, zero_cap) poseidon_gl::permute_mont_mfma_grouped(s, amat, gops, cap_only, zero_cap)
-#endif
-#endif
 // The sponge state of these kernels is kept in the permutation's Montgomery form (poseidon_gl.hpp): absorbed words go through
 // to_mont, the digest through from_mont (canonical); the capacity words never leave that form between absorptions.
 
-#ifdef GB_PROBE
-// Attribution build (tools/probe_leaves.py; never the product): every `wave_step`-th wave of k_gl_merkle_leaves writes a
-// (s_memtime, site) pair at each probe site into its slice of a trace buffer.
-struct ProbeCfg {
-    ulonglong2* buf;
-    u32 max_per_wave, wave_step, nslots;
-};
-__device__ ProbeCfg gb_probe_cfg;
-extern "C" int gb_probe_setup(void* dev_buf, unsigned max_per_wave, unsigned wave_step, unsigned nslots) {
-    ProbeCfg c{static_cast<ulonglong2*>(dev_buf), max_per_wave, wave_step, nslots};
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(gb_probe_cfg), &c, sizeof c);
-}
-#define GB_PROBE_INIT(amat)                                                                        \
-    do {                                                                                           \
-        const u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
-        const ProbeCfg pc = gb_probe_cfg;                                                          \
-        const bool traced = pc.buf && pc.wave_step && wave % pc.wave_step == 0 && wave / pc.wave_step < pc.nslots; \
-        amat.trace = traced ? pc.buf + (size_t)(wave / pc.wave_step) * pc.max_per_wave : nullptr;  \
-        amat.pidx = 0;                                                                             \
-    } while (0)
-#else
-#define GB_PROBE_INIT(amat) do {} while (0)
-#endif
-
-// The NEXT absorption's eight columns on their way while this one is permuted (GB_ABSORB_PREFETCH: an experiment of round 5, off in
-// the product).  A wave reads 512 contiguous bytes per column, and the s_memtime attribution
-// (profiles/r05_leaf_kernel_probe_attribution.txt) shows it parked ~10 k cycles per absorption on those loads; there are no sixteen
-// registers to land them in early (128 VGPRs, 4 waves per SIMD), so one throw-away dword per lane and column pulls the lines into
-// the cache hierarchy instead.  Measured: 41.0 ms with, 41.0-41.2 ms without (profiles/r05_leaf_kernel_ab.txt) - the three other
-// waves of the SIMD issue while one waits, nothing is gained.  (The asm loads are older than any load the compiler counts in vmcnt
-// and return in order: its waits stay correct.)
-__device__ __forceinline__ void prefetch_columns(const u64* __restrict__ cols, size_t col_stride, u32 c0, u32 c_end, u64 j) {
-#ifdef GB_ABSORB_PREFETCH
-    u32 sink;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (c0 + i < c_end) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(cols + (size_t)(c0 + i) * col_stride + j) : "memory");
-#endif
-}
+GB_LAB_DEFINE_PROBE_SETUP   // (lab builds: the attribution probes' setter, poseidon_gl_lab.hpp; nothing in the product)
 
 // hash/hashing.rs:100-123 (overwrite-mode sponge, rate 8) + plonk/config.rs:70-84 (hash_or_noop)
-__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
+__global__ __launch_bounds__(256, POSEIDON_OCC) void k_gl_merkle_leaves(const u64* __restrict__ cols, size_t col_stride, u32 width,
                                                                         u64 num_leaves, u64* __restrict__ out) {
     const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = j0 < num_leaves;
     const u64 j = live ? j0 : num_leaves - 1;
-#ifdef GB_PROBE
     poseidon_gl::MdsOperand amat = mds_mfma_matrix();
-    GB_PROBE_INIT(amat);
-#else
-    const poseidon_gl::MdsOperand amat = mds_mfma_matrix();
-#endif
+    GB_LAB_PROBE_INIT(amat);   // (lab builds: tools/probe_leaves.py; nothing in the product)
     GB_POSEIDON_OPS();
     u64 s[12];
 #pragma unroll
@@ -116,7 +58,6 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const
                 for (int i = 0; i < 8; i++)
                     if (c0 + i < width) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
             }
-            prefetch_columns(cols, col_stride, c0 + 8, width, j);
             GB_PROBE_AT(amat, 2, s);   // absorption: 8 column loads + to_mont
             // (a full absorption follows: words 0..7 of this permutation's output will be overwritten - only the capacity is produced)
             permute_mont_mfma(s, amat, c0 + 16 <= width, c0 == 0);  // the state stays a lazy Montgomery-form residue between absorptions; the first absorption meets a zero capacity
@@ -137,7 +78,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves(const
 // last absorption leaves alone (`keep_from` .. 7) when the following segment starts with it.  FIRST: fresh sponge; LAST: the
 // digest goes to `out`.  Every segment but the last absorbs whole groups of 8 columns.
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(const u64* __restrict__ cols, size_t col_stride, u32 c_begin,
+__global__ __launch_bounds__(256, POSEIDON_OCC) void k_gl_merkle_leaves_seg(const u64* __restrict__ cols, size_t col_stride, u32 c_begin,
                                                                             u32 c_end, u64 num_leaves, u64* __restrict__ state,
                                                                             u32 keep_from, u64* __restrict__ out) {
     const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,7 +107,6 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(c
             for (int i = 0; i < 8; i++)
                 if (c0 + i < c_end) s[i] = to_mont(cols[(size_t)(c0 + i) * col_stride + j]);
         }
-        prefetch_columns(cols, col_stride, c0 + 8, c_end, j);
         // is the absorption that follows (in this segment or at the head of the next) a full one?  then only the capacity matters
         const bool next_full = LAST ? c0 + 16 <= c_end : (c0 + 8 < c_end || keep_from == 8);
         permute_mont_mfma(s, amat, next_full, FIRST && c0 == c_begin);
@@ -188,7 +128,7 @@ __global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_leaves_seg(c
 }
 
 // hash/hashing.rs:76-96 compress / Hasher::two_to_one
-__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
+__global__ __launch_bounds__(256, POSEIDON_OCC) void k_gl_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, u64 num_out) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < num_out;
     const u64 i = live ? i0 : num_out - 1;
@@ -309,7 +249,7 @@ __global__ void k_u64_transpose_to_rows(const u64* __restrict__ cols, size_t col
 }
 
 // raw permutation, canonical in and out, through the same MFMA form the tree kernels use (gb_permute: the reference's KATs)
-__global__ __launch_bounds__(256, GB_POSEIDON_OCC) void k_gl_poseidon_permute(const u64* __restrict__ in, u64* __restrict__ out, u64 count) {
+__global__ __launch_bounds__(256, POSEIDON_OCC) void k_gl_poseidon_permute(const u64* __restrict__ in, u64* __restrict__ out, u64 count) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;

@@ -190,10 +190,7 @@ __global__ __launch_bounds__(256) void k_zs_finalize(ZsParams<F> p, const typena
 // accumulators stay in registers and a chunk's 2*CH loads are issued together.
 // waves per SIMD of k_quotient: the Goldilocks instance needs 97 VGPRs unconstrained - one more than five waves allow; held to 96
 // it runs 5.14 -> 5.05 ms at 2^20 rows (tools/ab_kernel_times.sh)
-#ifndef GB_QUOTIENT_OCC_GL
-#define GB_QUOTIENT_OCC_GL 5
-#endif
-#define GB_QUOTIENT_OCC(F) (sizeof(typename F::T) == 8 ? GB_QUOTIENT_OCC_GL : 4)
+#define GB_QUOTIENT_OCC(F) (sizeof(typename F::T) == 8 ? 5 : 4)
 template <class F, u32 C, u32 CH, bool SLICE>
 __global__ __launch_bounds__(256, GB_QUOTIENT_OCC(F)) void k_quotient(QuotientParams<F> p, const typename F::T* __restrict__ cs,
                                                   const typename F::T* __restrict__ wires, const typename F::T* __restrict__ zs,

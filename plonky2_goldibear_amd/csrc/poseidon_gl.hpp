@@ -16,6 +16,7 @@
 #pragma once
 #include "gl_field.hpp"
 #include "poseidon_constants.h"
+#include "poseidon_gl_lab.hpp"   // GB_PROBE_AT / GB_LAB_*: empty in the product
 
 namespace poseidon_gl {
 
@@ -360,19 +361,9 @@ __device__ static const raw::MfmaInitTable MFMA_INIT = raw::mfma_init_table();
 
 // The compiler pads MFMA -> VALU hazards with s_nop (gfx950 has no interlock: a read of a tile register is stale for 11 wait
 // states after the MFMA, a write to one is overwritten by the pipe's write-back for 8; tools/microbench_mfma_hazard.hip), but its
-// hazard recognizer does not look inside INLINE ASM - and the recombination below is made of asm v_mad_i64_i32.  Their sources
-// are never tile registers (a plain v_lshl_add_u32 reads the tile first and is padded), but their DESTINATIONS are whatever the
-// allocator finds free, and the registers of a tile that the kernel never reads (d[12..15] of a layer, most of a phase-A tile)
-// are free the moment the MFMA has issued: a result parked there is overwritten when the pipe writes the tile back.  That is
-// what round 3's "undefined operand" variant did (tools/mfma_guard.py shows twelve such writes in it, 1-5 wait states after the
-// MFMA) and what the first grouped kernels did.  GB_KEEP_TILES(d0, d1, after) keeps all sixteen registers of both tiles allocated
-// until `after` - a value computed from a padded read of the tiles - exists (without that operand the scheduler hoists the
-// statement to the MFMA itself), and tests/test_mfma_guard.py checks the assembly of every kernel for the pattern.
-#if defined(GB_EXP_NO_KEEP_TILES) || !defined(GB_MAD_ASM)   // (GB_EXP_NO_KEEP_TILES + GB_MAD_ASM: the negative case of tests/test_mfma_guard.py)
-#define GB_KEEP_TILES(d0, d1, after)
-#else
-#define GB_KEEP_TILES(d0, d1, after) asm volatile("" ::"v"(d0), "v"(d1), "v"(after))
-#endif
+// hazard recognizer does not look inside INLINE ASM: the recombination below is therefore written in C (round 3's asm form parked
+// results in tile registers the kernel never reads and hashed wrongly, HISTORY.md round 4); tests/test_mfma_guard.py checks the
+// assembly of every kernel for the pattern (tools/mfma_guard.py).
 // a * b + c, signed 32 x 32 + 64, as ONE v_mad_i64_i32.  Written in C so that the hazard recognizer sees the instruction; the
 // multipliers 1 and 2^16 are OPAQUE register constants (MdsOperand::one / ::k16: a volatile asm v_mov at the top of the kernel,
 // before any MFMA exists, that the optimizer cannot look into), or the compiler turns the products into sign-extend + shift + add.
@@ -380,73 +371,13 @@ __device__ static const raw::MfmaInitTable MFMA_INIT = raw::mfma_init_table();
 struct MdsOperand {
     v4i a;          // this lane's share of the constant A operand (mds_mfma_matrix)
     int one, k16;   // 1 and 65536
-#ifdef GB_PROBE     // tools/probe_leaves.py: time stamps of a few waves at segment boundaries (an attribution build, never the product)
-    mutable ulonglong2* trace;   // this wave's slice of the trace buffer, or nullptr (wave-uniform)
-    mutable u32 pidx;
-#endif
+    GB_LAB_PROBE_FIELDS
 };
-// GB_PROBE_AT(amat, ID, s): in the attribution build, wave time stamp (s_memtime, shader clock) + site ID into the wave's trace.
-// The state words pass through an empty asm as in-out operands, so that the vector work in front of the site is in front of it in
-// the instruction stream and the work behind it behind (a time stamp alone does not order arithmetic).  Nothing in the product.
-#ifdef GB_PROBE
-template <int N>
-__device__ __forceinline__ void probe_pin(u64 (&s)[N]) {
-    if constexpr (N == 12)
-        asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]), "+v"(s[8]), "+v"(s[9]),
-                     "+v"(s[10]), "+v"(s[11]));
-    else
-#pragma unroll
-        for (int i = 0; i < N; i++) asm volatile("" : "+v"(s[i]));
-}
-template <int N>
-__device__ __forceinline__ void probe_pin(long long (&s)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; i++) asm volatile("" : "+v"(s[i]));
-}
-template <int A, int B>
-__device__ __forceinline__ void probe_pin(u32 (&p)[A][B]) {
-#pragma unroll
-    for (int i = 0; i < A; i++)
-#pragma unroll
-        for (int j = 0; j < B; j++) asm volatile("" : "+v"(p[i][j]));
-}
-template <int ID>
-__device__ __forceinline__ void probe_stamp(const MdsOperand& m) {
-    asm volatile("; GB_PROBE_SITE %0" ::"n"(ID));
-    if (m.trace) {
-        const u64 t = __builtin_amdgcn_s_memtime();
-        if ((threadIdx.x & 63) == 0) m.trace[m.pidx] = make_ulonglong2(t, (u64)ID);
-        m.pidx++;
-    }
-}
-#define GB_PROBE_AT(amat, ID, ...)          \
-    do {                                    \
-        poseidon_gl::probe_pin(__VA_ARGS__);\
-        poseidon_gl::probe_stamp<ID>(amat); \
-    } while (0)
-#else
-#define GB_PROBE_AT(amat, ID, ...) do {} while (0)
-#endif
-#ifdef GB_MAD_ASM   // round 3's form (inline asm, invisible to the hazard recognizer: needs GB_KEEP_TILES)
-__device__ __forceinline__ long long mad_i64(int a, const MdsOperand& m, long long c) {
-    long long d;
-    u64 carry_unused;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(65536), "v"(c));
-    return d;
-}
-__device__ __forceinline__ long long mad_i64_start(int a, const MdsOperand& m, u64 c_uniform) {
-    long long d;
-    u64 carry_unused;
-    asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry_unused) : "v"(a), "s"(c_uniform));
-    return d;
-}
-#else
 __device__ __forceinline__ long long mad_i64(int a, const MdsOperand& m, long long c) { return (long long)a * (long long)m.k16 + c; }
 // a + c with c a UNIFORM 64-bit value: the accumulator's start value is the addend of a multiplication by the opaque 1
 __device__ __forceinline__ long long mad_i64_start(int a, const MdsOperand& m, u64 c_uniform) {
     return (long long)a * (long long)m.one + (long long)c_uniform;
 }
-#endif
 // 4 x 4 byte transpose: t[p] = [w0.b_p, w1.b_p, w2.b_p, w3.b_p] (8 v_perm_b32)
 __device__ __forceinline__ void byte_transpose4(u32 w0, u32 w1, u32 w2, u32 w3, u32 (&t)[4]) {
     const u32 a_lo = __builtin_amdgcn_perm(w1, w0, 0x05010400u);  // [w0.b0, w1.b0, w0.b1, w1.b1]
@@ -458,60 +389,6 @@ __device__ __forceinline__ void byte_transpose4(u32 w0, u32 w1, u32 w2, u32 w3, 
     t[2] = __builtin_amdgcn_perm(b_hi, a_hi, 0x05040100u);
     t[3] = __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
 }
-// The high words of four folds at once: r1[i] = th[i] + sh[i] (mod 2^32) and cnt += the carries, ALL ON THE VECTOR SIDE - an
-// experiment of round 5 (GB_FOLD_VCNT), NOT the product.  The product's fold ORs every add's carry mask into a scalar register pair:
-// twelve VALU -> SALU hand-overs per fold, and the s_memtime attribution (profiles/r05_leaf_kernel_probe_attribution.txt) shows a wave
-// spending 7.6 % of its lifetime in the folds for 2.3 % of its issue work.  Counting the carries with v_addc through three rotating
-// scalar pairs and looking at the counter once per fold removes those hand-overs - and makes the kernel 1.4 % SLOWER
-// (41.0-41.2 -> 41.5-41.8 ms, profiles/r05_leaf_kernel_ab.txt): while one wave waits for its scalar OR the three others issue, so
-// the wait costs the SIMD nothing, and the twelve extra vector instructions do.  The kernel's time is its VALU instruction count.
-// Inline asm: the hazard recognizer does not see it, so the sequence itself keeps two instructions between a VALU write of a
-// scalar pair and the VALU read of it (gfx940+: VALU writes SGPR -> VALU reads it: 2 wait states).
-__device__ __forceinline__ void fold_high4(u32 (&r1)[4], const u32 (&th)[4], const u32 (&sh)[4], u32& cnt) {
-    u64 ca, cb, cc;   // three rotating carry masks (scalar register pairs)
-    asm("v_add_co_u32 %0, %5, %8, %12\n\t"
-        "v_add_co_u32 %1, %6, %9, %13\n\t"
-        "v_add_co_u32 %2, %7, %10, %14\n\t"
-        "v_addc_co_u32_e64 %4, vcc, 0, %4, %5\n\t"
-        "v_add_co_u32 %3, %5, %11, %15\n\t"
-        "v_addc_co_u32_e64 %4, vcc, 0, %4, %6\n\t"
-        "v_addc_co_u32_e64 %4, vcc, 0, %4, %7\n\t"
-        "v_addc_co_u32_e64 %4, vcc, 0, %4, %5"
-        : "=&v"(r1[0]), "=&v"(r1[1]), "=&v"(r1[2]), "=&v"(r1[3]), "+v"(cnt), "=&s"(ca), "=&s"(cb), "=&s"(cc)
-        : "v"(th[0]), "v"(th[1]), "v"(th[2]), "v"(th[3]), "v"(sh[0]), "v"(sh[1]), "v"(sh[2]), "v"(sh[3])
-        : "vcc");
-}
-// (lo, hi)[Q0 .. 12) -> s[q] = lo + 2^32 hi as a lazy residue: value = (lo + (hi >> 32) EPS) + 2^32 (u32)hi, and the last addition
-// wraps only when (u32)hi lies within 2^12 of 2^32 - about 4e-4 of the wave-folds have such a lane.  The fast path is one mad and one
-// add per word (+ a quarter of fold_high4's counter adds); a wave in which any lane wrapped takes the branch and adds EPS (= 2^64
-// mod p) in those lanes (no second wrap: a wrapped high word is < 2^12).
-template <int Q0>
-__device__ __forceinline__ void fold_rows_counted(u64 (&s)[12], const long long (&lo)[12], const long long (&hi)[12]) {
-    static_assert((12 - Q0) % 4 == 0, "words are folded four at a time");
-    u32 cnt = 0;
-#pragma unroll
-    for (int q0 = Q0; q0 < 12; q0 += 4) {
-        u32 tl[4], th[4], sh[4], r1[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const u64 t = (u64)lo[q0 + i] + (u64)(u32)((u64)hi[q0 + i] >> 32) * EPS;
-            tl[i] = (u32)t;
-            th[i] = (u32)(t >> 32);
-            sh[i] = (u32)hi[q0 + i];
-        }
-        fold_high4(r1, th, sh, cnt);
-#pragma unroll
-        for (int i = 0; i < 4; i++) s[q0 + i] = (u64)tl[i] | ((u64)r1[i] << 32);
-    }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt != 0) != 0, 0)) {
-#pragma unroll
-        for (int q = Q0; q < 12; q++) {
-            const bool wrapped = (u32)(s[q] >> 32) < (u32)hi[q];   // r1 = t_hi + (u32)hi wrapped  <=>  r1 < (u32)hi
-            s[q] += wrapped ? EPS : 0;
-        }
-    }
-}
-
 // This lane's share of the constant A operand (see above); call with all 64 lanes of the wave active, blockDim.x a multiple of 64.
 __device__ __forceinline__ MdsOperand mds_mfma_matrix() {
     const u32 l = threadIdx.x & 63, r = l & 31, h = l >> 5;
@@ -564,26 +441,6 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& a
     const u64* ihi = MFMA_INIT.hi + 12 * rnext;
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int pad = amat.a[3];   // the fourth dword of the B operands (k = 12..15, which meet zeros in A): A's own fourth dword, zero in every lane
-#ifdef GB_MFMA_DEPTH4   // ablation: four MFMAs in flight (64 result registers) instead of two
-#pragma unroll
-    for (int hh = 0; hh < 2; hh++) {
-        v16i d[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            v4i b;
-            b[0] = (int)pl[4 * hh + p][0]; b[1] = (int)pl[4 * hh + p][1]; b[2] = (int)pl[4 * hh + p][2]; b[3] = pad;
-            d[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(amat.a, b, zero, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = Q0; q < 12; q++) {
-            const int t01 = (int)(((u32)d[1][q] << 8) + (u32)d[0][q]);
-            const int t23 = (int)(((u32)d[3][q] << 8) + (u32)d[2][q]);
-            if (hh == 0) lo[q] = mad_i64(t23, amat, mad_i64_start(t01, amat, ilo[q]));
-            else hi[q] = mad_i64(t23, amat, mad_i64_start(t01, amat, ihi[q]));
-        }
-        GB_KEEP_TILES(d[0], d[1], hh == 0 ? lo[11] : hi[11]); GB_KEEP_TILES(d[2], d[3], hh == 0 ? lo[11] : hi[11]);
-    }
-#else
 #pragma unroll
     for (int pp = 0; pp < 4; pp++) {   // planes two at a time: d_p + 2^8 d_(p+1) fits 32 bits (|.| < 2^25)
         v4i b0, b1;
@@ -599,19 +456,12 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& a
             else if (pp == 2) hi[q] = mad_i64_start(t, amat, ihi[q]);
             else hi[q] = mad_i64(t, amat, hi[q]);
         }
-        GB_KEEP_TILES(d0, d1, pp < 2 ? lo[11] : hi[11]);
     }
-#endif
-#ifdef GB_PROBE
-    if constexpr (Q0 == 0) { probe_pin(lo); probe_pin(hi); probe_stamp<21>(amat); }   // layer: 8 MFMAs + recombination
-#endif
+    if constexpr (Q0 == 0) GB_PROBE_AT(amat, 21, lo, hi);   // layer: 8 MFMAs + recombination
     // fold_halves with its carry fix on a rare path: value = lo + 2^32 hi = (lo + (hi >> 32) EPS) + 2^32 (u32)hi, and the last
     // addition wraps only when (u32)hi lies within 2^12 of 2^32 - about 4e-4 of the wave-layers have such a lane.  The fast path
     // is one mad and one add per word; the wave-wide OR of the carries is scalar work, and a wave in which any lane wrapped
     // takes the branch and adds EPS (= 2^64 mod p) in those lanes (no second wrap: a wrapped high word is < 2^12).
-#ifdef GB_FOLD_VCNT   // round 5 A/B: the carries counted on the vector side (fold_rows_counted) - 1.4 % SLOWER, see fold_high4
-    fold_rows_counted<Q0>(s, lo, hi);
-#else
     u64 any_carry = 0;
 #pragma unroll
     for (int q = Q0; q < 12; q++) {
@@ -630,171 +480,6 @@ __device__ __forceinline__ void mds_layer_mfma(u64 (&s)[12], const MdsOperand& a
             s[q] += wrapped ? EPS : 0;
         }
     }
-#endif
-}
-
-// Four full rounds; the state comes in with round0's constants already added, and leaves with `tail_rc` added (the
-// constants of whatever layer follows: FAST_PARTIAL_FIRST_ROUND_CONSTANT after the first half, nothing after the second).
-__device__ __forceinline__ void full_rounds(u64 (&s)[12], int round0, const u64* __restrict__ tail_rc) {
-    for (int k = 0; k < HALF_FULL; k++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        mds_layer(s, k + 1 < HALF_FULL ? GB_RC + 12 * (round0 + k + 1) : tail_rc);
-    }
-}
-
-// Rounds 0..3 of the permutation (state comes in with round 0's constants added) and everything linear up to the first
-// partial round: the fourth round's MDS, partial_first_constant_layer (:632-638) and mds_partial_layer_init (:657-683)
-// are applied as ONE 12 x 11 dot-product layer (MI_L, MI_K) plus the MDS's row 0 for the word that stays outside M_init.
-__device__ __forceinline__ void first_half_tail(u64 (&s)[12]);
-__device__ __forceinline__ void first_half(u64 (&s)[12]) {
-    for (int k = 0; k < HALF_FULL - 1; k++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        mds_layer(s, GB_RC + 12 * (k + 1));
-    }
-    first_half_tail(s);
-}
-// the fourth round: s-boxes, then MDS + first partial constants + M_init as one dot-product layer
-__device__ __forceinline__ void first_half_tail(u64 (&s)[12]) {
-    u64 y[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) y[i] = sbox(s[i]);
-    {  // row 0 of the MDS + FAST_PARTIAL_FIRST_ROUND_CONSTANT[0]
-        const u64 c = GB_FP_FIRST[0];
-        u64 sl = (u32)c, sh = c >> 32;
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            sl += (u64)(u32)y[i] * mds_circ(i);
-            sh += (u64)(u32)(y[i] >> 32) * mds_circ(i);
-        }
-        sl += (u64)(u32)y[0] * MDS_DIAG0;
-        sh += (u64)(u32)(y[0] >> 32) * MDS_DIAG0;
-        u64 t = sl + (sh >> 32) * EPS, r2;
-        bool cy = __builtin_uaddll_overflow(t, sh << 32, &r2);
-        r2 += cy ? EPS : 0;
-        s[0] = r2;
-    }
-#pragma unroll
-    for (int c = 1; c < 12; c++) {
-        Dot d;
-        const u64 kc = MI_K[c - 1];
-        d.t0[0] = (u32)kc;
-        d.t1[0] = kc >> 32;
-#pragma unroll
-        for (int j = 0; j < 12; j++) d.acc(y[j], MI_L.v[j * 11 + (c - 1)]);
-        s[c] = d.finish();
-    }
-}
-
-__device__ __forceinline__ void partial_rounds(u64 (&s)[12]) {
-    // Two rounds per iteration.  Round k updates s_i += u_k v_{k,i}; instead of reducing that and multiplying it into
-    // round k+1's dot product, round k+1 takes the block-start s_i plus u_k PAIR_C (linearity), and the state is updated
-    // once per pair: s_i + u_k v_{k,i} + u_{k+1} v_{k+1,i} summed as five limbs and folded once (11 folds per pair saved).
-    for (int kk = 0; kk < N_PARTIAL / 2; kk++) {
-        const int k = 2 * kk;
-        const Limb3* wh0 = WHATS_L.v + 11 * k;
-        const Limb3* wh1 = wh0 + 11;
-        const u64* vs0 = FP_VS + 11 * k;
-        const u64* vs1 = vs0 + 11;
-        // mds_partial_layer_fast (:718-744): d = s0*(CIRC[0]+DIAG[0]) + sum_i s[i]*w_hat[i-1]
-        const u64 u0 = add_rc(sbox(s[0]), GB_FP_RC[k]);
-        Dot d0;
-        d0.acc_small(u0, mds_circ(0) + MDS_DIAG0);
-#pragma unroll
-        for (int i = 1; i < 12; i++) d0.acc(s[i], wh0[i - 1]);
-        const u64 u1 = add_rc(sbox(d0.finish()), GB_FP_RC[k + 1]);
-        Dot d1;
-        d1.acc_small(u1, mds_circ(0) + MDS_DIAG0);
-#pragma unroll
-        for (int i = 1; i < 12; i++) d1.acc(s[i], wh1[i - 1]);
-        d1.acc(u0, PAIR_L.v[kk]);
-#pragma unroll
-        for (int i = 1; i < 12; i++) {
-            u32 p0, p1, p2, p3, q0, q1, q2, q3, c0, c1, c2, c3;
-            gl::mul_limbs(u0, vs0[i - 1], p0, p1, p2, p3);
-            gl::mul_limbs(u1, vs1[i - 1], q0, q1, q2, q3);
-            // p + q + s_i as five limbs
-            u32 r0 = __builtin_addc(p0, q0, 0u, &c0);
-            u32 r1 = __builtin_addc(p1, q1, c0, &c1);
-            u32 r2 = __builtin_addc(p2, q2, c1, &c2);
-            u32 r3 = __builtin_addc(p3, q3, c2, &c3);
-            u32 r4 = c3;
-            r0 = __builtin_addc(r0, (u32)s[i], 0u, &c0);
-            r1 = __builtin_addc(r1, (u32)(s[i] >> 32), c0, &c1);
-            r2 = __builtin_addc(r2, 0u, c1, &c2);
-            r3 = __builtin_addc(r3, 0u, c2, &c3);
-            r4 += c3;
-            s[i] = gl::fold160(r0, r1, r2, r3, r4);
-        }
-        s[0] = d1.finish();
-    }
-}
-
-// permute_mont with the seven plain MDS layers of the full rounds on the matrix pipe (the fourth round's layer stays inside the
-// merged 12 x 11 dot-product layer of first_half, the partial rounds in their fast form).  `amat` = mds_mfma_matrix(); all 64
-// lanes of the wave must be here together.  Same function, same lazy Montgomery-form conventions as permute_mont.
-__device__ __forceinline__ void permute_mont_mfma(u64 (&s)[12], const MdsOperand& amat) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
-    for (int k = 0; k < HALF_FULL - 1; k++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        mds_layer_mfma(s, amat, k + 1);
-    }
-    first_half_tail(s);
-    partial_rounds(s);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[12 * (HALF_FULL + N_PARTIAL) + i]);
-    for (int k = 0; k < HALF_FULL; k++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        mds_layer_mfma(s, amat, k + 1 < HALF_FULL ? HALF_FULL + N_PARTIAL + k + 1 : MFMA_NO_RC);
-    }
-}
-
-// The permutation in the reference's NAIVE round structure (hash/poseidon_goldilocks.rs:927-948: constants, s-box - all twelve
-// words in the full rounds, word 0 in the partial ones - then the full MDS; output-identical to the fast form, :1196-1198) with
-// every one of the 30 MDS layers on the matrix pipe: a partial round is then one s-box + one mds_layer_mfma (~310 VALU
-// instructions) where the fast form's sparse-matrix round is ~380 with 64-bit constants.
-__device__ __forceinline__ void permute_mont_mfma_naive(u64 (&s)[12], const MdsOperand& amat) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
-    for (int r = 0; r < 2 * HALF_FULL + N_PARTIAL; r++) {
-        if (r < HALF_FULL || r >= HALF_FULL + N_PARTIAL) {
-#pragma unroll
-            for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        } else {
-            s[0] = sbox(s[0]);
-        }
-        mds_layer_mfma(s, amat, r + 1 < 2 * HALF_FULL + N_PARTIAL ? r + 1 : MFMA_NO_RC);
-    }
-}
-
-// state in and out: MONTGOMERY-form residues, any u64 (to_mont what is absorbed, from_mont what is squeezed)
-__device__ __forceinline__ void permute_mont(u64 (&s)[12]) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[i]);
-    first_half(s);
-    partial_rounds(s);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = add_rc(s[i], GB_RC[12 * (HALF_FULL + N_PARTIAL) + i]);
-    full_rounds(s, HALF_FULL + N_PARTIAL, ZERO_RC);
-}
-
-// state in: any u64 residues; state out: any u64 residues (call to_canonical before storing)
-__device__ __forceinline__ void permute_lazy(u64 (&s)[12]) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = to_mont(s[i]);
-    permute_mont(s);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = mont_fold((u32)s[i], (u32)(s[i] >> 32), 0u, 0u);
-}
-
-__device__ __forceinline__ void permute(u64 (&s)[12]) {
-    permute_lazy(s);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = to_canonical(s[i]);
 }
 
 }  // namespace poseidon_gl

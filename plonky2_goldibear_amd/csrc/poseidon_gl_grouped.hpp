@@ -19,31 +19,17 @@ namespace poseidon_gl {
 
 namespace grp = poseidon_gl_groups;
 
-// The plan: GB_POSEIDON_GROUP_COUNT groups of GB_POSEIDON_GROUP partial rounds, then one group of GB_POSEIDON_GROUP2 (0: none),
-// then whatever is left of the 22 as single layers (mds_layer_mfma).
-#ifndef GB_POSEIDON_GROUP
-#define GB_POSEIDON_GROUP 4
-#endif
-#ifndef GB_POSEIDON_GROUP_COUNT
-#define GB_POSEIDON_GROUP_COUNT (22 / GB_POSEIDON_GROUP)
-#endif
-#ifndef GB_POSEIDON_GROUP2
-#define GB_POSEIDON_GROUP2 ((22 - GB_POSEIDON_GROUP * GB_POSEIDON_GROUP_COUNT) >= 2 ? (22 - GB_POSEIDON_GROUP * GB_POSEIDON_GROUP_COUNT) : 0)
-#endif
-#ifndef GB_POSEIDON_PHASE_A_MFMA
-#define GB_POSEIDON_PHASE_A_MFMA 0   // 1: the words the later s-boxes see come from MFMAs too (phase A operands), 0: from VALU dot products
-#endif
-static constexpr int GROUP_G = GB_POSEIDON_GROUP, GROUP_N = GB_POSEIDON_GROUP_COUNT, GROUP_G2 = GB_POSEIDON_GROUP2;
-static constexpr int GROUP_SINGLES = N_PARTIAL - GROUP_G * GROUP_N - GROUP_G2;
-static_assert(GROUP_SINGLES >= 0 && GROUP_G >= 2 && GROUP_G <= 5 && (GROUP_G2 == 0 || (GROUP_G2 >= 2 && GROUP_G2 <= 5)), "partial-round plan");
-// operands a workgroup keeps in LDS: the phase-B planes, and the phase-A planes in front of them when phase A runs on the matrix pipe
+// The plan: five groups of four partial rounds and one of two (G = 2 ... 4 with and without a remainder group, and phase A on the
+// matrix pipe as well, were measured in round 4: HISTORY.md, profiles/r04_poseidon_group_ablations.txt).
+static constexpr int GROUP_G = 4, GROUP_N = 5, GROUP_G2 = 2;
+static_assert(GROUP_G * GROUP_N + GROUP_G2 == N_PARTIAL, "partial-round plan");
+// operands a workgroup keeps in LDS: the phase-B planes of Shape<G>::ops() (the G - 1 phase-A planes in front of them are not loaded:
+// the words the later s-boxes see are VALU dot products - row 0 of M^j, j <= 3, times twelve 32-bit halves fits 64 bits)
 template <int G>
 struct GroupOps {
-    static constexpr int skip = GB_POSEIDON_PHASE_A_MFMA ? 0 : G - 1;            // operands of Shape<G>::ops() that are not loaded
-    static constexpr int count = G >= 2 ? 2 * G - 1 - skip : 0;
-    static constexpr int first_b = GB_POSEIDON_PHASE_A_MFMA ? G - 1 : 0;         // index of phase B's plane 0 in the table
+    static constexpr int skip = G - 1;
+    static constexpr int count = G;
 };
-static_assert(GB_POSEIDON_PHASE_A_MFMA || (GROUP_G <= 4 && GROUP_G2 <= 4), "row 0 of M^4 times twelve 32-bit halves does not fit 64 bits");
 static constexpr int GROUP_OPS_MAIN = GroupOps<GROUP_G>::count, GROUP_OPS_REM = GroupOps<GROUP_G2>::count;
 static constexpr int GROUP_OPS_TOTAL = GROUP_OPS_MAIN + GROUP_OPS_REM;
 static constexpr int GROUP_LDS_V4 = GROUP_OPS_TOTAL * 64;   // v4i entries a workgroup needs
@@ -117,7 +103,7 @@ __device__ __forceinline__ void group_chain(v16i& d, const u32 (&pl)[8][4], cons
     constexpr int n = PHASE_B ? S::LEN_B[PLANE] : S::LEN_A[PLANE];
     if constexpr (E < n) {
         constexpr grp::Mfma m = PHASE_B ? S::SCHED_B[PLANE][E] : S::SCHED_A[PLANE][E];
-        const v4i a = ops[((PHASE_B ? GroupOps<G>::first_b : 0) + m.k) * 64];
+        const v4i a = ops[m.k * 64];
         v4i b;
         if constexpr (m.comp != 0) {
             b[0] = (int)cpl[m.p][0]; b[1] = (int)cpl[m.p][1]; b[2] = (int)cpl[m.p][2]; b[3] = (int)cpl[m.p][3];
@@ -131,13 +117,7 @@ __device__ __forceinline__ void group_chain(v16i& d, const u32 (&pl)[8][4], cons
 template <int G, bool PHASE_B, int PLANE>
 __device__ __forceinline__ v16i group_plane(const u32 (&pl)[8][4], const u32 (&cpl)[8][4], const v4i* __restrict__ ops) {
     v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef GB_EXP_SETPRIO
-    __builtin_amdgcn_s_setprio(GB_EXP_SETPRIO);
-#endif
     group_chain<G, PHASE_B, PLANE, 0>(d, pl, cpl, ops);
-#ifdef GB_EXP_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     return d;
 }
 
@@ -179,40 +159,6 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
     GB_PROBE_AT(amat, 31, pl);   // group: byte planes of the state (cut + complements)
     // ---- phase A: the words u_1 .. u_(G-1) before the d_i terms
     u64 ulo[G - 1], uhi[G - 1];
-#if GB_POSEIDON_PHASE_A_MFMA
-    {
-        long long alo[G - 1], ahi[G - 1];
-        {
-            const v16i d0 = group_plane<G, false, 0>(pl, cpl, ops), d1 = group_plane<G, false, 1>(pl, cpl, ops);
-#pragma unroll
-            for (int j = 0; j < G - 1; j++) alo[j] = mad_i64_start((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, init.ulo[gi][j]);
-            GB_KEEP_TILES(d0, d1, alo[G - 2]);
-        }
-        {
-            const v16i d0 = group_plane<G, false, 2>(pl, cpl, ops), d1 = group_plane<G, false, 3>(pl, cpl, ops);
-#pragma unroll
-            for (int j = 0; j < G - 1; j++) alo[j] = mad_i64((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, alo[j]);
-            GB_KEEP_TILES(d0, d1, alo[G - 2]);
-        }
-        {
-            const v16i d0 = group_plane<G, false, 4>(pl, cpl, ops), d1 = group_plane<G, false, 5>(pl, cpl, ops);
-#pragma unroll
-            for (int j = 0; j < G - 1; j++) ahi[j] = mad_i64_start((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, init.uhi[gi][j]);
-            GB_KEEP_TILES(d0, d1, ahi[G - 2]);
-        }
-        {
-            const v16i d0 = group_plane<G, false, 6>(pl, cpl, ops), d1 = group_plane<G, false, 7>(pl, cpl, ops);
-#pragma unroll
-            for (int j = 0; j < G - 1; j++) ahi[j] = mad_i64((int)(((u32)d1[j] << 8) + (u32)d0[j]), amat, ahi[j]);
-            GB_KEEP_TILES(d0, d1, ahi[G - 2]);
-        }
-#pragma unroll
-        for (int j = 0; j < G - 1; j++) {
-            ulo[j] = (u64)alo[j];
-            uhi[j] = (u64)ahi[j];
-        }
-    }
-#else
     // on the VALU: row 0 of M^j has entries below 2^(8j - 3), so the two 32-bit halves of the twelve words accumulate unreduced in
     // 64 bits - 24 v_mad_u64_u32 per word, against 8 j MFMAs whose pipe time the kernel does not hide (profiles/r04_poseidon_groups.txt)
 #pragma unroll
@@ -227,10 +173,7 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
         ulo[j - 1] = lo;
         uhi[j - 1] = hi;
     }
-#endif
-#ifdef GB_PROBE
-    probe_pin(ulo); probe_pin(uhi); probe_stamp<32>(amat);   // group: phase A dot products
-#endif
+    GB_PROBE_AT(amat, 32, ulo, uhi);   // group: phase A dot products
     // ---- the s-boxes of rounds r0 + 1 .. r0 + G - 1, one after the other
     u64 dl[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -244,9 +187,7 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
         const u64 u = fold_halves(lo, hi);
         dl[j - 1] = sub_lazy(sbox(u), u);
     }
-#ifdef GB_PROBE
-    probe_pin(dl); probe_stamp<33>(amat);   // group: the G - 1 dependent s-boxes
-#endif
+    GB_PROBE_AT(amat, 33, dl);   // group: the G - 1 dependent s-boxes
     // ---- the d_j's byte planes into dword 3 of the B operands
     if constexpr (G == 2) {   // one word: byte p of it in slot 12, the slots beside it meet zeros
 #pragma unroll
@@ -274,34 +215,24 @@ __device__ __forceinline__ void partial_group(u64 (&s)[12], const MdsOperand& am
         const v16i d0 = group_plane<G, true, 0>(pl, cpl, ops), d1 = group_plane<G, true, 1>(pl, cpl, ops);
 #pragma unroll
         for (int q = 0; q < 12; q++) lo[q] = mad_i64_start((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, init.olo[gi][q]);
-        GB_KEEP_TILES(d0, d1, lo[11]);
     }
     {
         const v16i d0 = group_plane<G, true, 2>(pl, cpl, ops), d1 = group_plane<G, true, 3>(pl, cpl, ops);
 #pragma unroll
         for (int q = 0; q < 12; q++) lo[q] = mad_i64((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, lo[q]);
-        GB_KEEP_TILES(d0, d1, lo[11]);
     }
     {
         const v16i d0 = group_plane<G, true, 4>(pl, cpl, ops), d1 = group_plane<G, true, 5>(pl, cpl, ops);
 #pragma unroll
         for (int q = 0; q < 12; q++) hi[q] = mad_i64_start((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, init.ohi[gi][q]);
-        GB_KEEP_TILES(d0, d1, hi[11]);
     }
     {
         const v16i d0 = group_plane<G, true, 6>(pl, cpl, ops), d1 = group_plane<G, true, 7>(pl, cpl, ops);
 #pragma unroll
         for (int q = 0; q < 12; q++) hi[q] = mad_i64((int)(((u32)d1[q] << 8) + (u32)d0[q]), amat, hi[q]);
-        GB_KEEP_TILES(d0, d1, hi[11]);
     }
-#ifdef GB_PROBE
-    probe_pin(lo); probe_pin(hi); probe_stamp<35>(amat);   // group: phase B MFMA chains + recombination
-#endif
-#ifdef GB_FOLD_VCNT   // round 5 A/B (poseidon_gl.hpp, fold_high4): slower, not the product
-    fold_rows_counted<0>(s, lo, hi);
-#else
+    GB_PROBE_AT(amat, 35, lo, hi);   // group: phase B MFMA chains + recombination
     fold_rows_rare_carry(s, lo, hi);
-#endif
     GB_PROBE_AT(amat, 36, s);   // group: fold
 }
 
@@ -330,10 +261,6 @@ __device__ __forceinline__ void permute_mont_mfma_grouped(u64 (&s)[12], const Md
     }
     for (int gidx = 0; gidx < GROUP_N; gidx++) partial_group<GROUP_G>(s, amat, ops, HALF_FULL + GROUP_G * gidx);
     if constexpr (GROUP_G2 >= 2) partial_group<GROUP_G2>(s, amat, ops + GROUP_OPS_MAIN * 64, HALF_FULL + GROUP_G * GROUP_N);
-    for (int r = HALF_FULL + N_PARTIAL - GROUP_SINGLES; r < HALF_FULL + N_PARTIAL; r++) {
-        s[0] = sbox(s[0]);
-        mds_layer_mfma(s, amat, r + 1);
-    }
     for (int r = HALF_FULL + N_PARTIAL; r + 1 < 2 * HALF_FULL + N_PARTIAL; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);

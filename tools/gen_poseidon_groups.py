@@ -34,7 +34,7 @@ OUT = os.path.join(ROOT, "plonky2_goldibear_amd", "csrc", "poseidon_gl_groups.h"
 P = 0xFFFFFFFF00000001
 R = (1 << 64) % P            # Montgomery radix of the device's state words
 N_FULL_HALF, N_PARTIAL = 4, 22
-GROUP_SIZES = (2, 3, 4, 5)   # group shapes the header carries
+GROUP_SIZES = (2, 4)   # group shapes the header carries: the product's plan is five groups of four and one of two (3 and 5 were measured in round 4)
 MAXD = 4                     # K slots 12..15 of the B operand hold d_1 .. d_4
 
 
@@ -284,7 +284,7 @@ def check(n=6):
     rnd = random.Random(1234)
     states = [[0] * 12, [P - 1] * 12, [rnd.randrange(P) for _ in range(12)]]
     states += [[rnd.choice((0, 1, P - 1, 0x80808080_80808080 % P, 0x7F7F7F7F_7F7F7F7F, rnd.randrange(P))) for _ in range(12)] for _ in range(n)]
-    plans = [(2,) * 11, (3,) * 7 + (1,), (4,) * 5 + (2,), (5,) * 4 + (2,), (1,) * 22]
+    plans = [(2,) * 11, (4,) * 5 + (2,), (4,) * 4 + (2,) * 3, (1,) * 22]
     for st in states:
         want = permute_naive(st)
         for sizes in plans:
@@ -335,10 +335,14 @@ def emit():
     o.append("// schedules and accumulator start values; see the generator's docstring and csrc/poseidon_gl_grouped.hpp.")
     o.append("#pragma once")
     o.append("#include <stdint.h>")
-    o.append("#if defined(__HIPCC__)")
+    o.append("#if defined(__HIPCC__)   // (the one host / device split: the header is also read by host-only tools)")
     o.append("#define GB_GROUPS_DEVICE __device__")
+    o.append("#define GB_GROUPS_ACCESSORS(OPS, INIT)                                                    \\")
+    o.append("    static __device__ __forceinline__ const uint32_t (*ops())[16][4] { return OPS; }   \\")
+    o.append("    static __device__ __forceinline__ const GroupInit& init() { return INIT; }")
     o.append("#else")
     o.append("#define GB_GROUPS_DEVICE")
+    o.append("#define GB_GROUPS_ACCESSORS(OPS, INIT)")
     o.append("#endif")
     o.append("namespace poseidon_gl_groups {")
     o.append("struct Mfma { unsigned char p, k, comp; };   // data plane, operand (matrix plane), complemented bytes")
@@ -393,10 +397,7 @@ def emit():
                 o.append("        {" + ", ".join(ent) + "},")
             o.append("    };")
         o.append("    static constexpr uint32_t TRI[%d] = {%s};   // (M^k)_00" % (g, ", ".join(str(t) + "u" for t in sh.tri)))
-        o.append("#if defined(__HIPCC__)")
-        o.append("    static __device__ __forceinline__ const uint32_t (*ops())[16][4] { return OPS_%d; }" % g)
-        o.append("    static __device__ __forceinline__ const GroupInit& init() { return INIT_%d; }" % g)
-        o.append("#endif")
+        o.append("    GB_GROUPS_ACCESSORS(OPS_%d, INIT_%d)" % (g, g))
         o.append("};")
     o.append("}  // namespace poseidon_gl_groups")
     return "\n".join(o) + "\n"

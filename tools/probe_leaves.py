@@ -2,7 +2,7 @@
 """Where the wave cycles of k_gl_merkle_leaves go: s_memtime segment probes (rocprofv3's PC sampling and thread
 trace are not available on this pool - "configuration is not supported on any of the agents", no trace decoder library).
 
-The attribution build of the library (tools/build_variant.sh probe "-DGB_PROBE" kernels_merkle.hip; never the product) stamps the
+The attribution build of the library (tools/build_variant.sh probe "-DGB_LAB" kernels_merkle.hip; never the product) stamps the
 shader clock (s_memtime) and a site ID at every segment boundary of the permutation in a few hundred waves spread over the grid.
 This script runs the wires commitment (135 x 2^20 Goldilocks, input resident in HBM) on that library, reads the trace back and prints,
 per segment: occurrences per permutation, wave cycles per occurrence, share of the wave's lifetime - next to the segment's STATIC
@@ -10,7 +10,7 @@ instruction mix from the same build's assembly, priced with the issue-cost model
 shares its SIMD with three others, so "wave cycles per model issue cycle" is ~4 / efficiency for a segment that issues as the model
 says and larger where the wave waits for something the other waves do not fill.
 
-  tools/build_variant.sh probe "-DGB_PROBE" kernels_merkle.hip
+  tools/build_variant.sh probe "-DGB_LAB" kernels_merkle.hip
   gpurun -- 'python3 tools/probe_leaves.py > gpurun_out/probe_leaves.txt'
 """
 import collections
@@ -41,7 +41,7 @@ NAMES = {
 }
 
 
-def static_segments(flags=("-DGB_PROBE",)):
+def static_segments(flags=("-DGB_LAB",)):
     """instruction mix between consecutive probe sites of the kernel, in assembly order: {(id_a, id_b): [mix, ...]}"""
     import isa_mix
     with tempfile.TemporaryDirectory() as td:
@@ -93,7 +93,7 @@ def model_cycles(mix):
 
 def main():
     if not os.path.exists(VARIANT):
-        raise SystemExit("build the attribution library first: tools/build_variant.sh probe \"-DGB_PROBE\" kernels_merkle.hip")
+        raise SystemExit("build the attribution library first: tools/build_variant.sh probe \"-DGB_LAB\" kernels_merkle.hip")
     from plonky2_goldibear_amd import build as B
     product = B.LIB
     keep = product + ".product"
@@ -149,7 +149,7 @@ def run():
     nw = len(life)
     total = sum(seg_cyc.values())
     stat = static_segments()
-    print("k_gl_merkle_leaves (attribution build, -DGB_PROBE), wires commitment 135 x 2^20 Goldilocks: 'hash leaves' %.2f ms with probes" % ms)
+    print("k_gl_merkle_leaves (attribution build, -DGB_LAB), wires commitment 135 x 2^20 Goldilocks: 'hash leaves' %.2f ms with probes" % ms)
     print("%d traced waves, %.0f wave cycles (s_memtime) from first to last probe on average, %d permutations per wave" % (nw, np.mean(life), perms))
     # Shader clock under this load.  s_memtime counters of different XCDs are not synchronised, so stamps of different waves are not
     # compared; instead: the grid's n_waves run in 4096 wave slots (256 CUs x 16 waves: 128 VGPRs, 4 waves per SIMD), back to back, so a
@@ -194,7 +194,7 @@ def run():
     if out_json:
         import json
         from csrc_hash import measured_sha16
-        json.dump({"kernel": "gbk::k_gl_merkle_leaves (attribution build, -DGB_PROBE)", "hash_leaves_ms_with_probes": ms, "traced_waves": nw,
+        json.dump({"kernel": "gbk::k_gl_merkle_leaves (attribution build, -DGB_LAB)", "hash_leaves_ms_with_probes": ms, "traced_waves": nw,
                    "wave_cycles_per_permutation": tot_c, "model_issue_cycles_per_permutation": tot_m,
                    "simd_issue_utilisation_vs_model": 4.0 * tot_m / tot_c, "shader_clock_hz_under_load": clock_hz,
                    "classes": {cls: {"share": v[0], "wave_cycles_per_permutation": v[1], "model_cycles_per_permutation": v[2]} for cls, v in agg.items()},
