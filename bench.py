@@ -43,7 +43,7 @@ SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32; a 
 GL_P = 0xFFFFFFFF00000001
 SCOPES = ("IFFT", "FFT + blinding", "build Merkle tree", "hash leaves", "compute wires commitment", "compute partial products",
           "compute quotient polys", "construct the opening set", "compute opening proofs", "find proof-of-work witness",
-          "fri query rounds")
+          "fri query rounds", "quotient IFFT", "FRI LDE")
 
 
 def splitmix64_matrix(seed, rows, cols):
@@ -302,14 +302,26 @@ class ProveLeg:
             self.ctx.set_profiling(True)  # per-scope HIP events; with several proofs in flight scopes overlap, so only wall time
         self.ctx.scope_reset()
         self.barrier()
+        self.trace_marker()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
         self.barrier()
         dt = sharding.max_over_ranks(time.perf_counter() - t0)  # whole job = the slowest rank
+        self.trace_marker()
         scopes = {s: self.ctx.scope_ms(s) for s in SCOPES}
         self.ctx.set_profiling(False)
         return dt, scopes, self.retries
+
+    trace_markers = False
+
+    def trace_marker(self):
+        """--trace-markers (tools/make_profiles.sh, under rocprofv3 --kernel-trace): one dispatch of a kernel that a proof never
+        launches (the raw permutation of ONE state) in front of and behind every timed region, outside the clock - so that
+        tools/roofline_recompute.py can cut exactly the dispatches of the timed steps out of the same process's trace"""
+        if self.trace_markers:
+            self.ctx.permute(np.zeros((1, 12), dtype=np.uint64))
+            self.ctx.synchronize()
 
     def no_retry_rate(self):
         """proofs/s over the timed steps that needed no InvZeroPermArg retry (this rank, one proof in flight); None if none"""
@@ -393,7 +405,10 @@ class ProveLeg:
         leaf_perms += int(redo * redo_leaf_perms)
         perms += int(redo * (redo_leaf_perms + N_ - 16))
         live = inflight == 1
-        ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0]) / steps if live else None
+        # every transform the algorithmic bytes count: the commitments' scopes and the first FRI layer's coset_fft of the final
+        # polynomial's D coordinate columns (the whole "FRI LDE" scope: the three smaller layers are ~2 % of it); the quotient's
+        # per-coset inverse transforms ("quotient IFFT") are neither in the bytes nor in the time
+        ntt_ms = (scopes["IFFT"][0] + scopes["FFT + blinding"][0] + scopes["FRI LDE"][0]) / steps if live else None
         merkle_ms = scopes["build Merkle tree"][0] / steps if live else None
         leaves_ms = scopes["hash leaves"][0] / steps if live else None
         achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None
@@ -410,6 +425,7 @@ class ProveLeg:
                          "frac": _num(achieved / HBM_PEAK_GBS if achieved else None), "traffic": traffic,
                          "traffic_source": tj and {"file": tj["profile_file"], "stale": tj["stale"]},
                          "algorithmic_bytes": alg_bytes, "ms": _num(ntt_ms),
+                         "scopes_ms": live and {k: scopes[k][0] / steps for k in ("IFFT", "FFT + blinding", "FRI LDE", "quotient IFFT")},
                          # `frac` is live (HIP-event scopes of this run); frac_from_profile is the same ratio from the kernel trace
                          # committed under profiles/ (sum of the NTT kernels' durations per proof): rocprofv3's per-kernel times on
                          # another box of the pool, a few per cent apart
@@ -479,7 +495,7 @@ def host_footprint(leg):
     except OSError:
         pass
     wit = leg.nwires * (1 << leg.log_n) * leg.esz * leg.inflight
-    return {"rss_mb": rss, "rss_peak_mb": peak, "pinned_witness_mb": wit / 2.0 ** 20, "library_staging_ring_mb": 256.0,
+    return {"rss_mb": rss, "rss_peak_mb": peak, "pinned_witness_mb": wit / 2.0 ** 20, "library_staging_ring_mb": 4 * max(64.0, (1 << leg.log_n) * leg.esz / 2.0 ** 20),   # four slots of max(64 MiB, one column): include/goldibear_gpu.h
             "circuit_columns_build_s": leg.build_s, "circuit_create_s": leg.circuit_create_s}
 
 
@@ -741,6 +757,8 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident-witness leg (value_hbm_resident)")
     ap.add_argument("--no-inflight2", action="store_true", help="skip the two-proofs-in-flight legs (value_inflight2)")
     ap.add_argument("--no-vecs", action="store_true", help="skip the Vec<Vec<F>> legs (value_vec_of_vecs)")
+    ap.add_argument("--trace-markers", action="store_true",
+                    help="one marker dispatch (gb_permute of one state) around every timed region, for tools/roofline_recompute.py --db")
     ap.add_argument("--no-checks", action="store_true",
                     help="skip the proofs made outside the timed region (every witness verified once, the golden SHA-256): kernel traces")
     ap.add_argument("--lib-option", action="append", default=[], metavar="KEY=VALUE",
@@ -796,6 +814,7 @@ def main():
     for k, v in lib_options:
         ctx.set_option(k, v)
     ProveLeg.lib_options = lib_options
+    ProveLeg.trace_markers = args.trace_markers
     out = None
     if args.workload == "prove":
         inflight = max(1, args.inflight)

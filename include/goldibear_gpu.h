@@ -68,7 +68,9 @@ const char* gb_last_error(const gb_ctx* ctx); /* valid until the next call on ct
 gb_status gb_ctx_synchronize(gb_ctx* ctx);
 /* Freed batches keep their device blocks in a per-context pool for reuse by later commits of the
  * same shape (the reference allocates fresh Vecs per PolynomialBatch); this returns them to HIP - together with what failed
- * attempts keep for gb_prove_retry and the page-locked staging ring of pageable inputs (256 MiB of host memory, its copy threads). */
+ * attempts keep for gb_prove_retry, the work buffers of transforms above 2^22 rows and the page-locked staging ring of pageable
+ * inputs (four slots of max(64 MiB, one column): 256 MiB of host memory up to 2^23 Goldilocks rows, 512 MiB at 2^24; its copy
+ * threads). */
 gb_status gb_ctx_trim(gb_ctx* ctx);
 /* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
 gb_status gb_ctx_stream(gb_ctx* ctx, void** stream_out);
@@ -82,7 +84,8 @@ gb_status gb_ctx_set_option(gb_ctx* ctx, const char* key, int64_t value);
 /* ---- host memory ---------------------------------------------------------------------------
  * The reference's inputs are pageable Vecs (MatrixWitness.wire_values: Vec<Vec<F>>, iop/witness.rs:277-279;
  * Vec<PolynomialValues<F>>, fri/oracle.rs:68-75).  Every host input may be pageable: big batches are staged through a
- * page-locked ring the context owns (256 MiB, allocated at the first such call) by its copy threads, column by column, while
+ * page-locked ring the context owns (four slots of max(64 MiB, one column), allocated at the first such call and grown when a
+ * longer column arrives) by its copy threads, column by column, while
  * the columns before are transformed and hashed.  A host that can place its columns itself skips that copy: memory from
  * gb_host_alloc (hipHostMalloc) or registered with gb_host_register (hipHostRegister; unregister before freeing it) is read by
  * the copy engine directly - e.g. an allocator for the witness columns.  Registration costs about as much as one copy: it pays
@@ -95,8 +98,10 @@ gb_status gb_host_unregister(gb_ctx* ctx, void* p);
 /* ---- timing: the reference's timed!() scopes (util/proving_process_info.rs:196-212) ---------
  * With profiling on, each commit records HIP events on ctx's stream around the scopes
  * "IFFT", "FFT + blinding", "build Merkle tree" (fri/oracle.rs:76-114; "transpose LDEs" does not
- * exist here).  gb_ctx_scope_ms returns the accumulated milliseconds of a scope since the last
- * reset and synchronises the stream. */
+ * exist here); gb_prove adds the scopes of prove() ("compute wires commitment", ..., "fri query rounds") and two of the library's
+ * own for the transforms that belong to no commitment: "quotient IFFT" (the per-coset inverse transforms of compute_quotient_polys'
+ * coset_ifft) and "FRI LDE" (the layers' coset_fft, fri/prover.rs:122-125).  gb_ctx_scope_ms returns the accumulated milliseconds of
+ * a scope since the last reset (*count_out: how many times it was entered) and synchronises the stream. */
 gb_status gb_ctx_set_profiling(gb_ctx* ctx, int32_t on);
 gb_status gb_ctx_scope_ms(gb_ctx* ctx, const char* scope, double* ms_out, uint64_t* count_out);
 gb_status gb_ctx_scope_reset(gb_ctx* ctx);
@@ -161,11 +166,16 @@ gb_status gb_batch_device_ptrs(gb_batch* b, void** coeffs, void** lde, void** di
  * LookupGate / LookupTableGate, which are GB_ERR_UNSUPPORTED - and evaluates it on the GPU as well.
  * Both of the reference's configurations are served (plonk/config.rs:119-150): GB_GOLDILOCKS = D 2, H 4,
  * Poseidon-12, 8-byte elements; GB_BABYBEAR = D 4 (x^4 - 11), H 8, Poseidon2-16, 4-byte elements.
- * Configuration range of the prover: degree_bits 2 .. 22; max_quotient_degree_factor 8 (Goldilocks also 16); rate_bits from
+ * Configuration range of the prover: degree_bits from 2 up to the field's two-adicity less rate_bits (32 / 27: the reference has no
+ * other cap, plonk/prover.rs:228-447; 2^21 and 2^22 rows run the library's own transform passes, larger ones an outer radix step
+ * around them, and what does not fit the device is GB_ERR_OOM - a 2^23-row Goldilocks proof holds ~170 GB of commitments);
+ * max_quotient_degree_factor 8 (Goldilocks also 16); rate_bits from
  * log2 of that factor up to 8 - above it the quotient is computed on every 2^(rate_bits - log2 factor)-th point of the LDE, as
  * plonk/prover.rs:735-749 does (the reference's size-optimised recursion proofs use rate_bits 7 and 8,
  * recursion/recursive_verifier.rs:573-611); num_challenges 1 .. 16 (BabyBear from 4: circuit_builder.rs:1190-1192 demands
- * (31 - degree_bits) * c >= 100, and a count that fails that assert is GB_ERR_INVALID for either field); FRI arity_bits 1 .. 8;
+ * (31 - degree_bits) * c >= 100 - CircuitConfig.security_bits is fixed at the 100 of every configuration the reference defines,
+ * plonk/circuit_data.rs:102-159, and is not a field of gb_circuit_config - and a count that fails that assert is GB_ERR_INVALID for
+ * either field); FRI arity_bits 1 .. 8;
  * num_constants <= 4.  The quotient and gate kernels keep their per-challenge sums in registers and are compiled for 1 .. 4
  * challenges (Goldilocks) and 4 .. 10 (BabyBear) - the stock configurations; other counts run as slices of those widths. */
 typedef struct gb_circuit gb_circuit;
@@ -175,7 +185,11 @@ typedef struct gb_circuit_config {
     uint32_t num_wires, num_routed_wires, num_constants; /* CircuitConfig (plonk/circuit_data.rs:63-93) */
     uint32_t num_challenges, max_quotient_degree_factor;
     uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds; /* FriConfig (fri/mod.rs:25-45) */
-    uint32_t arity_bits, final_poly_bits;  /* FriReductionStrategy::ConstantArityBits */
+    uint32_t arity_bits, final_poly_bits;  /* FriReductionStrategy::ConstantArityBits.  A circuit whose strategy is Fixed(..) or
+                                              MinSize(..) passes arity_bits = 0 (or any pair ConstantArityBits would panic on,
+                                              fri/reduction_strategies.rs:45) and hands its list over after the create call
+                                              (gb_circuit_set_fri_reduction_arity_bits); until then gb_prove* / gb_prove_openings /
+                                              gb_verify* / gb_proof_* on the object answer GB_ERR_INVALID */
     uint32_t num_selectors;         /* 1 */
     uint32_t gate_constant, gate_pi;/* selector values of ConstantGate / PublicInputGate (NoopGate is the third) */
     uint32_t zero_knowledge;        /* CircuitConfig.zero_knowledge (= FriParams.hiding): the wires / Zs / quotient leaves carry

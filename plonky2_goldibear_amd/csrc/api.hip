@@ -887,7 +887,8 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
                 if (!ok) break;
                 const size_t want_mont = !values_dev ? 0 : values_mont_cols ? *values_mont_cols : ncols;
                 bool direct;
-                if (p3) {   // Montgomery words as they are in the host's memory: nothing to convert
+                if (p3) {   // Montgomery words as they are in the host's memory: nothing to convert, but nothing to trust either
+                    gbk::bb_reduce_words(vals + c0 * n, cc * n, st);
                     Scope sc(ctx, "IFFT");
                     gbk::bb_intt_columns(vals + c0 * n, coeffs + c0 * n, ntt_scr, cc, *bt, st);
                     if (values_mont_cols) *values_mont_cols = ncols;
@@ -916,6 +917,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
         } else if ((flags & GB_INPUT_DEVICE_FORM) || p3) {  // already Montgomery words on the device (prover-internal; a host's p3 words)
             if (hipMemcpyAsync(coeffs, in_dev, in_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return cleanup(fail(ctx, GB_ERR_HIP, "copy of input columns failed"));
+            if (p3) gbk::bb_reduce_words(coeffs, ncols * n, st);   // a host's words (the library's own device form is in range)
         } else if (!is_coeffs && log_n >= 16 && log_n <= gbk::NTT_NATIVE_LOG) {
             // canonical values on the device (a resident witness, a small host batch): the inverse transform takes them as they are
             Scope sc(ctx, "IFFT");
@@ -937,7 +939,7 @@ gb_status commit(gb_ctx* ctx, uint32_t field, ColSrc cols, size_t ncols, uint32_
                     if (hipMemcpyAsync(scr, salts, (size_t)nsalt * N * 4, hipMemcpyHostToDevice, st) != hipSuccess)
                         return cleanup(fail(ctx, GB_ERR_HIP, "copy of salts failed"));
                     mark_upload(ctx);
-                    if (p3) gbk::bb_from_mont(scr, scr, (size_t)nsalt * N, st);   // the salt columns are F::rand_vec words too
+                    if (p3) { gbk::bb_reduce_words(scr, (size_t)nsalt * N, st); gbk::bb_from_mont(scr, scr, (size_t)nsalt * N, st); }   // the salt columns are F::rand_vec words too
                     sdev = scr;
                 }
                 gbk::bb_bitrev_copy_to_mont(sdev, lde + ncols * N, log_N, nsalt, st);

@@ -122,6 +122,7 @@ void bb_merkle_leaves_segment(const u32* cols, size_t col_stride, u32 c_begin, u
 void bb_merkle_level(const u32* in, u32* out, u64 num_out, hipStream_t stream);
 void bb_poseidon2_permute(const u32* in, u32* out, u64 count, hipStream_t stream);  // canonical in/out
 void bb_to_mont(const u32* src, u32* dst, size_t n, hipStream_t stream);
+void bb_reduce_words(u32* p, size_t n, hipStream_t stream);   // any u32 -> the residue below p, in place (p3 words from a host)
 void bb_from_mont(const u32* src, u32* dst, size_t n, hipStream_t stream);
 void bb_gather_row(const u32* cols, size_t col_stride, u32 width, u64 index, u32* dst, hipStream_t stream);  // -> canonical
 void bb_bitrev_copy_to_mont(const u32* src, u32* dst, u32 bits, size_t ncols, hipStream_t stream);

@@ -487,6 +487,22 @@ void bb_merkle_level(const u32* in, u32* out, u64 num_out, hipStream_t stream) {
 void bb_poseidon2_permute(const u32* in, u32* out, u64 count, hipStream_t stream) {
     hipLaunchKernelGGL(k_bb_permute, dim3(nblk(count, 256)), dim3(256), 0, stream, in, out, count);
 }
+// any u32 word -> its residue below p, in place, 4 words per thread (GB_INPUT_P3_REPR: p3-monty-31 keeps its Montgomery words below
+// p, but the words are the caller's memory: one out of range would otherwise go into the transforms as it is - ADVICE r5)
+__global__ __launch_bounds__(256) void k_bb_reduce_words(u32* __restrict__ p, size_t count) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    auto red = [](u32 x) { x = x >= 2 * bb::P ? x - 2 * bb::P : x; return x >= bb::P ? x - bb::P : x; };
+    if (i + 3 < count) {
+        uint4 v = *reinterpret_cast<uint4*>(p + i);
+        v.x = red(v.x); v.y = red(v.y); v.z = red(v.z); v.w = red(v.w);
+        *reinterpret_cast<uint4*>(p + i) = v;
+    } else {
+        for (size_t k = i; k < count; k++) p[k] = red(p[k]);
+    }
+}
+void bb_reduce_words(u32* p, size_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_bb_reduce_words, dim3(nblk(n, 1024)), dim3(256), 0, stream, p, n);
+}
 void bb_to_mont(const u32* src, u32* dst, size_t n, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_bb_to_mont, dim3(nblk(n, 256)), dim3(256), 0, stream, src, dst, n);
 }

@@ -109,3 +109,19 @@ def test_public_input_count_is_checked(golden_dir):
     other, _, _ = _fixture_circuit(golden_dir, num_public_inputs=cd["num_public_inputs"] + 1)
     with pytest.raises(N.ShapeError, match="public inputs"):
         other.verify(raw)
+
+
+def test_a_circuit_without_constant_arity_bits_waits_for_its_list(golden_dir):
+    """a circuit whose FriReductionStrategy is Fixed(..) / MinSize(..) has no meaningful (arity_bits, final_poly_bits) -
+    it passes arity_bits = 0 (or a pair ConstantArityBits would panic on, fri/reduction_strategies.rs:45), the create call succeeds,
+    everything that needs the list answers GB_ERR_INVALID until gb_circuit_set_fri_reduction_arity_bits has handed it over, and the
+    reference's own proof - whose CommonCircuitData carries [4, 4, 4] - verifies afterwards."""
+    circ, cd, raw = _fixture_circuit(golden_dir, arity_bits=0, final_poly_bits=0)
+    with pytest.raises(N.ShapeError, match="gb_circuit_set_fri_reduction_arity_bits"):
+        circ.verify(raw)
+    with pytest.raises(N.ShapeError, match="gb_circuit_set_fri_reduction_arity_bits"):
+        circ.compress(raw)
+    assert circ.reduction_arity_bits == []
+    circ.set_reduction_arity_bits([4, 4, 4])
+    assert circ.verify(raw)
+    circ.free()

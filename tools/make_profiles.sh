@@ -11,7 +11,7 @@
 # that quotes them - so that no committed bench line says "stale": true about a sibling of the same run.  Everything that has to
 # come back is also written under gpurun_out/profiles/ (only gpurun_out/ travels back).
 set -e
-R=${GB_PROFILE_ROUND:-r05}
+R=${GB_PROFILE_ROUND:-r06}
 OUT=gpurun_out
 P=$OUT/profiles
 if [ "$1" = "--collect" ]; then
@@ -52,16 +52,21 @@ if [ -f tools/bin/libs/probe.so ]; then
 fi
 # one field per run, host-witness leg only, under the kernel trace: 7 proofs each (5 timed + 2 warm-up), no verification proofs
 for F in goldilocks babybear; do
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$F -o p -- python3 bench.py --field $F --steps 5 --warmup 2 --no-babybear --no-resident --no-inflight2 --no-vecs --no-cpu-baseline --no-checks > $OUT/prof_$F.log 2>&1
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$F -o p -- python3 bench.py --field $F --steps 5 --warmup 2 --no-babybear --no-resident --no-inflight2 --no-vecs --no-cpu-baseline --no-checks --trace-markers > $OUT/prof_$F.log 2>&1
     python3 tools/rocpd_kernel_stats.py $OUT/prof_$F/p_results.db $P/${R}_prove_${F}_2p20_kernel_stats.csv
     grep '"metric"' $OUT/prof_$F.log > $P/${R}_bench_prove_${F}_2p20.json
 done
-python3 tools/roofline_recompute.py $P $R 7 > /dev/null
+GB_PROFILE_DB_GOLDILOCKS=$OUT/prof_goldilocks/p_results.db GB_PROFILE_DB_BABYBEAR=$OUT/prof_babybear/p_results.db GB_PROFILE_STEPS=5 python3 tools/roofline_recompute.py $P $R 7 > /dev/null
 cp $P/${R}_* profiles/          # the box's own tree: what the bench line below quotes
 fi
 [ "$STAGE" = counters ] && { ls -la $P; exit 0; }
-# the driver's own command under the kernel trace, then once more bare (the line the driver will reproduce)
-timeout -k 10 700 rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 > $OUT/prof_bench.log 2>&1
+# the driver's own command under the kernel trace: the line and the trace are ONE process on ONE box (round 6; the program itself
+# after `--`), with a marker dispatch around every timed region (--trace-markers) so that tools/roofline_recompute.py can sum exactly
+# the dispatches the line's scopes cover -> rNN_bench_default.json carries `frac` (HIP events) and `frac_from_profile` (kernel trace)
+# of the same dispatches.  Then once more bare: the line the driver will reproduce (rNN_bench_untraced.json).
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o p -- python3 bench.py --steps 10 --warmup 3 --trace-markers > $OUT/prof_bench.log 2>&1
 python3 tools/rocpd_kernel_stats.py $OUT/prof_bench/p_results.db $P/${R}_bench_default_kernel_stats.csv
-timeout -k 10 700 python3 bench.py --steps 20 --warmup 5 > $P/${R}_bench_default.json 2> $OUT/bench_default.err
+grep '"metric"' $OUT/prof_bench.log > $OUT/prof_bench_line.json
+python3 tools/roofline_recompute.py --db $OUT/prof_bench/p_results.db --line $OUT/prof_bench_line.json --out $P/${R}_bench_default.json > $OUT/prof_bench_recompute.log 2>&1
+timeout -k 10 700 python3 bench.py --steps 20 --warmup 5 > $P/${R}_bench_untraced.json 2> $OUT/bench_default.err
 ls -la $P
