@@ -87,6 +87,11 @@ struct gb_ctx {
     std::vector<gb_circuit*> circuits;                      // live circuits of this context: what they keep for gb_prove_retry is
                                                             // released by gb_ctx_trim and when an allocation would fail
     Stager* stager = nullptr;                               // made on first use by a pageable host input
+    // the prover's small transfers - uniform tables up, caps / openings / query rows down - go through page-locked memory of the
+    // context (stage_up / ReadBack below): from pageable memory every one of them is a blocking, staged copy of 70-90 us
+    char *xfer_up = nullptr, *xfer_down = nullptr;
+    size_t xfer_up_off = 0;
+    bool xfer_failed = false;
     // gb_ctx_set_option
     int copy_threads = 4;                                   // "copy_threads": -1 = no staging ring (hipMemcpyAsync straight from pageable memory)
     bool retry_verify = false;                              // "retry_verify": gb_prove_retry compares the whole matrix with the kept copy
@@ -195,6 +200,71 @@ gb_status finish_host_commit(gb_ctx* ctx, gb_status s, gb_batch** out) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->upload_marked = false;
     return s;
+}
+
+// ---- small transfers through page-locked memory (round 6).  A 2^12-row proof spent 1.1 of its 4.3 ms in 13 host round trips of
+// ~80 us each (profiles/r06_recursion_shape.txt): hipMemcpyAsync from a std::vector is a synchronous, runtime-staged copy.
+static constexpr size_t XFER_UP_BYTES = (size_t)4 << 20, XFER_DOWN_BYTES = (size_t)1 << 20;
+bool xfer_ready(gb_ctx* ctx) {
+    if (ctx->xfer_up) return true;
+    if (ctx->xfer_failed) return false;
+    void *u = nullptr, *d = nullptr;
+    if (hipHostMalloc(&u, XFER_UP_BYTES, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&d, XFER_DOWN_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (u) (void)hipHostFree(u);
+        ctx->xfer_failed = true;   // no page-locked memory to be had: the plain copies still work
+        return false;
+    }
+    ctx->xfer_up = static_cast<char*>(u);
+    ctx->xfer_down = static_cast<char*>(d);
+    return true;
+}
+// `bytes` of page-locked memory to fill and hand to ONE hipMemcpyAsync on ctx->stream; it is not written again before the stream
+// has passed that copy (the arena is a ring; wrapping around waits for the stream).  nullptr: too big or no arena - copy directly.
+void* stage_up(gb_ctx* ctx, size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes > XFER_UP_BYTES / 4 || !xfer_ready(ctx)) return nullptr;
+    if (ctx->xfer_up_off + bytes > XFER_UP_BYTES) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+        ctx->xfer_up_off = 0;
+    }
+    void* p = ctx->xfer_up + ctx->xfer_up_off;
+    ctx->xfer_up_off += bytes;
+    return p;
+}
+// device -> host copies that end in one wait: add() enqueues each into the page-locked buffer (or straight into the destination when
+// it does not fit), finish() waits for the stream and hands the bytes out
+struct ReadBack {
+    gb_ctx* ctx;
+    struct Item { void* dst; const char* src; size_t bytes; };
+    Item items[48];
+    unsigned n = 0;
+    size_t off = 0;
+    explicit ReadBack(gb_ctx* c) : ctx(c) {}
+    gb_status add(void* host_dst, const void* dev, size_t bytes) {
+        if (!bytes) return GB_OK;
+        const size_t padded = (bytes + 63) & ~(size_t)63;
+        if (n < 48 && off + padded <= XFER_DOWN_BYTES && xfer_ready(ctx)) {
+            char* p = ctx->xfer_down + off;
+            HIP_TRY(ctx, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            items[n++] = Item{host_dst, p, bytes};
+            off += padded;
+            return GB_OK;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return GB_OK;
+    }
+    gb_status finish() {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (unsigned i = 0; i < n; i++) std::memcpy(items[i].dst, items[i].src, items[i].bytes);
+        n = 0; off = 0;
+        return GB_OK;
+    }
+};
+gb_status read_back(gb_ctx* ctx, void* host_dst, const void* dev, size_t bytes) {
+    ReadBack rb(ctx);
+    if (gb_status s = rb.add(host_dst, dev, bytes)) return s;
+    return rb.finish();
 }
 
 gb_status ensure(gb_ctx* ctx, DeviceBuf& buf, size_t bytes) {
@@ -1091,6 +1161,8 @@ gb_status gb_ctx_destroy(gb_ctx* ctx) try {
     for (auto& kv : ctx->pool) hipFree(kv.second);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     delete ctx->stager;   // joins the copy threads, frees the page-locked ring
+    if (ctx->xfer_up) (void)hipHostFree(ctx->xfer_up);
+    if (ctx->xfer_down) (void)hipHostFree(ctx->xfer_down);
     hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
@@ -1295,9 +1367,7 @@ gb_status gb_batch_cap(gb_batch* b, void* out) try {
     gb_ctx* ctx = b->ctx;
     const u64 N = (u64)1 << (b->log_n + b->rate_bits);
     const u64* cap = b->levels + 4 * level_offset(N, b->log_n + b->rate_bits - b->cap_height);  // 32 B per digest
-    HIP_TRY(ctx, hipMemcpyAsync(out, cap, ((size_t)1 << b->cap_height) * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return GB_OK;
+    return read_back(ctx, out, cap, ((size_t)1 << b->cap_height) * 32);
 } GB_CATCH(b ? b->ctx : nullptr)
 
 gb_status gb_batch_coeffs(gb_batch* b, size_t col, void* out) try {

@@ -194,10 +194,16 @@ __host__ __device__ __forceinline__ u64 mul_mont(u64 a_canonical, u64 t_mont_can
 __host__ __device__ inline u64 to_mont_slow(u64 x);
 
 // a * b mod p, any u64 in, canonical out.
-__host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+#if defined(__HIPCC__)   // (device overload on limbs; the host's is one 64 x 64 -> 128 multiplication: the transcript hashes with it)
+__device__ __forceinline__ u64 mul(u64 a, u64 b) {
     u32 r0, r1, hl, hh;
     mul_limbs(a, b, r0, r1, hl, hh);
     return canon(fold128(r0, r1, hl, hh));
+}
+#endif
+__host__ inline u64 mul(u64 a, u64 b) {
+    const unsigned __int128 t = (unsigned __int128)a * b;
+    return reduce128((u64)t, (u64)(t >> 64));
 }
 __host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 __host__ __device__ inline u64 to_mont_slow(u64 x) { return mul(x, EPS); }   // R = 2^64 mod p = 2^32 - 1

@@ -208,6 +208,9 @@ void l0_table(u32 log_n, u32 rate_bits, const PowTab<F>& w_N, const typename F::
 template <class F>
 void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typename F::T* a, const typename F::T* mat,
                       const CosetPow<F>& inv_shift, typename F::T* out, hipStream_t st);
+// lo[e] = z^e (e < 1024), hi[h] = z^(1024 h) (h < nhi): the split tables of ExtPowTab, built on the device
+template <class F>
+void ext_powtab(typename F::E z, typename F::E* lo, typename F::E* hi, u32 nhi, hipStream_t st);
 template <class F>
 void ext_pow_table(const ExtPowTab<F>& z, size_t n, typename F::E* table, hipStream_t st);
 template <class F>

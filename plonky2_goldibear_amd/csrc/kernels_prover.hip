@@ -378,6 +378,15 @@ __global__ __launch_bounds__(256) void k_quotient_combine(u32 log_n, u32 rate_bi
 
 // ------------------------------------------------------------------ openings: sum_t c_t z^t
 
+// the split power tables of an extension element on the device (round 6: on the host they were 8 x 1024 extension products and
+// 16 small uploads per proof - a third of a millisecond of a 4 ms recursion-shaped proof): lo[e] = z^e, e < 1024; hi[h] = z^(1024 h)
+template <class F>
+__global__ __launch_bounds__(256) void k_ext_powtab(typename F::E z, typename F::E* __restrict__ lo, typename F::E* __restrict__ hi, u32 nhi) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 1024) lo[t] = epow<F>(z, t);
+    else if (t - 1024 < nhi) hi[t - 1024] = epow<F>(z, (u64)(t - 1024) << 10);
+}
+
 // table[t] = z^t, t < n
 template <class F>
 __global__ __launch_bounds__(256) void k_ext_pow_table(ExtPowTab<F> z, size_t n, typename F::E* __restrict__ table) {
@@ -703,26 +712,23 @@ void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, con
 // A challenge count with no specialisation of its own runs as slices of compiled widths <= WMAX (balanced: every slice
 // floor or ceil of count / slices); the hot counts (Goldilocks 1..4, BabyBear 6..10) are one plain launch, as before.
 #define GB_Q(FF, CC, HH, SL) hipLaunchKernelGGL((k_quotient<FF, CC, HH, SL>), grid, block, 0, st, q, cs, wires, zs, uniforms, qv)
+// Instances: the stock factor 8 with every hot challenge count as one plain launch (Goldilocks 1 .. 4, BabyBear 4 .. 10, slices 5 .. 8
+// wide); the other factors the reference's CircuitConfig allows (2, 4, 16: plonk/circuit_data.rs:86, prover.rs:735-749; round 6) with
+// a reduced set - Goldilocks 1 .. 2, BabyBear 4 .. 8 - every other count as slices of those.
 template <class F, u32 CH>
 static bool quotient_slice(QuotientParams<F> q, u32 width, bool slice, const typename F::T* cs, const typename F::T* wires,
                            const typename F::T* zs, const typename F::T* uniforms, typename F::T* qv, dim3 grid, dim3 block, hipStream_t st) {
     q.num_challenges = width;
+#define GB_QW(W) case W: if (slice) GB_Q(F, W, CH, true); else GB_Q(F, W, CH, false); return true
     if constexpr (F::TAG == 0) {
-        if (slice) switch (width) {
-            case 1: GB_Q(F, 1, CH, true); return true;
-            case 2: GB_Q(F, 2, CH, true); return true;
-            case 3: if constexpr (CH == 8) { GB_Q(F, 3, CH, true); return true; } else return false;
-            case 4: if constexpr (CH == 8) { GB_Q(F, 4, CH, true); return true; } else return false;
-            default: return false;
-        }
         switch (width) {
-            case 1: GB_Q(F, 1, CH, false); return true;
-            case 2: GB_Q(F, 2, CH, false); return true;
-            case 3: if constexpr (CH == 8) { GB_Q(F, 3, CH, false); return true; } else return false;
-            case 4: if constexpr (CH == 8) { GB_Q(F, 4, CH, false); return true; } else return false;
+            GB_QW(1);
+            GB_QW(2);
+            case 3: if constexpr (CH == 8) { if (slice) GB_Q(F, 3, CH, true); else GB_Q(F, 3, CH, false); return true; } else return false;
+            case 4: if constexpr (CH == 8) { if (slice) GB_Q(F, 4, CH, true); else GB_Q(F, 4, CH, false); return true; } else return false;
             default: return false;
         }
-    } else {
+    } else if constexpr (CH == 8) {
         if (slice) switch (width) {
             case 5: GB_Q(F, 5, CH, true); return true;
             case 6: GB_Q(F, 6, CH, true); return true;
@@ -740,39 +746,54 @@ static bool quotient_slice(QuotientParams<F> q, u32 width, bool slice, const typ
             case 10: GB_Q(F, 10, CH, false); return true;
             default: return false;
         }
+    } else {
+        switch (width) {
+            GB_QW(4);
+            GB_QW(5);
+            GB_QW(6);
+            GB_QW(7);
+            GB_QW(8);
+            default: return false;
+        }
     }
+#undef GB_QW
 }
 #undef GB_Q
+static inline u32 quotient_gl_wmax(u32 chunk) { return chunk == 8 ? 4 : 2; }
+static inline u32 quotient_bb_wmax(u32 chunk) { return chunk == 8 ? 10 : 8; }
 template <class F>
 bool quotient_values(const QuotientParams<F>& p, const typename F::T* cs, const typename F::T* wires, const typename F::T* zs,
                      const typename F::T* uniforms, typename F::T* qv, hipStream_t st) {
     const size_t NQ = (size_t)1 << (p.log_n + p.rate_bits);
     const dim3 grid(nblk(NQ, 256)), block(256);
     u32 widths[MAX_CHALLENGES];
-    const u32 ns = challenge_slices(F::TAG, p.chunk == 8 ? 4 : 2, p.num_challenges, widths);
-    if (!ns || (p.chunk != 8 && !(F::TAG == 0 && p.chunk == 16))) return false;
+    const u32 ns = challenge_slices(F::TAG, quotient_gl_wmax(p.chunk), p.num_challenges, widths, quotient_bb_wmax(p.chunk));
+    if (!ns || !quotient_shape_supported(F::TAG, p.chunk, p.num_challenges)) return false;
     QuotientParams<F> q = p;
     q.total_challenges = p.num_challenges;
     q.k0 = 0;
     for (u32 i = 0; i < ns; q.k0 += widths[i], i++) {
         bool ok;
-        if constexpr (F::TAG == 0)
-            ok = p.chunk == 8 ? quotient_slice<F, 8>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st)
-                              : quotient_slice<F, 16>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st);
-        else
-            ok = quotient_slice<F, 8>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st);
+        switch (p.chunk) {
+            case 2: ok = quotient_slice<F, 2>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st); break;
+            case 4: ok = quotient_slice<F, 4>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st); break;
+            case 8: ok = quotient_slice<F, 8>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st); break;
+            case 16: ok = quotient_slice<F, 16>(q, widths[i], ns > 1, cs, wires, zs, uniforms, qv, grid, block, st); break;
+            default: ok = false;
+        }
         if (!ok) return false;
     }
     return true;
 }
 template bool quotient_values<GlF>(const QuotientParams<GlF>&, const u64*, const u64*, const u64*, const u64*, u64*, hipStream_t);
 template bool quotient_values<BbF>(const QuotientParams<BbF>&, const u32*, const u32*, const u32*, const u32*, u32*, hipStream_t);
+// max_quotient_degree_factor 2, 4, 8, 16 (a power of two up to 2^rate_bits, plonk/prover.rs:736-740);
 // BabyBear: (31 - degree_bits) * c >= 100 (circuit_builder.rs:1190-1192) needs c >= 4; Goldilocks c >= 2
 bool quotient_shape_supported(u32 field, u32 chunk, u32 num_challenges) {
     u32 widths[MAX_CHALLENGES];
     if (num_challenges == 0 || num_challenges > MAX_CHALLENGES) return false;
-    if (chunk != 8 && !(field == GlF::TAG && chunk == 16)) return false;
-    return challenge_slices(field, chunk == 8 ? 4 : 2, num_challenges, widths) != 0;
+    if (chunk != 2 && chunk != 4 && chunk != 8 && chunk != 16) return false;
+    return challenge_slices(field, quotient_gl_wmax(chunk), num_challenges, widths, quotient_bb_wmax(chunk)) != 0;
 }
 
 template <class F>
@@ -787,6 +808,11 @@ void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typena
     const size_t n = (size_t)1 << log_n;
     hipLaunchKernelGGL(k_quotient_combine<F>, dim3(nblk(n, 256), num_challenges), dim3(256), 0, st, log_n, rate_bits, a, mat,
                        inv_shift, out);
+}
+
+template <class F>
+void ext_powtab(typename F::E z, typename F::E* lo, typename F::E* hi, u32 nhi, hipStream_t st) {
+    hipLaunchKernelGGL(k_ext_powtab<F>, dim3(nblk((size_t)1024 + nhi, 256)), dim3(256), 0, st, z, lo, hi, nhi);
 }
 
 template <class F>
@@ -868,6 +894,7 @@ void gather_siblings_multi(const typename F::T* levels, u32 log_leaves, u32 cap_
                                          F::T*, F::T*, u32*, F::T*, hipStream_t);                                                   \
     template void quotient_combine<F>(u32, u32, u32, const F::T*, const F::T*, const CosetPow<F>&, F::T*, hipStream_t);             \
     template void l0_table<F>(u32, u32, const PowTab<F>&, const F::T*, F::T*, hipStream_t);                                         \
+    template void ext_powtab<F>(F::E, F::E*, F::E*, u32, hipStream_t);                                                              \
     template void ext_pow_table<F>(const ExtPowTab<F>&, size_t, F::E*, hipStream_t);                                                \
     template void eval_columns<F>(const F::T*, size_t, size_t, const F::E*, F::E*, F::E*, hipStream_t);                             \
     template void reduce_polys<F>(const PolyGroups<F>&, size_t, const F::E*, F::E*, hipStream_t);                                   \

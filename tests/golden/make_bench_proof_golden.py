@@ -63,8 +63,11 @@ def golden(field, log_n, challenges):
 if __name__ == "__main__":
     O.use_host_cpu_share()
     log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    only = sys.argv[2] if len(sys.argv) > 2 else None      # one field only (2^21 rows: the Goldilocks oracle run needs ~56 GB)
     out = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for field, ch in (("goldilocks", max(2, -(-100 // (64 - log_n)))), ("babybear", max(6, -(-100 // (31 - log_n))))):
+        if only and field != only:
+            continue
         out["%s_2p%d" % (field, log_n)] = golden(field, log_n, ch)
         json.dump(out, open(OUT, "w"), indent=1, sort_keys=True)
     print("wrote", OUT)

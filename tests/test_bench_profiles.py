@@ -44,9 +44,11 @@ def test_a_source_change_makes_the_quote_stale(tmp_path, monkeypatch):
 
 
 def test_roofline_is_reproducible_from_the_committed_summaries():
-    """profiles/rNN_roofline_recompute.json holds, per field, exactly what tools/roofline_recompute.py derives from
-    the committed kernel-stats / traffic / counter summaries of the same round - frac_from_profile to the digit - and the newest
-    committed bench line quotes those figures."""
+    """profiles/rNN_roofline_recompute.json holds, per field, exactly what tools/roofline_recompute.py derives from the committed
+    kernel-stats / traffic / counter summaries of the same round, and - round 6, VERDICT r5 item 3 - profiles/rNN_bench_default.json is
+    ONE process on ONE box: the driver's command under `rocprofv3 --kernel-trace` with a marker dispatch around every timed region, its
+    JSON line (`frac`: HIP-event scopes) completed with `frac_from_profile` = the kernel-trace durations of exactly the dispatches those
+    scopes cover.  The two agree within 3 %; what the trace holds beyond them (the quotient's per-coset inverse transforms) is itemised."""
     import csv
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_recompute.json")))
@@ -62,18 +64,31 @@ def test_roofline_is_reproducible_from_the_committed_summaries():
         assert f["algorithmic_bytes_per_proof"] == alg
         ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_prove_%s_2p20_kernel_stats.csv" % (rnd, field))))
                  if "intt" in r["Name"] or "lde_p" in r["Name"]) / 7
-        assert abs(f["ntt_kernel_ms_per_proof"] - ns / 1e6) < 1e-9
-        assert abs(f["frac_from_profile"] - alg / (ns * 1e-9) / 8.0e12) < 1e-12
+        if "all_transform_kernels_ms_per_proof" in f:   # round 6: the dispatch-level sum is the quoted one, the name-level sum beside it
+            assert abs(f["all_transform_kernels_ms_per_proof"] - ns / 1e6) < 1e-9
+            sc = f["scopes_ms_per_proof_from_trace"]
+            assert abs(f["ntt_kernel_ms_per_proof"] - (sc["IFFT"] + sc["FFT + blinding"] + sc["FRI LDE"])) < 1e-9
+            # the timed steps' dispatches, sorted into scopes, add up to the name-level sum over all 7 proofs of the trace within 2 %
+            assert abs(sum(sc.values()) / f["all_transform_kernels_ms_per_proof"] - 1) < 0.02
+            assert 0.0 < sc["quotient IFFT"] < 0.1 * f["ntt_kernel_ms_per_proof"]
+        else:
+            assert abs(f["ntt_kernel_ms_per_proof"] - ns / 1e6) < 1e-9
+        assert abs(f["frac_from_profile"] - alg / (f["ntt_kernel_ms_per_proof"] * 1e-3) / 8.0e12) < 1e-12
         t = json.load(open(os.path.join(ROOT, "profiles", "%s_ntt_traffic_pmc_%s.json" % (rnd, field))))
         phys = t["ifft_bytes_per_column"] * ncv + t["lde_bytes_per_column"] * (ncv + ncc)
         assert abs(f["physical_bytes_per_proof"] - phys) < 1.0
         assert 0.10 < f["frac_from_profile"] < f["valu_ceiling_frac"] < 0.40 and 0.15 < f["pass_structure_ceiling_frac"] < 0.30
     line_path = os.path.join(ROOT, "profiles", "%s_bench_default.json" % rnd)
-    if os.path.exists(line_path):
-        line = json.loads(open(line_path).read().strip().splitlines()[-1])
-        for field, obj in (("goldilocks", line["roofline"]), ("babybear", line["babybear"]["roofline"])):
-            assert obj["frac_from_profile"] == j[field]["frac_from_profile"] and obj["valu_ceiling_frac"] == j[field]["valu_ceiling_frac"]
-            assert obj["profile_source"]["stale"] is False
-        assert line["proof_sha256_matches_golden"] is True and line["babybear"]["proof_sha256_matches_golden"] is True
-        assert line["verified_witnesses"] == "16 of 16" and "value_vec_of_vecs" in line and "value_vec_of_vecs" in line["babybear"]
-        assert line["cpu_baseline"]["scaled"] is False and line["cpu_baseline"]["sample_log_n"] == 20
+    assert os.path.exists(line_path)
+    line = json.loads(open(line_path).read().strip().splitlines()[-1])
+    for field, obj in (("goldilocks", line["roofline"]), ("babybear", line["babybear"]["roofline"])):
+        assert obj["profile_source"]["same_process"] is True
+        assert abs(obj["frac"] / obj["frac_from_profile"] - 1) <= 0.03, (field, obj["frac"], obj["frac_from_profile"])
+        assert set(obj["trace_ms"]) == {"IFFT", "FFT + blinding", "FRI LDE", "quotient IFFT"} == set(obj["scopes_ms"])
+        assert abs(obj["ms"] - (obj["scopes_ms"]["IFFT"] + obj["scopes_ms"]["FFT + blinding"] + obj["scopes_ms"]["FRI LDE"])) < 1e-9
+        assert obj["valu_ceiling_frac"] == j[field]["valu_ceiling_frac"]
+    bare = os.path.join(ROOT, "profiles", "%s_bench_untraced.json" % rnd)     # the same command without the profiler: what the driver reproduces
+    line = json.loads(open(bare).read().strip().splitlines()[-1])
+    assert line["proof_sha256_matches_golden"] is True and line["babybear"]["proof_sha256_matches_golden"] is True
+    assert line["verified_witnesses"] == "16 of 16" and "value_vec_of_vecs" in line and "value_vec_of_vecs" in line["babybear"]
+    assert line["cpu_baseline"]["scaled"] is False and line["cpu_baseline"]["sample_log_n"] == 20

@@ -68,7 +68,7 @@ def draw(seed):
     return F, tag, lg, cfg, bits, zk
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(36))   # (48 until round 6; tools/fuzz_configs.py walks hundreds more offline: profiles/r05_config_fuzz.txt)
 def test_random_configuration(ctx, seed):
     F, tag, lg, cfg, bits, zk = draw(seed)
     circ = D.DummyCircuit(lg, cfg, F=F)

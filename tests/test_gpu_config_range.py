@@ -142,6 +142,22 @@ def test_proof_bytes_with_other_challenge_counts(ctx, field_name, degree_bits, n
     _prove_and_compare(ctx, circ, tag, seed=degree_bits + num_challenges)
 
 
+@pytest.mark.parametrize("field_name,degree_bits,rate_bits,qdf,nch,kw", [
+    ("goldilocks", 7, 3, 4, 2, {}), ("goldilocks", 6, 2, 4, 3, {}), ("goldilocks", 8, 3, 2, 2, dict(num_routed_wires=40)),
+    ("goldilocks", 9, 1, 2, 5, dict(num_routed_wires=33, num_wires=70)), ("goldilocks", 5, 4, 16, 2, {}),
+    ("babybear", 7, 3, 4, 6, {}), ("babybear", 6, 4, 16, 6, {}), ("babybear", 8, 3, 2, 9, {}), ("babybear", 9, 5, 16, 11, {}),
+    ("babybear", 5, 2, 4, 4, {}),
+])
+def test_proof_bytes_with_other_quotient_degree_factors(ctx, field_name, degree_bits, rate_bits, qdf, nch, kw):
+    """max_quotient_degree_factor is a free CircuitConfig field (plonk/circuit_data.rs:86; a power of two up to 2^rate_bits,
+    prover.rs:735-749): 2, 4 and 16 for both fields (round 6; every stock configuration uses 8) - chunk products of 2 / 4 / 16
+    wires, num_partial_products = ceil(routed / factor) - 1, a quotient of factor x n coefficients per challenge; reduced kernel
+    widths, so 5, 9 and 11 challenges run as slices."""
+    F, tag, mk = _field(field_name)
+    circ = D.DummyCircuit(degree_bits, mk(num_challenges=nch, rate_bits=rate_bits, max_quotient_degree_factor=qdf, **kw), F=F)
+    _prove_and_compare(ctx, circ, tag, seed=degree_bits + qdf)
+
+
 def test_goldilocks_degree_factor_16_with_sliced_challenges(ctx):
     circ = D.DummyCircuit(8, D.CircuitConfig(num_challenges=5, rate_bits=4, max_quotient_degree_factor=16), F=GL)
     _prove_and_compare(ctx, circ, N.GB_GOLDILOCKS, seed=3)

@@ -61,16 +61,15 @@ def test_from_values_above_2pow20_rows(ctx, field_name, log_n, ncols):
     ctx.trim()
 
 
-@pytest.mark.parametrize("field_name,ch", [("goldilocks", 3), ("babybear", 10)])
-def test_prove_2pow21_rows_bytes_equal_oracle(ctx, field_name, ch):
-    """prove() of the 2^21-row dummy circuit: the proof BYTES equal the CPU oracle prover's (round 5 only verified proofs of this
-    size: 28 queried leaves per tree say nothing about the other 2^24), and - through the stage entry points, driven like the
-    reference's prover loop (tests/test_gpu_stage_abi.py) - the oracle prover's own intermediates equal the GPU's element for
-    element: the Z / partial-product values (a running product over 2048 blocks) and the quotient chunk coefficients."""
-    from oracle.fields import BB
+def test_prove_2pow21_rows_bytes_equal_oracle(ctx):
+    """prove() of the 2^21-row Goldilocks dummy circuit: the proof BYTES equal the CPU oracle prover's (round 5 only verified
+    proofs of this size: 28 queried leaves per tree say nothing about the other 2^24), and - through the stage entry points, driven
+    like the reference's prover loop (tests/test_gpu_stage_abi.py) - the oracle prover's own intermediates equal the GPU's element for
+    element: the Z / partial-product values (a running product over 2048 blocks) and the quotient chunk coefficients.  (This
+    comparison found the overflow of the suffix-total buffer of divide_by_linear - 1024 entries, 2048 blocks at this size.)"""
     from test_gpu_stage_abi import _gpu_circuit, prove_by_stages
-    lg = 21
-    F, tag, cfg = (GL, N.GB_GOLDILOCKS, D.CircuitConfig(num_challenges=ch)) if field_name == "goldilocks" else (BB, GB_BABYBEAR, D.CircuitConfig.babybear(ch))
+    lg, ch = 21, 3
+    F, tag, cfg = GL, N.GB_GOLDILOCKS, D.CircuitConfig(num_challenges=ch)
     circ = D.DummyCircuit(lg, cfg, F=F)
     gpu = _gpu_circuit(ctx, circ, tag)
     circ.set_cap(gpu.constants_sigmas_cap)     # prove_cpu() asserts that it IS the cap of the oracle's own commitment
@@ -86,6 +85,33 @@ def test_prove_2pow21_rows_bytes_equal_oracle(ctx, field_name, ch):
     assert prove_by_stages(gpu, circ, w, [], tag, mid) == want
     assert (mid["zs_partial_products"] == dump["zs_partial_products"]).all()
     assert (mid["quotient_chunks"] == dump["quotient_chunks"]).all()
+    gpu.free()
+    ctx.trim()
+
+
+def test_babybear_prove_2pow21_rows_bytes_equal_golden(ctx):
+    """The same for BabyBear (num_challenges 10) against the oracle prover's proof as a committed golden vector
+    (tests/golden/bench_proof_sha256.json "babybear_2p21": tests/golden/make_bench_proof_golden.py 21 babybear - the oracle prover,
+    2.3 minutes of the GPU box's host cores that the test step does not have twice), plus the stage entry points assembling the same
+    bytes."""
+    import hashlib
+    import json
+    import os
+    from oracle.fields import BB
+    from test_gpu_stage_abi import prove_by_stages
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bench_proof_sha256.json")))["babybear_2p21"]
+    lg, ch = g["log_n"], g["num_challenges"]
+    cs, k_is, pi_row, _ = DC.build_dummy_circuit_bb(lg)
+    gpu = CircuitData(ctx, lg, cs, k_is, num_wires=167, num_routed_wires=41, num_challenges=ch, arity_bits=3, field=GB_BABYBEAR)
+    assert [int(x) for x in gpu.circuit_digest] == g["circuit_digest"]
+    assert hashlib.sha256(np.ascontiguousarray(gpu.constants_sigmas_cap).tobytes()).hexdigest() == g["constants_sigmas_cap_sha256"]
+    w = DC.dummy_witness_bb(lg, pi_row, seed=g["witness_seed"])
+    proof = gpu.prove_once(w)
+    assert len(proof) == g["proof_len"] and hashlib.sha256(proof).hexdigest() == g["sha256"]
+    assert gpu.verify(proof)
+    view = D.DummyCircuit.verifier_view(lg, D.CircuitConfig.babybear(ch), BB, k_is)   # (what prove_by_stages reads of a circuit)
+    view.set_cap(gpu.constants_sigmas_cap)
+    assert prove_by_stages(gpu, view, w, [], GB_BABYBEAR) == proof
     gpu.free()
     ctx.trim()
 
