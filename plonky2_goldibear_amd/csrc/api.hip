@@ -254,7 +254,7 @@ struct ReadBack {
         HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         return GB_OK;
     }
-    gb_status finish() {
+    gb_status finish() {   // (polling an event before blocking was tried: no gain - the wake-up is not what these waits cost)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (unsigned i = 0; i < n; i++) std::memcpy(items[i].dst, items[i].src, items[i].bytes);
         n = 0; off = 0;

@@ -93,15 +93,20 @@ def test_oracle_prover_with_a_fixed_list(F, bits):
 def test_library_mirrors_the_assert_of_constant_arity_bits(golden_dir):
     """fri/reduction_strategies.rs:45 `assert!(degree_bits >= arity_bits)`: the fixture's circuit has cap_height 4; with
     ConstantArityBits(5, 0) at rate_bits 8 a reduction comes up that needs 5 bits where fewer are left while the tree would still
-    be high enough - the reference panics in build(), gb_verifier_create (no device) returns GB_ERR_INVALID instead of deriving a
-    list that wraps around."""
+    be high enough - the reference panics in build().  The library never derives a list that wraps around: since round 6
+    gb_verifier_create (no device) leaves the list OPEN for such a pair - a circuit with a Fixed / MinSize strategy has no meaningful
+    ConstantArityBits parameters and hands its list over after the create call - and everything that needs the list answers
+    GB_ERR_INVALID, naming the reference's assert, until gb_circuit_set_fri_reduction_arity_bits has been called."""
     _, cd, _ = _fixture_circuit(golden_dir)
     lg = cd["fri_params"]["degree_bits"]
     with pytest.raises(AssertionError):
         FP.constant_arity_bits(5, 0, lg, 8, 4)
+    circ, _, raw = _fixture_circuit(golden_dir, arity_bits=5, final_poly_bits=0, rate_bits=8)
+    assert circ.reduction_arity_bits == []
     with pytest.raises(N.GoldibearError) as e:
-        _fixture_circuit(golden_dir, arity_bits=5, final_poly_bits=0, rate_bits=8)
-    assert e.value.status == N.GB_ERR_INVALID and "degree_bits >= arity_bits" in str(e.value)
+        circ.verify(raw)
+    assert e.value.status == N.GB_ERR_INVALID and "fri/reduction_strategies.rs:45" in str(e.value) and "ConstantArityBits" in str(e.value)
+    circ.free()
     for ab, fpb in ((4, 0), (3, 1), (7, 2), (8, 5)):    # pairs the reference accepts: the library derives the same list
         want = FP.constant_arity_bits(ab, fpb, lg, 3, 4)
         circ, _, _ = _fixture_circuit(golden_dir, arity_bits=ab, final_poly_bits=fpb)

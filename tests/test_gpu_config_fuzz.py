@@ -108,14 +108,22 @@ def test_random_configuration(ctx, seed):
 def test_constant_arity_that_does_not_fit_the_degree_is_rejected(ctx):
     """`assert!(degree_bits >= arity_bits)` inside ConstantArityBits' loop (fri/reduction_strategies.rs:45): 2^6 rows, arity 2^4,
     cap_height 0 - the second reduction would need 4 of the 2 bits that are left.  The reference panics in build(); the library
-    says GB_ERR_INVALID (and used to derive a list that wrapped around)."""
+    (which used to derive a list that wrapped around) leaves the list open - such a pair is what a circuit with a Fixed / MinSize
+    strategy passes - and prove() answers GB_ERR_INVALID with the reference's assert until a list has been handed over; with the list
+    the valid circuit's strategy would have derived, the proof equals the oracle's."""
     cfg = D.CircuitConfig(num_challenges=2, cap_height=0, arity_bits=4, final_poly_bits=0)
     with pytest.raises(AssertionError):
         D.DummyCircuit(6, cfg, F=GL)
     with pytest.raises(AssertionError):
         FP.constant_arity_bits(4, 0, 6, 3, 0)
     ok = D.DummyCircuit(6, D.CircuitConfig(num_challenges=2, cap_height=0), F=GL)    # the columns of a valid circuit of that size
+    gpu = CircuitData(ctx, 6, ok.constants_sigmas, ok.k_is, num_challenges=2, cap_height=0, arity_bits=4, final_poly_bits=0,
+                      gate_constant=ok.GATE_CONSTANT, gate_pi=ok.GATE_PI)
+    assert gpu.reduction_arity_bits == []
+    w = ok.witness(seed=2)
     with pytest.raises(N.GoldibearError) as e:
-        CircuitData(ctx, 6, ok.constants_sigmas, ok.k_is, num_challenges=2, cap_height=0, arity_bits=4, final_poly_bits=0,
-                    gate_constant=ok.GATE_CONSTANT, gate_pi=ok.GATE_PI)
-    assert e.value.status == N.GB_ERR_INVALID and "degree_bits >= arity_bits" in str(e.value)
+        gpu.prove(w)
+    assert e.value.status == N.GB_ERR_INVALID and "fri/reduction_strategies.rs:45" in str(e.value)
+    gpu.set_reduction_arity_bits(ok.reduction_arity_bits)
+    assert gpu.prove(w) == D.prove_cpu(ok, w)[0]
+    gpu.free()
