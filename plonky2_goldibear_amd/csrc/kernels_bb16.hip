@@ -366,24 +366,35 @@ __global__ __launch_bounds__(256 << K, 4) void k_bb_lde_pa32(const u32* __restri
     constexpr u32 L = 20 + K, A0 = 8u << K, NT = 256u << K, SLOT = NT, ROWS = 256u << K, JW = 32;
     __shared__ u32 sh[32 * SLOT];      // [k_a1 slot][a0][j]
     __shared__ u32 twl[ROWS];          // w_ROWS^m: the inter-stage twiddles
+    __shared__ u32 phs[2][ROWS];       // s_c^(4096 a') of this coset and of the next (see k_gl_lde_pa32)
     const size_t col = blockIdx.x >> 7;
     const u32 tg = blockIdx.x & 127;
     const u32 tid = threadIdx.x, hi = tid >> 5, j = tid & 31;
     const u32 l = tg * JW + j;
     const size_t n = (size_t)1 << L;
     const u32* cin = coeffs + col * n + l;
-    for (u32 i = tid; i < ROWS; i += NT) twl[i] = tw4096[i << (4 - K)];
+    for (u32 i = tid; i < ROWS; i += NT) {
+        twl[i] = tw4096[i << (4 - K)];
+        phs[0][i] = pow_hi[i];
+    }
     u32 orig[32];
 #pragma unroll
     for (u32 a1 = 0; a1 < 32; a1++) orig[a1] = cin[(size_t)(a1 * A0 + hi) << 12];
     __syncthreads();
     const u32 ratio = bb_tw_split16(tw_hi, tw_lo, 32 * l);   // w_n^(32 l)
-    for (u32 c = 0; c < (1u << rate_bits); c++) {
-        const u32* ph = pow_hi + (size_t)c * ROWS + hi;
+    const u32 ncosets = 1u << rate_bits;
+    u32 sl_next = pow_lo[l];
+    for (u32 c = 0; c < ncosets; c++) {
+        const u32 sl = sl_next;
+        u32 nph = 0;                                             // ROWS == NT: one factor of the next coset per thread, in flight
+        if (c + 1 < ncosets) {
+            nph = pow_hi[(size_t)(c + 1) * ROWS + tid];
+            sl_next = pow_lo[(size_t)(c + 1) * 4096 + l];
+        }
+        const u32* ph = phs[c & 1] + hi;
         u32 x[32];
 #pragma unroll
         for (u32 a1 = 0; a1 < 32; a1++) x[a1] = bb::mul(orig[a1], ph[a1 * A0]);  // s_c^(4096 a'), a' = a1 A0 + a0
-        const u32 sl = pow_lo[(size_t)c * 4096 + l];
         dft32<false>(x);
 #pragma unroll
         for (u32 s = 0; s < 32; s++) sh[s * SLOT + tid] = s ? bb::mul(x[s], twl[(brevk(s, 5) * hi) & (ROWS - 1)]) : x[s];
@@ -415,6 +426,7 @@ __global__ __launch_bounds__(256 << K, 4) void k_bb_lde_pa32(const u32* __restri
                 }
             }
         }
+        if (c + 1 < ncosets) phs[(c + 1) & 1][tid] = nph;
         __syncthreads();
     }
 }

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(THREADS, 3) void k_gl_lde_pa16x2(const u64* __restr
 // then two radix-16 DFTs over a0 per thread), 32 x 32 at 2^22 rows (512 threads).  Every root of unity of order <= 64 is a shift, so
 // the radix-32 DFT costs one butterfly layer more and NO general multiplication more: the multiplications per output are those of
 // the 2^20-row pass (scale, inter-stage twiddle, output twiddle and its chain).  The price is registers - 32 coefficients + 32
-// working values per thread = two waves per SIMD - and a tile of 64 / 128 KB of LDS: 1.24x / 1.47x the 2^20-row pass per element.
+// working values per thread = two waves per SIMD - and a tile of 64 / 128 KB of LDS: 1.20x / 1.39x the 2^20-row pass per element
+// (1.24x / 1.47x before the coset factors s_c^(4096 a') went through LDS one coset ahead: the sixteen threads of a row share them).
 // (The alternative measured on the same box, profiles/r06_large_sizes.txt: 16 points per thread, four waves per SIMD, a radix-R stage
 // over the top digit as a butterfly ACROSS LANES - v_permlane16/32_swap - and one general twiddle more per output: 1.27x / 1.58x,
 // its instruction count.  BabyBear's 2^22-row pass is that form, kernels_bb16.hip: its words are half as wide.)
@@ -283,24 +284,37 @@ __global__ __launch_bounds__(128 << K, 2) void k_gl_lde_pa32(const u64* __restri
     constexpr u32 L = 20 + K, A0 = 8u << K /* values of a0: 16 / 32 */, LA0 = 3 + K, NT = 128u << K, SLOT = NT + 16, ROWS = 256u << K;
     __shared__ u64 sh[32 * SLOT];      // [k_a1 slot][a0][j], slots padded by 16 words
     __shared__ u64 twl[ROWS];          // w_ROWS^m: the inter-stage twiddles
+    __shared__ u64 phs[2][ROWS];       // s_c^(4096 a') of this coset and of the next: the 16 threads of a row share them, so the
+                                       // workgroup loads each once (two per thread, one coset ahead) instead of 32 per thread
     const size_t col = blockIdx.x >> 8;
     const u32 tg = blockIdx.x & 255;
     const u32 tid = threadIdx.x, hi = tid >> 4, j = tid & 15;   // stage 1: a0 = hi; stage 2: slot(s) from hi
     const u32 l = (tg << 4) + j;
     const size_t n = (size_t)1 << L;
     const u64* cin = coeffs + col * n + l;
-    for (u32 i = tid; i < ROWS; i += NT) twl[i] = tw4096[i << (4 - K)];
+    for (u32 i = tid; i < ROWS; i += NT) {
+        twl[i] = tw4096[i << (4 - K)];
+        phs[0][i] = pow_hi[i];
+    }
     u64 orig[32];
 #pragma unroll
     for (u32 a1 = 0; a1 < 32; a1++) orig[a1] = cin[(size_t)(a1 * A0 + hi) << 12];
-    __syncthreads();  // twl visible
+    __syncthreads();  // twl, phs[0] visible
     const u64 ratio = tw_split16(tw_hi, tw_lo, 32 * l);   // w_n^(32 l)
-    for (u32 c = 0; c < (1u << rate_bits); c++) {
-        const u64* ph = pow_hi + (size_t)c * ROWS + hi;
+    const u32 ncosets = 1u << rate_bits;
+    u64 sl_next = pow_lo[l];
+    for (u32 c = 0; c < ncosets; c++) {
+        const u64 sl = sl_next;
+        u64 nph[ROWS / NT];                                  // the next coset's factors, in flight across this coset's work
+        if (c + 1 < ncosets) {
+#pragma unroll
+            for (u32 k = 0; k < ROWS / NT; k++) nph[k] = pow_hi[(size_t)(c + 1) * ROWS + tid + k * NT];
+            sl_next = pow_lo[(size_t)(c + 1) * 4096 + l];
+        }
+        const u64* ph = phs[c & 1] + hi;
         u64 x[32];
 #pragma unroll
         for (u32 a1 = 0; a1 < 32; a1++) x[a1] = ph[a1 * A0];  // s_c^(4096 a'), a' = a1 A0 + a0
-        const u64 sl = pow_lo[(size_t)c * 4096 + l];
 #pragma unroll
         for (u32 a1 = 0; a1 < 32; a1++) x[a1] = gl::mul_mont<true>(orig[a1], x[a1]);
         dft32<false>(x);
@@ -333,6 +347,10 @@ __global__ __launch_bounds__(128 << K, 2) void k_gl_lde_pa32(const u64* __restri
                     if (k < 15) f = gl::mul_mont_lazy<true>(f, ratio);
                 }
             }
+        }
+        if (c + 1 < ncosets) {
+#pragma unroll
+            for (u32 k = 0; k < ROWS / NT; k++) phs[(c + 1) & 1][tid + k * NT] = nph[k];
         }
         __syncthreads();
     }
