@@ -144,6 +144,10 @@ def main():
                 f["frac_from_profile"] = alg / (counted * 1e-9) / HBM
                 f["scopes_ms_per_proof_from_trace"] = {k: v / steps / 1e6 for k, v in tot.items()}
                 f["dispatch_selection"] = "timed steps only (markers), scopes by dispatch order; the quotient's inverse transforms are not in the sum"
+                # what the name-level sum holds beyond the timed steps: the circuit's own constants/sigmas commitment and the warm-up proofs
+                outside = sum(r[2] - r[1] for r in rows[:marks[0]] + rows[marks[1]:] if "intt" in r[0] or "lde_p" in r[0])
+                f["transform_ms_outside_timed_steps"] = outside / 1e6
+                f["timed_steps"], f["proofs_in_trace"] = steps, proofs
                 ntt_ns = counted
         tj = os.path.join(pdir, "%s_ntt_traffic_pmc_%s.json" % (rnd, field))
         if os.path.exists(tj):
