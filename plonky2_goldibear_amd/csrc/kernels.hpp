@@ -155,6 +155,7 @@ template <class F>
 struct ZsParams {
     u32 log_n, num_routed, num_challenges, chunk /* quotient_degree_factor */, nchunks;
     PowTab<F> w_n;   // subgroup generator powers
+    typename F::T betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];   // device form; by value: no upload between the transcript and the launch
 };
 template <class F>
 struct QuotientParams {
@@ -190,8 +191,7 @@ struct PowState {    // canonical sponge state before the candidate is written a
 
 template <class F>
 void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, const typename F::T* sigma, const typename F::T* k_is,
-                         const typename F::T* betas, const typename F::T* gammas, typename F::T* q_tmp, typename F::T* zloc_tmp,
-                         typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st);
+                         typename F::T* q_tmp, typename F::T* zloc_tmp, typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st);
 // false if (chunk, num_challenges) cannot be run (see quotient_shape_supported); challenge counts without a specialisation of
 // their own run as slices of compiled widths (the uniforms are laid out for the total either way)
 template <class F>
@@ -208,9 +208,21 @@ void l0_table(u32 log_n, u32 rate_bits, const PowTab<F>& w_N, const typename F::
 template <class F>
 void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typename F::T* a, const typename F::T* mat,
                       const CosetPow<F>& inv_shift, typename F::T* out, hipStream_t st);
-// lo[e] = z^e (e < 1024), hi[h] = z^(1024 h) (h < nhi): the split tables of ExtPowTab, built on the device
+// lo[e] = z^e (e < nlo), hi[h] = z^(1024 h) (h < nhi): the split tables of ExtPowTab (nlo = 1024) - or a plain list of powers
+// (nhi = 0) - built on the device, up to six tables per launch (a proof needs zeta, zeta_next, their inverses and FRI's alpha at once)
 template <class F>
-void ext_powtab(typename F::E z, typename F::E* lo, typename F::E* hi, u32 nhi, hipStream_t st);
+struct ExtPowJob {
+    typename F::E z;
+    typename F::E *lo, *hi;
+    u32 nlo, nhi;
+};
+static constexpr u32 EXT_POW_JOBS = 6;
+template <class F>
+struct ExtPowJobs {
+    ExtPowJob<F> j[EXT_POW_JOBS];
+};
+template <class F>
+void ext_powtabs(const ExtPowJobs<F>& jobs, u32 njobs, hipStream_t st);
 template <class F>
 void ext_pow_table(const ExtPowTab<F>& z, size_t n, typename F::E* table, hipStream_t st);
 template <class F>
@@ -231,15 +243,30 @@ template <class F>
 void fri_fold(const typename F::T* in, size_t in_len, u32 arity_bits, typename F::E beta, typename F::T* out, hipStream_t st);
 template <class F>
 void pow_grind(const PowState<F>& s, u64 start, u64 count, u32 min_lz, u64* result, hipStream_t st);
-// gathers write CANONICAL values
+// Query rounds (fri/prover.rs:190-255): every opened row and Merkle path of the proof in ONE launch per twelve trees and one
+// device buffer (one read-back) - four oracle batches, then the FRI layers.  Job j writes its nidx rows at out + j.out (CANONICAL
+// values) and the nidx paths (layers x H words each, level i = sibling of leaf >> i) behind them.
 template <class F>
-void gather_rows_multi(const typename F::T* cols, size_t stride, u32 width, const u64* idx, u32 nidx, typename F::T* rows,
-                       hipStream_t st);
+struct QueryJob {
+    const typename F::T* vals;    // the oracle's LDE batch, column-major with `stride`; a FRI layer: [D][stride] coordinate columns, leaf order
+    const typename F::T* levels;  // the tree's digest levels
+    u64 stride;
+    u64 out;
+    u32 width;                    // base elements per opened row (FRI layer: D << arity_bits)
+    u32 log_leaves, layers;       // layers = log_leaves - cap_height
+    u32 shift;                    // leaf = query index >> shift
+    u32 arity_bits, fri;
+};
+static constexpr u32 QUERY_JOBS = 12;
 template <class F>
-void gather_fri_leaves(const typename F::T* vals, size_t len, u32 arity_bits, const u64* idx, u32 nidx, typename F::T* out,
-                       hipStream_t st);
+struct QueryJobs {
+    QueryJob<F> j[QUERY_JOBS];
+};
+static constexpr u32 QUERY_IDX_INLINE = 64;   // up to this many query indices travel as a launch argument (idx_dev may be null then)
+struct QueryIdx {
+    u64 v[QUERY_IDX_INLINE];
+};
 template <class F>
-void gather_siblings_multi(const typename F::T* levels, u32 log_leaves, u32 cap_height, const u64* idx, u32 nidx, typename F::T* out,
-                           hipStream_t st);
+void query_gather(const QueryJobs<F>& jobs, u32 njobs, const u64* idx_host, const u64* idx_dev, u32 nidx, typename F::T* out, hipStream_t st);
 
 }  // namespace gbk

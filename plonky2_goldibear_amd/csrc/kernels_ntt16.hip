@@ -281,7 +281,7 @@ __global__ __launch_bounds__(128 << K, 2) void k_gl_lde_pa32(const u64* __restri
                                                              const u64* __restrict__ tw4096, const u64* __restrict__ tw_hi,
                                                              const u64* __restrict__ tw_lo, const u64* __restrict__ pow_lo,
                                                              const u64* __restrict__ pow_hi) {
-    constexpr u32 L = 20 + K, A0 = 8u << K /* values of a0: 16 / 32 */, LA0 = 3 + K, NT = 128u << K, SLOT = NT + 16, ROWS = 256u << K;
+    constexpr u32 L = 20 + K, A0 = 8u << K /* values of a0: 16 / 32 */, NT = 128u << K, SLOT = NT + 16, ROWS = 256u << K;
     __shared__ u64 sh[32 * SLOT];      // [k_a1 slot][a0][j], slots padded by 16 words
     __shared__ u64 twl[ROWS];          // w_ROWS^m: the inter-stage twiddles
     __shared__ u64 phs[2][ROWS];       // s_c^(4096 a') of this coset and of the next: the 16 threads of a row share them, so the

@@ -40,7 +40,6 @@ __device__ __forceinline__ typename F::E pow_split(const ExtPowTab<F>& t, u64 e)
 template <class F>
 __global__ __launch_bounds__(256) void k_zs_quotients(ZsParams<F> p, const typename F::T* __restrict__ witness,
                                                       const typename F::T* __restrict__ sigma, const typename F::T* __restrict__ k_is,
-                                                      const typename F::T* __restrict__ betas, const typename F::T* __restrict__ gammas,
                                                       typename F::T* __restrict__ q, u32* __restrict__ err) {
     typedef typename F::T T;
     // 1-D grid of nblk * num_challenges workgroups.  The challenges of one block of 256 rows read the same witness and sigma
@@ -59,7 +58,7 @@ __global__ __launch_bounds__(256) void k_zs_quotients(ZsParams<F> p, const typen
     const u32 row = rb * 256 + threadIdx.x;
     const size_t n = (size_t)1 << p.log_n;
     if (row >= n) return;
-    const T beta = betas[ch], gamma = gammas[ch];
+    const T beta = p.betas[ch], gamma = p.gammas[ch];
     const T bx = F::mul(beta, pow_split(p.w_n, row));
     T N[MAX_CHUNKS], Dn[MAX_CHUNKS];
     for (u32 m = 0; m < p.nchunks; m++) {
@@ -381,10 +380,11 @@ __global__ __launch_bounds__(256) void k_quotient_combine(u32 log_n, u32 rate_bi
 // the split power tables of an extension element on the device (round 6: on the host they were 8 x 1024 extension products and
 // 16 small uploads per proof - a third of a millisecond of a 4 ms recursion-shaped proof): lo[e] = z^e, e < 1024; hi[h] = z^(1024 h)
 template <class F>
-__global__ __launch_bounds__(256) void k_ext_powtab(typename F::E z, typename F::E* __restrict__ lo, typename F::E* __restrict__ hi, u32 nhi) {
+__global__ __launch_bounds__(256) void k_ext_powtabs(ExtPowJobs<F> jobs) {   // blockIdx.y = table
+    const ExtPowJob<F>& J = jobs.j[blockIdx.y];
     const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t < 1024) lo[t] = epow<F>(z, t);
-    else if (t - 1024 < nhi) hi[t - 1024] = epow<F>(z, (u64)(t - 1024) << 10);
+    if (t < J.nlo) J.lo[t] = epow<F>(J.z, t);
+    else if (t - J.nlo < J.nhi) J.hi[t - J.nlo] = epow<F>(J.z, (u64)(t - J.nlo) << 10);
 }
 
 // table[t] = z^t, t < n
@@ -658,37 +658,37 @@ __global__ __launch_bounds__(256) void k_pow_grind(PowState<F> st, u64 start, u6
 
 // ------------------------------------------------------------------ query gathers (outputs canonical)
 
-// rows[q][w] = cols[w * stride + idx[q]]
-template <class F>
-__global__ void k_gather_rows(const typename F::T* __restrict__ cols, size_t stride, u32 width, const u64* __restrict__ idx,
-                              u32 nidx, typename F::T* __restrict__ rows) {
+// blockIdx.y = job.  rows[q][e] = vals[e * stride + leaf_q]  (FRI layer: v_(e % D)[arity * leaf_q + e / D]);  path[q][i][0..H) =
+// level_i[(leaf_q >> i) ^ 1];  leaf_q = idx[q] >> shift
+template <class F, bool INLINE>
+__global__ __launch_bounds__(256) void k_query_gather(QueryJobs<F> jobs, QueryIdx inl, const u64* __restrict__ idx, u32 nidx,
+                                                      typename F::T* __restrict__ out) {
+    constexpr u32 H = F::H, D = F::D;
+    const QueryJob<F>& J = jobs.j[blockIdx.y];
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nidx * width) return;
-    u32 q = g / width, w = g % width;
-    rows[g] = (typename F::T)F::dec(cols[(size_t)w * stride + idx[q]]);
-}
-// FRI layer leaf: out[q][D k + comp] = v_comp[arity * idx[q] + k]
-template <class F>
-__global__ void k_gather_fri_leaves(const typename F::T* __restrict__ vals, size_t len, u32 arity_bits,
-                                    const u64* __restrict__ idx, u32 nidx, typename F::T* __restrict__ out) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 width = F::D << arity_bits;
-    if (g >= nidx * width) return;
-    u32 q = g / width, e = g % width;
-    out[g] = (typename F::T)F::dec(vals[(size_t)(e % F::D) * len + (idx[q] << arity_bits) + e / F::D]);
-}
-// sib[q][i][0..H) = level_i[(idx[q] >> i) ^ 1]
-template <class F>
-__global__ void k_gather_siblings_multi(const typename F::T* __restrict__ levels, u32 log_leaves, u32 cap_height,
-                                        const u64* __restrict__ idx, u32 nidx, typename F::T* __restrict__ out) {
-    constexpr u32 H = F::H;
-    const u32 layers = log_leaves - cap_height;
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nidx * layers * H) return;
-    u32 e = g % H, i = (g / H) % layers, q = (g / H) / layers;
-    const u64 N = (u64)1 << log_leaves;
+    const u32 nrow = nidx * J.width;
+    const bool row = g < nrow;
+    if (!row) g -= nrow;
+    if (!row && g >= nidx * J.layers * H) return;
+    const u32 q = row ? g / J.width : (g / H) / J.layers;
+    u64 x = 0;
+    if (INLINE) {   // the indices came with the launch (no upload): static indexing of the argument, one select per slot
+#pragma unroll
+        for (u32 i = 0; i < QUERY_IDX_INLINE; i++) x = q == i ? inl.v[i] : x;
+    } else {
+        x = idx[q];
+    }
+    const u64 leaf = x >> J.shift;
+    if (row) {
+        const u32 e = g % J.width;
+        const size_t src = J.fri ? (size_t)(e % D) * J.stride + (leaf << J.arity_bits) + e / D : (size_t)e * J.stride + leaf;
+        out[J.out + g] = (typename F::T)F::dec(J.vals[src]);
+        return;
+    }
+    const u32 e = g % H, i = (g / H) % J.layers;
+    const u64 N = (u64)1 << J.log_leaves;
     const u64 off = 2 * N - ((2 * N) >> i);
-    out[g] = levels[H * (off + ((idx[q] >> i) ^ 1)) + e];
+    out[J.out + nrow + g] = J.levels[H * (off + ((leaf >> i) ^ 1)) + e];
 }
 
 // ------------------------------------------------------------------ launchers
@@ -697,12 +697,10 @@ static inline u32 nblk(size_t n, u32 bs) { return (u32)((n + bs - 1) / bs); }
 
 template <class F>
 void zs_partial_products(const ZsParams<F>& p, const typename F::T* witness, const typename F::T* sigma, const typename F::T* k_is,
-                         const typename F::T* betas, const typename F::T* gammas, typename F::T* q_tmp, typename F::T* zloc_tmp,
-                         typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st) {
+                         typename F::T* q_tmp, typename F::T* zloc_tmp, typename F::T* totals_tmp, u32* err, typename F::T* out, hipStream_t st) {
     const size_t n = (size_t)1 << p.log_n;
     const u32 nb1024 = nblk(n, 1024);
-    hipLaunchKernelGGL(k_zs_quotients<F>, dim3(nblk(n, 256) * p.num_challenges), dim3(256), 0, st, p, witness, sigma, k_is, betas,
-                       gammas, q_tmp, err);
+    hipLaunchKernelGGL(k_zs_quotients<F>, dim3(nblk(n, 256) * p.num_challenges), dim3(256), 0, st, p, witness, sigma, k_is, q_tmp, err);
     hipLaunchKernelGGL(k_zs_scan_local<F>, dim3(nb1024, p.num_challenges), dim3(256), 0, st, p, q_tmp, zloc_tmp, totals_tmp);
     hipLaunchKernelGGL(k_zs_scan_totals<F>, dim3(p.num_challenges), dim3(1024), 0, st, totals_tmp, nb1024);
     hipLaunchKernelGGL(k_zs_finalize<F>, dim3(nblk(n, 256), p.num_challenges), dim3(256), 0, st, p, q_tmp, zloc_tmp, totals_tmp,
@@ -811,8 +809,10 @@ void quotient_combine(u32 log_n, u32 rate_bits, u32 num_challenges, const typena
 }
 
 template <class F>
-void ext_powtab(typename F::E z, typename F::E* lo, typename F::E* hi, u32 nhi, hipStream_t st) {
-    hipLaunchKernelGGL(k_ext_powtab<F>, dim3(nblk((size_t)1024 + nhi, 256)), dim3(256), 0, st, z, lo, hi, nhi);
+void ext_powtabs(const ExtPowJobs<F>& jobs, u32 njobs, hipStream_t st) {
+    u32 most = 0;
+    for (u32 j = 0; j < njobs; j++) most = std::max(most, jobs.j[j].nlo + jobs.j[j].nhi);
+    if (most) hipLaunchKernelGGL(k_ext_powtabs<F>, dim3(nblk(most, 256), njobs), dim3(256), 0, st, jobs);
 }
 
 template <class F>
@@ -870,31 +870,25 @@ void pow_grind(const PowState<F>& s, u64 start, u64 count, u32 min_lz, u64* resu
 }
 
 template <class F>
-void gather_rows_multi(const typename F::T* cols, size_t stride, u32 width, const u64* idx, u32 nidx, typename F::T* rows,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(k_gather_rows<F>, dim3(nblk((size_t)nidx * width, 256)), dim3(256), 0, st, cols, stride, width, idx, nidx, rows);
-}
-template <class F>
-void gather_fri_leaves(const typename F::T* vals, size_t len, u32 arity_bits, const u64* idx, u32 nidx, typename F::T* out,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(k_gather_fri_leaves<F>, dim3(nblk((size_t)nidx * (F::D << arity_bits), 256)), dim3(256), 0, st, vals, len,
-                       arity_bits, idx, nidx, out);
-}
-template <class F>
-void gather_siblings_multi(const typename F::T* levels, u32 log_leaves, u32 cap_height, const u64* idx, u32 nidx, typename F::T* out,
-                           hipStream_t st) {
-    const u32 layers = log_leaves - cap_height;
-    if (!layers) return;
-    hipLaunchKernelGGL(k_gather_siblings_multi<F>, dim3(nblk((size_t)nidx * layers * F::H, 256)), dim3(256), 0, st, levels,
-                       log_leaves, cap_height, idx, nidx, out);
+void query_gather(const QueryJobs<F>& jobs, u32 njobs, const u64* idx_host, const u64* idx_dev, u32 nidx, typename F::T* out, hipStream_t st) {
+    size_t most = 0;
+    for (u32 j = 0; j < njobs; j++) most = std::max(most, (size_t)nidx * (jobs.j[j].width + (size_t)jobs.j[j].layers * F::H));
+    if (!most || !njobs) return;
+    QueryIdx inl{};
+    if (nidx <= QUERY_IDX_INLINE) {
+        std::copy(idx_host, idx_host + nidx, inl.v);
+        hipLaunchKernelGGL((k_query_gather<F, true>), dim3(nblk(most, 256), njobs), dim3(256), 0, st, jobs, inl, idx_dev, nidx, out);
+    } else {
+        hipLaunchKernelGGL((k_query_gather<F, false>), dim3(nblk(most, 256), njobs), dim3(256), 0, st, jobs, inl, idx_dev, nidx, out);
+    }
 }
 
 #define GB_INSTANTIATE(F)                                                                                                           \
-    template void zs_partial_products<F>(const ZsParams<F>&, const F::T*, const F::T*, const F::T*, const F::T*, const F::T*, F::T*, \
-                                         F::T*, F::T*, u32*, F::T*, hipStream_t);                                                   \
+    template void zs_partial_products<F>(const ZsParams<F>&, const F::T*, const F::T*, const F::T*, F::T*, F::T*, F::T*, u32*, F::T*,  \
+                                         hipStream_t);                                                                              \
     template void quotient_combine<F>(u32, u32, u32, const F::T*, const F::T*, const CosetPow<F>&, F::T*, hipStream_t);             \
     template void l0_table<F>(u32, u32, const PowTab<F>&, const F::T*, F::T*, hipStream_t);                                         \
-    template void ext_powtab<F>(F::E, F::E*, F::E*, u32, hipStream_t);                                                              \
+    template void ext_powtabs<F>(const ExtPowJobs<F>&, u32, hipStream_t);                                                           \
     template void ext_pow_table<F>(const ExtPowTab<F>&, size_t, F::E*, hipStream_t);                                                \
     template void eval_columns<F>(const F::T*, size_t, size_t, const F::E*, F::E*, F::E*, hipStream_t);                             \
     template void reduce_polys<F>(const PolyGroups<F>&, size_t, const F::E*, F::E*, hipStream_t);                                   \
@@ -904,9 +898,7 @@ void gather_siblings_multi(const typename F::T* levels, u32 log_leaves, u32 cap_
     template void fri_leaves<F>(const F::T*, size_t, u32, u64, F::T*, hipStream_t);                                                 \
     template void fri_fold<F>(const F::T*, size_t, u32, F::E, F::T*, hipStream_t);                                                  \
     template void pow_grind<F>(const PowState<F>&, u64, u64, u32, u64*, hipStream_t);                                               \
-    template void gather_rows_multi<F>(const F::T*, size_t, u32, const u64*, u32, F::T*, hipStream_t);                              \
-    template void gather_fri_leaves<F>(const F::T*, size_t, u32, const u64*, u32, F::T*, hipStream_t);                              \
-    template void gather_siblings_multi<F>(const F::T*, u32, u32, const u64*, u32, F::T*, hipStream_t);
+    template void query_gather<F>(const QueryJobs<F>&, u32, const u64*, const u64*, u32, F::T*, hipStream_t);
 GB_INSTANTIATE(GlF)
 GB_INSTANTIATE(BbF)
 #undef GB_INSTANTIATE

@@ -16,46 +16,65 @@ inline void permute(u64 (&s)[12]) {
     static const u64 RC[GL_POSEIDON_ALL_ROUND_CONSTANTS_LEN] = {GL_POSEIDON_ALL_ROUND_CONSTANTS_LIST};
     static const u64 CIRC[12] = {GL_POSEIDON_MDS_CIRC_LIST};
     static const u64 DIAG[12] = {GL_POSEIDON_MDS_DIAG_LIST};
-    // the defining (naive) form: hash/poseidon_goldilocks.rs:927-948
+    static const u64 FIRST[12] = {GL_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT_LIST};
+    static const u64 PRC[22] = {GL_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS_LIST};
+    static const u64 VS[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_VS_LIST};
+    static const u64 WHAT[22 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_W_HATS_LIST};
+    static const u64 INIT[11 * 11] = {GL_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX_LIST};
     auto sbox = [](u64 x) {
         u64 x2 = gl::sqr(x), x4 = gl::sqr(x2), x3 = gl::mul(x, x2);
         return gl::mul(x3, x4);
     };
-    // MDS entries are below 2^6: each output is two 64-bit sums over the 32-bit halves of the inputs (< 2^42 each, no carries) and ONE
-    // reduction - loops over r with unit stride that the host compiler vectorises - instead of thirteen 64 x 64 -> 128 products
-    // (round 6: the transcript's ~80 permutations per proof were 0.4 ms of a 4 ms recursion-shaped proof)
+    // MDS entries are below 2^6: a row is a sum of thirteen 64 x 6-bit products (< 2^74) in one 128-bit accumulator and ONE reduction
     auto mds = [&](u64 (&st)[12]) {
-        u64 lo2[24], hi2[24], sl[12], sh[12];
-        for (int i = 0; i < 12; i++) {
-            lo2[i] = lo2[i + 12] = (uint32_t)st[i];
-            hi2[i] = hi2[i + 12] = st[i] >> 32;
-        }
+        u64 d[24];
+        for (int i = 0; i < 12; i++) d[i] = d[i + 12] = st[i];
         for (int r = 0; r < 12; r++) {
-            sl[r] = lo2[r] * DIAG[r];
-            sh[r] = hi2[r] * DIAG[r];
-        }
-        for (int i = 0; i < 12; i++) {
-            const u64 c = CIRC[i];
-            for (int r = 0; r < 12; r++) {
-                sl[r] += lo2[r + i] * c;
-                sh[r] += hi2[r + i] * c;
-            }
-        }
-        for (int r = 0; r < 12; r++) {
-            const unsigned __int128 acc = (unsigned __int128)sl[r] + ((unsigned __int128)sh[r] << 32);
+            unsigned __int128 acc = (unsigned __int128)d[r] * DIAG[r];
+            for (int i = 0; i < 12; i++) acc += (unsigned __int128)d[r + i] * CIRC[i];
             st[r] = gl::reduce128((u64)acc, (u64)(acc >> 64));
         }
     };
-    int round = 0;
-    for (int phase = 0; phase < 3; phase++) {
-        int cnt = phase == 1 ? 22 : 4;
-        for (int k = 0; k < cnt; k++, round++) {
-            for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], RC[12 * round + i]);
-            if (phase == 1) s[0] = sbox(s[0]);
-            else for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-            mds(s);
+    auto full_round = [&](int round) {
+        for (int i = 0; i < 12; i++) s[i] = sbox(gl::add(s[i], RC[12 * round + i]));
+        mds(s);
+    };
+    // sum of up to 16 full 64 x 64 products, reduced once: the carries out of bit 128 are worth 2^128 = -2^32 (mod p) each
+    struct Acc {
+        unsigned __int128 v = 0;
+        u64 over = 0;
+        void mad(u64 a, u64 b) {
+            const unsigned __int128 t = (unsigned __int128)a * b;
+            v += t;
+            over += v < t;
         }
+        u64 value() const { return gl::sub(gl::reduce128((u64)v, (u64)(v >> 64)), over << 32); }
+    };
+    for (int r = 0; r < 4; r++) full_round(r);
+    // the 22 partial rounds in the (v, w_hat, M_init) form of hash/poseidon.rs:718-744, :899-909 - one s-box and 23 products a round
+    // instead of a 12 x 12 matrix (round 6: 4.5 -> 1.6 us a permutation; the transcript of a 2^12-row proof is ~120 of them)
+    for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], FIRST[i]);
+    {
+        u64 t[12];
+        t[0] = s[0];
+        for (int c = 0; c < 11; c++) {
+            Acc a;
+            for (int r = 1; r < 12; r++) a.mad(s[r], INIT[(r - 1) * 11 + c]);
+            t[c + 1] = a.value();
+        }
+        std::memcpy(s, t, sizeof t);
     }
+    for (int k = 0; k < 22; k++) {
+        const u64 s0 = gl::add(sbox(s[0]), PRC[k]);
+        Acc d;
+        d.mad(s0, CIRC[0] + DIAG[0]);
+        for (int i = 1; i < 12; i++) {
+            d.mad(s[i], WHAT[k * 11 + i - 1]);
+            s[i] = gl::add(s[i], gl::mul(s0, VS[k * 11 + i - 1]));
+        }
+        s[0] = d.value();
+    }
+    for (int r = 26; r < 30; r++) full_round(r);
 }
 
 // hash_n_to_hash_no_pad (hash/hashing.rs:100-133)

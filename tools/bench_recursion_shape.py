@@ -86,7 +86,6 @@ def main():
             many_in_flight(log_n, k)
         return
     ctx = GpuContext(0)
-    ctx.set_profiling(True)
     for log_n in [int(a) for a in args] or [12, 13, 14]:
         # circuit_builder.rs:1190-1192: (64 - degree_bits) * num_challenges >= 100 needs a third challenge above 2^14 rows
         b, pw, _ = recursion_gates_circuit(FIELD, seed=log_n, num_challenges=_challenges(log_n), **CFG_KW)
@@ -99,15 +98,24 @@ def main():
         assert c.data.verify(proof)
         import torch
         wd = torch.from_numpy(w.view(VIEW)).to("cuda:0")
+        def timed(n=20):
+            ts = []
+            for _ in range(n):
+                ctx.synchronize()
+                t = time.perf_counter()
+                c.data.prove(wd, pis)
+                ts.append(time.perf_counter() - t)
+            return ts
+        # the quoted time is taken the way a caller runs the prover - timing scopes off (the reference's timed! scopes are off below
+        # log level debug too); a second pass with the scopes on gives the breakdown (each scope is two HIP events in the stream)
         for _ in range(3):
             c.data.prove(wd, pis)
+        ctx.set_profiling(False)
+        ts = timed()
+        ctx.set_profiling(True)
+        c.data.prove(wd, pis)
         ctx.scope_reset()
-        ts = []
-        for _ in range(20):
-            ctx.synchronize()
-            t = time.perf_counter()
-            c.data.prove(wd, pis)
-            ts.append(time.perf_counter() - t)
+        ts_scopes = timed()
         scopes = {}
         for name in ("compute wires commitment", "compute partial products", "compute quotient polys", "construct the opening set",
                      "compute opening proofs", "find proof-of-work witness", "build Merkle tree", "IFFT", "FFT + blinding"):
@@ -116,7 +124,8 @@ def main():
         print(json.dumps({"workload": "recursion-shaped circuit, %d gates in the set" % len(c.gate_table),
                           "field": "babybear" if FIELD else "goldilocks", "log_n": log_n, "rate_bits": CFG_KW.get("rate_bits", 3),
                           "prove_ms_median": round(1e3 * float(np.median(ts)), 3), "prove_ms_min": round(1e3 * min(ts), 3),
-                          "proofs_per_s": round(1.0 / float(np.median(ts)), 1), "proof_bytes": len(proof), "verified": True,
+                          "proofs_per_s": round(1.0 / float(np.median(ts)), 1),
+                          "prove_ms_median_with_timing_scopes": round(1e3 * float(np.median(ts_scopes)), 3), "proof_bytes": len(proof), "verified": True,
                           "scopes_ms_per_proof": scopes}), flush=True)
         c.data.free()
 
