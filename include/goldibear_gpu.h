@@ -62,6 +62,11 @@ enum {
 #define GB_SALT_SIZE 4 /* fri/oracle.rs:25 */
 
 /* ---- context ------------------------------------------------------------------------------- */
+/* One context = one HIP stream (+ a copy stream) and one proving thread.  Several contexts of one process prove concurrently -
+ * the way to use the GPU with recursion-sized circuits, which cannot fill it alone.  They overlap only as far as the HIP runtime
+ * gives their streams hardware queues of their own: it creates GPU_MAX_HW_QUEUES of them (environment, read when the runtime
+ * initialises; 4 by default), so a host that keeps more than four contexts busy exports GPU_MAX_HW_QUEUES=8 before its first
+ * HIP call (six 2^12-row proofs in flight: 576 proofs/s on 4 queues, 831 on 8).  The library never changes the environment. */
 gb_status gb_ctx_create(int device, gb_ctx** out);
 gb_status gb_ctx_destroy(gb_ctx* ctx);
 const char* gb_last_error(const gb_ctx* ctx); /* valid until the next call on ctx; ctx may be NULL */

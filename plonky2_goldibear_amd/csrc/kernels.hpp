@@ -223,11 +223,29 @@ struct ExtPowJobs {
 };
 template <class F>
 void ext_powtabs(const ExtPowJobs<F>& jobs, u32 njobs, hipStream_t st);
+// table_k[t] = z_k^t (t < n) from the split tables, for up to two points in one launch
 template <class F>
-void ext_pow_table(const ExtPowTab<F>& z, size_t n, typename F::E* table, hipStream_t st);
+struct ExtPowTables {
+    ExtPowTab<F> z[2];
+    typename F::E* table[2];
+};
 template <class F>
-void eval_columns(const typename F::T* coeffs, size_t ncols, size_t n, const typename F::E* ztab, typename F::E* partial_tmp,
-                  typename F::E* out, hipStream_t st);
+void ext_pow_tables(const ExtPowTables<F>& z, u32 count, size_t n, hipStream_t st);
+// out[col] = sum_t coeffs_col[t] ztab[t] for every column of up to five batches (columns numbered through the jobs in order);
+// partial_tmp: ceil(n / 4096) elements per column
+template <class F>
+struct EvalJob {
+    const typename F::T* coeffs;   // [ncols][n]
+    const typename F::E* ztab;     // the point's powers (ext_pow_tables)
+    u32 ncols;
+};
+static constexpr u32 EVAL_JOBS = 5;
+template <class F>
+struct EvalJobs {
+    EvalJob<F> j[EVAL_JOBS];
+};
+template <class F>
+void eval_columns(const EvalJobs<F>& jobs, u32 njobs, size_t n, typename F::E* partial_tmp, typename F::E* out, hipStream_t st);
 template <class F>
 void reduce_polys(const PolyGroups<F>& g, size_t n, const typename F::E* apow, typename F::E* comp, hipStream_t st);
 template <class F>

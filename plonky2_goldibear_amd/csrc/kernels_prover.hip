@@ -387,11 +387,11 @@ __global__ __launch_bounds__(256) void k_ext_powtabs(ExtPowJobs<F> jobs) {   // 
     else if (t - J.nlo < J.nhi) J.hi[t - J.nlo] = epow<F>(J.z, (u64)(t - J.nlo) << 10);
 }
 
-// table[t] = z^t, t < n
+// table_k[t] = z_k^t, t < n  (blockIdx.y = k)
 template <class F>
-__global__ __launch_bounds__(256) void k_ext_pow_table(ExtPowTab<F> z, size_t n, typename F::E* __restrict__ table) {
+__global__ __launch_bounds__(256) void k_ext_pow_tables(ExtPowTables<F> z, size_t n) {
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t < n) table[t] = pow_split(z, t);
+    if (t < n) z.table[blockIdx.y][t] = pow_split(z.z[blockIdx.y], t);
 }
 
 template <class F>
@@ -407,13 +407,17 @@ __device__ __forceinline__ typename F::E block_reduce_add(typename F::E v, typen
     return r;
 }
 
-// grid (nchunks = ceil(n / 4096), ncols): partial[col][chunk] = sum over the chunk of c_t * z^t
+// Evaluation of every column of up to five coefficient batches at their points (OpeningSet::new: constants/sigmas, wires, Z at
+// zeta and g zeta, quotient) in two launches; columns are numbered through the jobs in order.
+// grid (nchunks = ceil(n / 4096), total columns): partial[col][chunk] = sum over the chunk of c_t * z^t
 template <class F>
-__global__ __launch_bounds__(256) void k_eval_partial(const typename F::T* __restrict__ coeffs, size_t n,
-                                                      const typename F::E* __restrict__ ztab, typename F::E* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_eval_partial(EvalJobs<F> jobs, size_t n, typename F::E* __restrict__ partial) {
     typedef typename F::E E;
     __shared__ E sh[256];
-    const typename F::T* c = coeffs + (size_t)blockIdx.y * n;
+    u32 col = blockIdx.y, j = 0;
+    while (col >= jobs.j[j].ncols) col -= jobs.j[j++].ncols;
+    const typename F::T* c = jobs.j[j].coeffs + (size_t)col * n;
+    const E* ztab = jobs.j[j].ztab;
     const size_t base = (size_t)blockIdx.x * 4096;
     E acc = F::ezero();
     for (u32 k = 0; k < 16; k++) {
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(256) void k_eval_partial(const typename F::T* __res
     E r = block_reduce_add<F>(acc, sh);
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
-// grid (ncols): out[col] = sum of partial[col][*]
+// grid (total columns): out[col] = sum of partial[col][*]
 template <class F>
 __global__ __launch_bounds__(256) void k_eval_final(const typename F::E* __restrict__ partial, u32 nchunks,
                                                     typename F::E* __restrict__ out) {
@@ -816,17 +820,18 @@ void ext_powtabs(const ExtPowJobs<F>& jobs, u32 njobs, hipStream_t st) {
 }
 
 template <class F>
-void ext_pow_table(const ExtPowTab<F>& z, size_t n, typename F::E* table, hipStream_t st) {
-    hipLaunchKernelGGL(k_ext_pow_table<F>, dim3(nblk(n, 256)), dim3(256), 0, st, z, n, table);
+void ext_pow_tables(const ExtPowTables<F>& z, u32 count, size_t n, hipStream_t st) {
+    if (count && n) hipLaunchKernelGGL(k_ext_pow_tables<F>, dim3(nblk(n, 256), count), dim3(256), 0, st, z, n);
 }
 
 template <class F>
-void eval_columns(const typename F::T* coeffs, size_t ncols, size_t n, const typename F::E* ztab, typename F::E* partial_tmp,
-                  typename F::E* out, hipStream_t st) {
-    if (!ncols) return;
+void eval_columns(const EvalJobs<F>& jobs, u32 njobs, size_t n, typename F::E* partial_tmp, typename F::E* out, hipStream_t st) {
+    u32 total = 0;
+    for (u32 j = 0; j < njobs; j++) total += jobs.j[j].ncols;
+    if (!total) return;
     const u32 nch = nblk(n, 4096);
-    hipLaunchKernelGGL(k_eval_partial<F>, dim3(nch, (u32)ncols), dim3(256), 0, st, coeffs, n, ztab, partial_tmp);
-    hipLaunchKernelGGL(k_eval_final<F>, dim3((u32)ncols), dim3(256), 0, st, partial_tmp, nch, out);
+    hipLaunchKernelGGL(k_eval_partial<F>, dim3(nch, total), dim3(256), 0, st, jobs, n, partial_tmp);
+    hipLaunchKernelGGL(k_eval_final<F>, dim3(total), dim3(256), 0, st, partial_tmp, nch, out);
 }
 
 template <class F>
@@ -889,8 +894,8 @@ void query_gather(const QueryJobs<F>& jobs, u32 njobs, const u64* idx_host, cons
     template void quotient_combine<F>(u32, u32, u32, const F::T*, const F::T*, const CosetPow<F>&, F::T*, hipStream_t);             \
     template void l0_table<F>(u32, u32, const PowTab<F>&, const F::T*, F::T*, hipStream_t);                                         \
     template void ext_powtabs<F>(const ExtPowJobs<F>&, u32, hipStream_t);                                                           \
-    template void ext_pow_table<F>(const ExtPowTab<F>&, size_t, F::E*, hipStream_t);                                                \
-    template void eval_columns<F>(const F::T*, size_t, size_t, const F::E*, F::E*, F::E*, hipStream_t);                             \
+    template void ext_pow_tables<F>(const ExtPowTables<F>&, u32, size_t, hipStream_t);                                              \
+    template void eval_columns<F>(const EvalJobs<F>&, u32, size_t, F::E*, F::E*, hipStream_t);                                      \
     template void reduce_polys<F>(const PolyGroups<F>&, size_t, const F::E*, F::E*, hipStream_t);                                   \
     template void divide_by_linear_accumulate<F>(const F::E*, size_t, const ExtPowTab<F>&, const ExtPowTab<F>&, F::E, int, F::E*,   \
                                                  F::E*, F::E*, hipStream_t);                                                        \

@@ -8,6 +8,13 @@ import os
 
 from . import build as _build
 
+# Several contexts proving at once (one stream and one host thread each - recursion-sized proofs cannot fill the GPU alone) need
+# a hardware queue each to overlap: the HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues, 4 unless the environment says
+# otherwise, and reads the variable when it initialises - so it is set here, before anything touches the GPU, unless the host has
+# chosen a value (tools/bench_recursion_shape.py --inflight 6: 576 proofs/s on 4 queues, 831 on 8).  A C host sets it itself
+# (INTEGRATION.md).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 GB_OK, GB_ERR_INVALID, GB_ERR_HIP, GB_ERR_OOM, GB_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 GB_ERR_PERM_ARG_ZERO, GB_ERR_OPENING_IN_SUBGROUP, GB_ERR_BUFFER_TOO_SMALL, GB_ERR_VERIFY = 16, 17, 18, 19
 GB_GOLDILOCKS, GB_BABYBEAR = 0, 1

@@ -55,7 +55,7 @@ def many_in_flight(log_n, k):
         ctx.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"workload": "recursion-shaped circuits, %d in flight (one stream + one host thread each)" % k, "log_n": log_n,
-                      "proofs": k * per_thread, "seconds": round(dt, 4), "proofs_per_s": round(k * per_thread / dt, 1)}), flush=True)
+                      "proofs": k * per_thread, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "seconds": round(dt, 4), "proofs_per_s": round(k * per_thread / dt, 1)}), flush=True)
     for ctx, c, _, _ in lanes:
         c.data.free()
         ctx.close()
