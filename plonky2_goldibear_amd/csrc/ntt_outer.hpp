@@ -37,24 +37,29 @@ __device__ __forceinline__ typename F::T tw_split(const typename F::T* __restric
 }
 
 // R-point DFT (R = 2^K <= 16) of z[0..R) with the primitive R-th root `wr` (forward or inverse, as the caller passes it): X[k1] in
-// z[k1].  R = 2 and 4 in registers; 8 and 16 (2^23 and 2^24 rows) as the plain O(R^2) sum - coverage, not speed.
-template <class F>
-__device__ __forceinline__ void dft_r(typename F::T (&z)[16], u32 K, typename F::T wr) {
+// z[k1].  K is a template parameter of everything here, so that the R values live in registers (as run-time bounds they lived in
+// scratch memory and the combine pass ran at 2.5 TB/s).  R = 8 and 16 as the plain O(R^2) sum.
+template <class F, u32 K>
+__device__ __forceinline__ void dft_r(typename F::T (&z)[1u << K], typename F::T wr) {
     typedef typename F::T T;
-    if (K == 1) {
+    constexpr u32 R = 1u << K;
+    if constexpr (K == 1) {
         const T a = z[0], b = z[1];
         z[0] = F::add(a, b);
         z[1] = F::sub(a, b);
-    } else if (K > 2) {
-        const u32 R = 1u << K;
-        T wp[16], x[16];
+    } else if constexpr (K > 2) {
+        T wp[R], x[R];
         wp[0] = F::one();
+#pragma unroll
         for (u32 j = 1; j < R; j++) wp[j] = F::mul(wp[j - 1], wr);
+#pragma unroll
         for (u32 k1 = 0; k1 < R; k1++) {
             T acc = z[0];
+#pragma unroll
             for (u32 i1 = 1; i1 < R; i1++) acc = F::add(acc, F::mul(z[i1], wp[(i1 * k1) & (R - 1)]));
             x[k1] = acc;
         }
+#pragma unroll
         for (u32 k1 = 0; k1 < R; k1++) z[k1] = x[k1];
     } else {
         const T w4 = wr;
@@ -67,46 +72,72 @@ __device__ __forceinline__ void dft_r(typename F::T (&z)[16], u32 K, typename F:
 }
 
 // in place: data[col][k1][k2] <- r_inv * sum_i1 w_R^-(i1 k1) w_n^-(i1 k2) data[col][i1][k2]
-template <class F>
-__global__ __launch_bounds__(THREADS) void k_intt_combine(typename F::T* __restrict__ data, u32 log_m, u32 K, const typename F::T* __restrict__ tw_hi_inv,
+template <class F, u32 K>
+__global__ __launch_bounds__(THREADS) void k_intt_combine(typename F::T* __restrict__ data, u32 log_m, const typename F::T* __restrict__ tw_hi_inv,
                                                           const typename F::T* __restrict__ tw_lo_inv, typename F::T w4_inv, typename F::T r_inv) {
     typedef typename F::T T;
+    constexpr u32 R = 1u << K;
     const size_t g = (size_t)blockIdx.x * THREADS + threadIdx.x;
     const size_t col = g >> log_m;
-    const u32 k2 = (u32)(g & (((size_t)1 << log_m) - 1)), R = 1u << K;
+    const u32 k2 = (u32)(g & (((size_t)1 << log_m) - 1));
     T* p = data + ((col << log_m) << K) + k2;
     const T w = tw_split<F>(tw_hi_inv, tw_lo_inv, k2);   // w_n^-k2
-    T z[16], f = r_inv;
+    T z[R], f = r_inv;
+#pragma unroll
     for (u32 i1 = 0; i1 < R; i1++) {
         z[i1] = F::mul(p[(size_t)i1 << log_m], f);
-        f = F::mul(f, w);
+        if (i1 + 1 < R) f = F::mul(f, w);
     }
-    dft_r<F>(z, K, w4_inv);
+    dft_r<F, K>(z, w4_inv);
+#pragma unroll
     for (u32 k1 = 0; k1 < R; k1++) p[(size_t)k1 << log_m] = z[k1];
 }
 
 // sub: [col][i1][c][q] (q = brev(k2): the sub-LDEs' leaf order) -> lde[col][c][q R + brev_K(k1)]
-template <class F>
-__global__ __launch_bounds__(THREADS) void k_lde_combine(const typename F::T* __restrict__ sub, typename F::T* __restrict__ lde, u32 log_m, u32 K, u32 rate_bits,
+template <class F, u32 K>
+__global__ __launch_bounds__(THREADS) void k_lde_combine(const typename F::T* __restrict__ sub, typename F::T* __restrict__ lde, u32 log_m, u32 rate_bits,
                                                          const typename F::T* __restrict__ tw_hi, const typename F::T* __restrict__ tw_lo,
                                                          const typename F::T* __restrict__ pow_lo, u32 nlo, typename F::T w4) {
     typedef typename F::T T;
+    constexpr u32 R = 1u << K;
     const size_t g = (size_t)blockIdx.x * THREADS + threadIdx.x;   // (col, c, q)
-    const u32 q = (u32)(g & (((size_t)1 << log_m) - 1)), R = 1u << K;
+    const u32 q = (u32)(g & (((size_t)1 << log_m) - 1));
     const size_t cc = g >> log_m;
     const u32 c = (u32)(cc & ((1u << rate_bits) - 1));
     const size_t col = cc >> rate_bits;
     const u32 k2 = brev_bits(q, log_m);
     const T gk = F::mul(pow_lo[(size_t)c * nlo + 1], tw_split<F>(tw_hi, tw_lo, k2));   // s_c w_n^k2
-    T z[16], f = F::one();
+    T z[R], f = gk;
+#pragma unroll
     for (u32 i1 = 0; i1 < R; i1++) {
         const T v = sub[(((((col << K) + i1) << rate_bits) + c) << log_m) + q];
         z[i1] = i1 ? F::mul(v, f) : v;
-        f = F::mul(f, gk);
+        if (i1 && i1 + 1 < R) f = F::mul(f, gk);
     }
-    dft_r<F>(z, K, w4);
+    dft_r<F, K>(z, w4);
     T* o = lde + ((((col << rate_bits) + c) << log_m) << K) + ((size_t)q << K);
+#pragma unroll
     for (u32 k1 = 0; k1 < R; k1++) o[brev_bits(k1, K)] = z[k1];
+}
+
+// the kernels above by the run-time K (1 .. NTT_OUTER_MAX_BITS = 4)
+template <class F, class... A>
+void launch_intt_combine(u32 K, dim3 grid, hipStream_t st, A... a) {
+    switch (K) {
+        case 1: hipLaunchKernelGGL((k_intt_combine<F, 1>), grid, dim3(THREADS), 0, st, a...); break;
+        case 2: hipLaunchKernelGGL((k_intt_combine<F, 2>), grid, dim3(THREADS), 0, st, a...); break;
+        case 3: hipLaunchKernelGGL((k_intt_combine<F, 3>), grid, dim3(THREADS), 0, st, a...); break;
+        default: hipLaunchKernelGGL((k_intt_combine<F, 4>), grid, dim3(THREADS), 0, st, a...); break;
+    }
+}
+template <class F, class... A>
+void launch_lde_combine(u32 K, dim3 grid, hipStream_t st, A... a) {
+    switch (K) {
+        case 1: hipLaunchKernelGGL((k_lde_combine<F, 1>), grid, dim3(THREADS), 0, st, a...); break;
+        case 2: hipLaunchKernelGGL((k_lde_combine<F, 2>), grid, dim3(THREADS), 0, st, a...); break;
+        case 3: hipLaunchKernelGGL((k_lde_combine<F, 3>), grid, dim3(THREADS), 0, st, a...); break;
+        default: hipLaunchKernelGGL((k_lde_combine<F, 4>), grid, dim3(THREADS), 0, st, a...); break;
+    }
 }
 
 // ---- host side.  `Sub` = callables running the 2^(log_n - K)-row transforms: intt(src, dst, scratch, ncols) / lde(coeffs, out, ncols).
@@ -126,7 +157,7 @@ void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T
     }
     sub_intt(coeffs, coeffs, scratch, ncols << K);
     const T w4_inv = F::inv(F::two_adic_generator(K < 2 ? 2 : K)), r_inv = F::inv(F::enc((u64)1 << K));   // the R-th root (R = 2: unused)
-    hipLaunchKernelGGL(k_intt_combine<F>, dim3(grid), dim3(THREADS), 0, st, coeffs, log_m, K, tw_hi_inv, tw_lo_inv, w4_inv, r_inv);
+    launch_intt_combine<F>(K, dim3(grid), st, coeffs, log_m, tw_hi_inv, tw_lo_inv, w4_inv, r_inv);
 }
 
 // coefficients [ncols][n] -> lde [ncols][2^r][n] (leaf order); work holds work_elems elements (>= (1 + 2^r) n for one column)
@@ -144,8 +175,8 @@ void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, 
         T* wl = work + g * n;    // [g R][2^r][m] their LDEs
         hipLaunchKernelGGL(k_deinterleave<F>, dim3((u32)((g << log_m) / THREADS)), dim3(THREADS), 0, st, coeffs + c0 * n, wc, log_m, K);
         sub_lde(wc, wl, g << K);
-        hipLaunchKernelGGL(k_lde_combine<F>, dim3((u32)(((g << rate_bits) << log_m) / THREADS)), dim3(THREADS), 0, st, wl, lde + c0 * N, log_m, K, rate_bits,
-                           tw_hi, tw_lo, pow_lo, (u32)4096, w4);
+        launch_lde_combine<F>(K, dim3((u32)(((g << rate_bits) << log_m) / THREADS)), st, (const T*)wl, lde + c0 * N, log_m, rate_bits, tw_hi, tw_lo, pow_lo,
+                              (u32)4096, w4);
     }
 }
 
