@@ -19,14 +19,21 @@ static constexpr int THREADS = 256;
 __device__ __forceinline__ u32 brev_bits(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
 // dst[col][i1][i2] = src[col][R i2 + i1]
-template <class F>
-__global__ __launch_bounds__(THREADS) void k_deinterleave(const typename F::T* __restrict__ src, typename F::T* __restrict__ dst, u32 log_m, u32 K) {
+template <class F, u32 K>
+__global__ __launch_bounds__(THREADS) void k_deinterleave(const typename F::T* __restrict__ src, typename F::T* __restrict__ dst, u32 log_m) {
+    typedef typename F::T T;
+    constexpr u32 R = 1u << K, CHUNK = R * sizeof(T) >= 16 ? 16 / sizeof(T) : R;
+    struct alignas(CHUNK * sizeof(T)) Chunk { T v[CHUNK]; };
     const size_t g = (size_t)blockIdx.x * THREADS + threadIdx.x;   // (col, i2)
     const size_t col = g >> log_m, i2 = g & (((size_t)1 << log_m) - 1);
-    const u32 R = 1u << K;
-    const typename F::T* s = src + ((col << log_m) << K) + (i2 << K);
-    typename F::T* d = dst + ((col << log_m) << K) + i2;
-    for (u32 i1 = 0; i1 < R; i1++) d[(size_t)i1 << log_m] = s[i1];
+    const Chunk* s = reinterpret_cast<const Chunk*>(src + ((col << log_m) << K) + (i2 << K));
+    T* d = dst + ((col << log_m) << K) + i2;
+#pragma unroll
+    for (u32 j = 0; j < R / CHUNK; j++) {
+        const Chunk ch = s[j];
+#pragma unroll
+        for (u32 e = 0; e < CHUNK; e++) d[(size_t)(j * CHUNK + e) << log_m] = ch.v[e];
+    }
 }
 
 // w^e from split tables (e = 1024 e_hi + e_lo), device form
@@ -115,12 +122,33 @@ __global__ __launch_bounds__(THREADS) void k_lde_combine(const typename F::T* __
         if (i1 && i1 + 1 < R) f = F::mul(f, gk);
     }
     dft_r<F, K>(z, w4);
-    T* o = lde + ((((col << rate_bits) + c) << log_m) << K) + ((size_t)q << K);
+    // the R outputs of a thread are neighbours: stored as 16-byte words (one 8-byte store per element left every other sector of a
+    // line to a second instruction - 2.9 TB/s)
+    constexpr u32 CHUNK = R * sizeof(T) >= 16 ? 16 / sizeof(T) : R;
+    struct alignas(CHUNK * sizeof(T)) Chunk { T v[CHUNK]; };
+    T out[R];
 #pragma unroll
-    for (u32 k1 = 0; k1 < R; k1++) o[brev_bits(k1, K)] = z[k1];
+    for (u32 k1 = 0; k1 < R; k1++) out[brev_bits(k1, K)] = z[k1];
+    Chunk* o = reinterpret_cast<Chunk*>(lde + ((((col << rate_bits) + c) << log_m) << K) + ((size_t)q << K));
+#pragma unroll
+    for (u32 j = 0; j < R / CHUNK; j++) {
+        Chunk ch;
+#pragma unroll
+        for (u32 e = 0; e < CHUNK; e++) ch.v[e] = out[j * CHUNK + e];
+        o[j] = ch;
+    }
 }
 
 // the kernels above by the run-time K (1 .. NTT_OUTER_MAX_BITS = 4)
+template <class F, class... A>
+void launch_deinterleave(u32 K, dim3 grid, hipStream_t st, A... a) {
+    switch (K) {
+        case 1: hipLaunchKernelGGL((k_deinterleave<F, 1>), grid, dim3(THREADS), 0, st, a...); break;
+        case 2: hipLaunchKernelGGL((k_deinterleave<F, 2>), grid, dim3(THREADS), 0, st, a...); break;
+        case 3: hipLaunchKernelGGL((k_deinterleave<F, 3>), grid, dim3(THREADS), 0, st, a...); break;
+        default: hipLaunchKernelGGL((k_deinterleave<F, 4>), grid, dim3(THREADS), 0, st, a...); break;
+    }
+}
 template <class F, class... A>
 void launch_intt_combine(u32 K, dim3 grid, hipStream_t st, A... a) {
     switch (K) {
@@ -150,9 +178,9 @@ void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T
     const size_t n = (size_t)1 << log_n;
     const u32 grid = (u32)((ncols << log_m) / THREADS);
     if (src != coeffs) {
-        hipLaunchKernelGGL(k_deinterleave<F>, dim3(grid), dim3(THREADS), 0, st, src, coeffs, log_m, K);
+        launch_deinterleave<F>(K, dim3(grid), st, src, coeffs, log_m);
     } else {
-        hipLaunchKernelGGL(k_deinterleave<F>, dim3(grid), dim3(THREADS), 0, st, src, scratch, log_m, K);
+        launch_deinterleave<F>(K, dim3(grid), st, src, scratch, log_m);
         (void)hipMemcpyAsync(coeffs, scratch, ncols * n * sizeof(T), hipMemcpyDeviceToDevice, st);
     }
     sub_intt(coeffs, coeffs, scratch, ncols << K);
@@ -173,7 +201,7 @@ void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, 
         const size_t g = std::min(group, ncols - c0);
         T* wc = work;            // [g R][m] de-interleaved coefficients
         T* wl = work + g * n;    // [g R][2^r][m] their LDEs
-        hipLaunchKernelGGL(k_deinterleave<F>, dim3((u32)((g << log_m) / THREADS)), dim3(THREADS), 0, st, coeffs + c0 * n, wc, log_m, K);
+        launch_deinterleave<F>(K, dim3((u32)((g << log_m) / THREADS)), st, coeffs + c0 * n, wc, log_m);
         sub_lde(wc, wl, g << K);
         launch_lde_combine<F>(K, dim3((u32)(((g << rate_bits) << log_m) / THREADS)), st, (const T*)wl, lde + c0 * N, log_m, rate_bits, tw_hi, tw_lo, pow_lo,
                               (u32)4096, w4);

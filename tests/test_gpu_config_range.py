@@ -217,6 +217,23 @@ def test_proof_bytes_with_fixed_lists_of_wide_arities(ctx, field_name, degree_bi
     _prove_and_compare(ctx, circ, tag, bits=bits, seed=degree_bits)
 
 
+@pytest.mark.parametrize("field_name,degree_bits,kw,bits", [
+    ("goldilocks", 10, dict(num_query_rounds=84, rate_bits=3), None),        # > 64 query indices: the uploaded-index form of the gather
+    ("babybear", 9, dict(num_query_rounds=65, rate_bits=4), None),
+    ("goldilocks", 12, dict(cap_height=1), [1] * 11),                         # 4 + 11 trees: two launches of twelve jobs
+    ("babybear", 12, dict(cap_height=0, num_query_rounds=70), [1] * 12),      # 16 trees and 70 queries
+])
+def test_query_rounds_beyond_one_launch(ctx, field_name, degree_bits, kw, bits):
+    """fri_prover_query_rounds (fri/prover.rs:190-255) gathers every opened row and Merkle path in one launch per twelve trees, with
+    up to 64 query indices as a launch argument (csrc/kernels_prover.hip k_query_gather): the shapes beyond both limits, bytes ==
+    the oracle prover's."""
+    F, tag, mk = _field(field_name)
+    circ = D.DummyCircuit(degree_bits, mk(num_challenges=2 if F is GL else 6, **kw), F=F)
+    if bits is not None:
+        circ.reduction_arity_bits = list(bits)
+    _prove_and_compare(ctx, circ, tag, bits=bits, seed=degree_bits + len(bits or []))
+
+
 # ---------------------------------------------------------------------------------------------- the stage-level entry points
 @pytest.mark.parametrize("field_name,degree_bits,rate_bits,num_challenges", [("goldilocks", 9, 6, 5), ("goldilocks", 11, 7, 2),
                                                                              ("babybear", 8, 5, 11), ("babybear", 10, 8, 6)])
