@@ -4,7 +4,7 @@ standard_recursion_config_gl (num_challenges 2; 3 above 2^14 rows).  One row of 
 evaluates every gate of the set at every LDE point whatever sits in the rows, so the time is that of a full recursion circuit of
 the same size; the proof is verified.  The reference's one published number is for this shape: "about 170 ms" for a recursion
 proof (~2^12 rows) on a MacBook Pro (plonky2/README.md:5).
-usage: python tools/bench_recursion_shape.py [--babybear] [--high-rate] [--inflight K] [log_n ...]
+usage: python tools/bench_recursion_shape.py [--babybear] [--high-rate] [--no-scopes] [--inflight K] [log_n ...]
 --high-rate: the `high_rate_config` of the reference's size-optimised recursion test (recursion/recursive_verifier.rs:573-583: rate_bits 7,
 12 query rounds; the quotient then runs on every 16th LDE point) instead of the stock rate_bits 3 / 28 query rounds.
 --inflight K: K independent circuits proved concurrently, one context (= one HIP stream) and one host thread each - what an
@@ -80,6 +80,9 @@ def main():
     if args and args[0] == "--high-rate":
         CFG_KW.update(rate_bits=7, num_query_rounds=12)
         args = args[1:]
+    scopes_pass = True
+    if args and args[0] == "--no-scopes":     # skip the second, scope-timed pass (a kernel trace should end with the plain proofs)
+        scopes_pass, args = False, args[1:]
     if args and args[0] == "--inflight":
         k = int(args[1])
         for log_n in [int(a) for a in args[2:]] or [12]:
@@ -112,10 +115,12 @@ def main():
             c.data.prove(wd, pis)
         ctx.set_profiling(False)
         ts = timed()
-        ctx.set_profiling(True)
-        c.data.prove(wd, pis)
-        ctx.scope_reset()
-        ts_scopes = timed()
+        ts_scopes = [float("nan")]
+        if scopes_pass:
+            ctx.set_profiling(True)
+            c.data.prove(wd, pis)
+            ctx.scope_reset()
+            ts_scopes = timed()
         scopes = {}
         for name in ("compute wires commitment", "compute partial products", "compute quotient polys", "construct the opening set",
                      "compute opening proofs", "find proof-of-work witness", "build Merkle tree", "IFFT", "FFT + blinding"):
