@@ -35,7 +35,7 @@ def main():
             o += ["", "timing scopes of the 2^12-row Goldilocks proof (ms per proof; nested scopes overlap):", "  " + json.dumps(js[0]["scopes_ms_per_proof"])]
     g = os.path.join(d, "gaps.txt")
     if os.path.exists(g):
-        o += ["", "tools/trace_gaps.py on a kernel trace of the 2^12-row Goldilocks proof (rocprofv3 --kernel-trace; the tracer itself adds ~0.5 ms):"]
+        o += ["", "tools/trace_gaps.py on a kernel trace of the 2^12-row Goldilocks proof (rocprofv3 --kernel-trace, timing scopes off; the tracer adds about 0.2 ms per proof):"]
         o += ["  " + l.rstrip() for l in open(g)]
     open(out, "w").write("\n".join(o) + "\n")
     print("\n".join(o[:40]))
