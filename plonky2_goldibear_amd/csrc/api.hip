@@ -392,6 +392,15 @@ gb_status gl_tables_for(gb_ctx* ctx, u32 log_n, const gbk::GlNttTables** out) {
     if ((s = upload(ctx, vhi_i, &hi_i, &set.owned))) return s;
     set.t.tw_lo_fwd = lo_f; set.t.tw_hi_fwd = hi_f; set.t.tw_lo_inv = lo_i; set.t.tw_hi_inv = hi_i;
     set.t.n_inv = gl::inv((u64)n % gl::P);
+    set.t.tw_top_fwd = nullptr;
+    if (set.t.outer_bits) {
+        const u32 log_m = log_n - set.t.outer_bits;
+        std::vector<u64> top(256);
+        for (u32 j = 0; j < 256; j++) top[j] = gl::pow(w, (u64)bitrev32(j, 8) << (log_m - 8));
+        u64* t;
+        if ((s = upload(ctx, top, &t, &set.owned))) return s;
+        set.t.tw_top_fwd = t;
+    }
     {
         u64 *a, *b, *c, *d;
         if ((s = upload(ctx, times_r(vlo_f), &a, &set.owned))) return s;
@@ -526,6 +535,15 @@ gb_status bb_tables_for(gb_ctx* ctx, u32 log_n, const gbk::BbNttTables** out) {
     if ((s = upload32(ctx, bb_powers(bb::pow(wi, 1024), nhi), &hi_i, &set.owned))) return s;
     set.t.tw_lo_fwd = lo_f; set.t.tw_hi_fwd = hi_f; set.t.tw_lo_inv = lo_i; set.t.tw_hi_inv = hi_i;
     set.t.n_inv = bb::inv(bb::to_mont((u32)(n % bb::P)));
+    set.t.tw_top_fwd = nullptr;
+    if (set.t.outer_bits) {
+        const u32 log_m = log_n - set.t.outer_bits;
+        std::vector<u32> top(256);
+        for (u32 j = 0; j < 256; j++) top[j] = bb::pow(w, (u64)bitrev32(j, 8) << (log_m - 8));
+        u32* t;
+        if ((s = upload32(ctx, top, &t, &set.owned))) return s;
+        set.t.tw_top_fwd = t;
+    }
     auto res = ctx->bb_tables.emplace(log_n, std::move(set));
     *out = &res.first->second.t;
     return GB_OK;

@@ -34,6 +34,8 @@ struct GlNttTables {
     // log_n > 22: one outer radix-2^outer_bits step (ntt_outer.hpp) around transforms of log_n - outer_bits rows (`sub`); else null / 0
     const GlNttTables* sub;
     u32 outer_bits;
+    const u64* tw_top_fwd;   // log_n > 22: [256] w_n^(brev8(j) 2^(log_m - 8)), log_m = log_n - outer_bits - the factor of the outer
+                             // step's twiddle that varies over the 256 threads of a workgroup (ntt_outer.hpp k_lde_combine), contiguous
 };
 static constexpr u32 NTT_NATIVE_LOG = 22;   // largest transform the passes run without an outer step
 static constexpr u32 NTT_OUTER_MAX_BITS = 4;
@@ -104,6 +106,7 @@ struct BbNttTables {
     const BbNttTables* wide;   // log_n 22: the tables of the 2^20-row transform (k_bb_lde_pa16x2w's twiddles)
     const BbNttTables* sub;    // log_n > 22
     u32 outer_bits;
+    const u32* tw_top_fwd;     // log_n > 22: see GlNttTables
 };
 struct BbCosetTables {
     u32 rate_bits;

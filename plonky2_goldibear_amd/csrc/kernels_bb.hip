@@ -437,7 +437,7 @@ void bb_lde_columns(const u32* coeffs, u32* lde, size_t ncols, const BbNttTables
     const u32 L = t.log_n, r = ct.rate_bits;
     if (!ncols) return;
     if (t.sub) {
-        outer::lde_columns<BbF>(coeffs, lde, ncols, L, t.outer_bits, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, (u32*)*ct.work, *ct.work_bytes / sizeof(u32),
+        outer::lde_columns<BbF>(coeffs, lde, ncols, L, t.outer_bits, r, t.tw_hi_fwd, t.tw_lo_fwd, t.tw_top_fwd, ct.pow_lo, (u32*)*ct.work, *ct.work_bytes / sizeof(u32),
                                 [&](const u32* c, u32* o, size_t nc) { bb_lde_columns(c, o, nc, *t.sub, *ct.sub, stream); }, stream);
         return;
     }

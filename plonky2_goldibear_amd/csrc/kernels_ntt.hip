@@ -304,7 +304,7 @@ void gl_lde_columns(const u64* coeffs, u64* lde, size_t ncols, const GlNttTables
     const u32 L = t.log_n, r = ct.rate_bits;
     if (ncols == 0) return;
     if (t.sub) {
-        outer::lde_columns<GlF>(coeffs, lde, ncols, L, t.outer_bits, r, t.tw_hi_fwd, t.tw_lo_fwd, ct.pow_lo, (u64*)*ct.work, *ct.work_bytes / sizeof(u64),
+        outer::lde_columns<GlF>(coeffs, lde, ncols, L, t.outer_bits, r, t.tw_hi_fwd, t.tw_lo_fwd, t.tw_top_fwd, ct.pow_lo, (u64*)*ct.work, *ct.work_bytes / sizeof(u64),
                                 [&](const u64* c, u64* o, size_t nc) { gl_lde_columns(c, o, nc, *t.sub, *ct.sub, stream); }, stream);
         return;
     }

@@ -104,16 +104,21 @@ __global__ __launch_bounds__(THREADS) void k_intt_combine(typename F::T* __restr
 template <class F, u32 K>
 __global__ __launch_bounds__(THREADS) void k_lde_combine(const typename F::T* __restrict__ sub, typename F::T* __restrict__ lde, u32 log_m, u32 rate_bits,
                                                          const typename F::T* __restrict__ tw_hi, const typename F::T* __restrict__ tw_lo,
-                                                         const typename F::T* __restrict__ pow_lo, u32 nlo, typename F::T w4) {
+                                                         const typename F::T* __restrict__ tw_top, const typename F::T* __restrict__ pow_lo, u32 nlo,
+                                                         typename F::T w4) {
     typedef typename F::T T;
     constexpr u32 R = 1u << K;
+    static_assert(THREADS == 256, "tw_top holds the factor of the 256 threads of a workgroup");
     const size_t g = (size_t)blockIdx.x * THREADS + threadIdx.x;   // (col, c, q)
     const u32 q = (u32)(g & (((size_t)1 << log_m) - 1));
     const size_t cc = g >> log_m;
     const u32 c = (u32)(cc & ((1u << rate_bits) - 1));
     const size_t col = cc >> rate_bits;
-    const u32 k2 = brev_bits(q, log_m);
-    const T gk = F::mul(pow_lo[(size_t)c * nlo + 1], tw_split<F>(tw_hi, tw_lo, k2));   // s_c w_n^k2
+    // k2 = brev(q): the workgroup's 256 consecutive q are the TOP eight bits of k2 - taken from the split tables every lane of a load
+    // hit a cache line of its own (64 lines per kilobyte of data streamed: 2.9 TB/s).  w_n^k2 = tw_top[q & 255] * w_n^(the low bits),
+    // the second factor uniform over the workgroup, the first from 2 KB.
+    const u32 rest = brev_bits(q >> 8, log_m - 8);
+    const T gk = F::mul(F::mul(pow_lo[(size_t)c * nlo + 1], tw_split<F>(tw_hi, tw_lo, rest)), tw_top[threadIdx.x]);   // s_c w_n^k2
     T z[R], f = gk;
 #pragma unroll
     for (u32 i1 = 0; i1 < R; i1++) {
@@ -191,7 +196,7 @@ void intt_columns(const typename F::T* src, typename F::T* coeffs, typename F::T
 // coefficients [ncols][n] -> lde [ncols][2^r][n] (leaf order); work holds work_elems elements (>= (1 + 2^r) n for one column)
 template <class F, class SubLde>
 void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, u32 log_n, u32 K, u32 rate_bits, const typename F::T* tw_hi, const typename F::T* tw_lo,
-                 const typename F::T* pow_lo, typename F::T* work, size_t work_elems, SubLde sub_lde, hipStream_t st) {
+                 const typename F::T* tw_top, const typename F::T* pow_lo, typename F::T* work, size_t work_elems, SubLde sub_lde, hipStream_t st) {
     typedef typename F::T T;
     const u32 log_m = log_n - K;
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
@@ -203,8 +208,8 @@ void lde_columns(const typename F::T* coeffs, typename F::T* lde, size_t ncols, 
         T* wl = work + g * n;    // [g R][2^r][m] their LDEs
         launch_deinterleave<F>(K, dim3((u32)((g << log_m) / THREADS)), st, coeffs + c0 * n, wc, log_m);
         sub_lde(wc, wl, g << K);
-        launch_lde_combine<F>(K, dim3((u32)(((g << rate_bits) << log_m) / THREADS)), st, (const T*)wl, lde + c0 * N, log_m, rate_bits, tw_hi, tw_lo, pow_lo,
-                              (u32)4096, w4);
+        launch_lde_combine<F>(K, dim3((u32)(((g << rate_bits) << log_m) / THREADS)), st, (const T*)wl, lde + c0 * N, log_m, rate_bits, tw_hi, tw_lo, tw_top,
+                              pow_lo, (u32)4096, w4);
     }
 }
 
