@@ -6,11 +6,12 @@
 //   k_quotient      compute_quotient_polys + eval_vanishing_poly_base_batch for the gate set
 //                   {Noop, Constant, PublicInput}                    plonk/prover.rs:712-926, vanishing_poly.rs:177-346
 //   k_quotient_combine  the size-N coset_ifft's last radix-2^r step + chunking   prover.rs:921-925, :361-374
-//   k_eval_*        OpeningSet::new (Horner at zeta, g*zeta)         plonk/proof.rs:346-387
+//   k_ext_powtabs / k_ext_pow_tables / k_eval_*   OpeningSet::new: the powers of zeta and g*zeta (and FRI's alpha), every batch's
+//                   polynomials evaluated in two launches            plonk/proof.rs:346-387
 //   k_reduce_polys / k_divide_* / k_final_poly   prove_openings      fri/oracle.rs:187-231
 //   k_fri_*         fri_committed_trees fold + leaf hashing          fri/prover.rs:83-133
 //   k_pow_grind     fri_proof_of_work (minimum nonce)                fri/prover.rs:136-188
-//   k_gather_*      fri_prover_query_rounds                          fri/prover.rs:190-255
+//   k_query_gather  fri_prover_query_rounds: every opened row and path, one launch per twelve trees   fri/prover.rs:190-255
 // All data is column-major; LDE matrices are in leaf order (see kernels_ntt.hip).  Element data is in the
 // field's device form (F::T); digests and everything gathered for the proof bytes are canonical.
 #include "kernels.hpp"
