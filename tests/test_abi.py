@@ -68,3 +68,19 @@ def test_bench_golden_hashes_are_committed():
     for key, ch, plen in (("goldilocks_2p20", 3, 198432), ("babybear_2p20", 10, 180776)):
         e = g[key]
         assert e["log_n"] == 20 and e["num_challenges"] == ch and e["proof_len"] == plen and len(e["sha256"]) == 64
+
+
+def test_binding_asks_for_eight_hardware_queues_unless_the_host_chose():
+    """plonky2_goldibear_amd/native.py: several contexts proving at once overlap only as far as the HIP runtime has hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default, read when the runtime initialises) - the binding sets 8 at import unless the variable is set
+    (include/goldibear_gpu.h at gb_ctx_create; tools/bench_recursion_shape.py --inflight 6: 575 -> 839 proofs/s)"""
+    import subprocess
+    import sys
+    code = "import os; import plonky2_goldibear_amd.native; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    for preset, want in ((None, "8"), ("4", "4")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if preset:
+            env["GPU_MAX_HW_QUEUES"] = preset
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want

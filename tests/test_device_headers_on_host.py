@@ -44,3 +44,20 @@ def test_challenge_slices_cover_every_count(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
+
+
+def test_host_transcript_permutation_matches_the_defining_form(tmp_path):
+    """csrc/poseidon_gl_host.hpp (the Fiat-Shamir transcript's Poseidon-12: fast partial rounds with the sparse v / w_hat / M_init
+    constants, MDS rows in 128-bit accumulators) == the naive 30-round definition written from the round constants and the MDS matrix
+    alone, canonical outputs, on random and extreme states"""
+    exe = tmp_path / "poseidon_gl_host_forms"
+    shim = os.path.join(ROOT, "tests", "host_shim")
+    clang = "/opt/rocm/lib/llvm/bin/clang++"   # gl_field.hpp's limb code uses clang's __builtin_addc
+    if not os.path.exists(clang):
+        pytest.skip("needs the ROCm clang++ as the host compiler")
+    cmd = [clang, "-O2", "-std=c++17", "-include", os.path.join(shim, "shim.h"), "-I", shim,
+           "-I", os.path.join(ROOT, "plonky2_goldibear_amd", "csrc"), "-o", str(exe), os.path.join(shim, "poseidon_gl_host_forms.cpp")]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe), "20000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
